@@ -1,0 +1,131 @@
+/* tqdne_hip.h -- C ABI of libtqdne_hip.so: the MI355X (gfx950) kernels behind the tqdne 1-D EDM hot path.
+ *
+ * The reference (highfem/tqdne) has no FFI / plugin interface: its hot path is ordinary PyTorch modules
+ * (SURVEY.md section 8b).  These entry points are what a maintainer of the reference would bind (ctypes, see
+ * INTEGRATION.md) to replace the ATen op chains cited on each function.  Conventions:
+ *   - device pointers only, caller-owned memory, nothing allocated or synchronised inside;
+ *   - all work is enqueued on the given HIP stream (graph-capture safe);
+ *   - return 0 on success, a TQ_ERR_* code (negative) for bad arguments, or a hipError_t (>0) from the launch;
+ *   - re-entrant, no mutable global state: safe for one process per GPU and for several streams.
+ * Layouts: activations (B, T, C) fp32, C contiguous; network input/output (B, C, T) fp32 as in the reference;
+ * per-channel partial statistics (B, nslots, C, 2) fp32 with nslots = ceil(T / 128) and {sum, sum of squares};
+ * GroupNorm folded to per-(b, c) scale/shift (B, C) fp32:  norm(x) = scale * x + shift.
+ */
+#ifndef TQDNE_HIP_H
+#define TQDNE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define TQ_ABI_VERSION 1
+
+#define TQ_ERR_ARG (-1)   /* null / inconsistent pointer arguments */
+#define TQ_ERR_SHAPE (-2) /* unsupported shape */
+
+/* flags of TqConvDesc.flags */
+#define TQ_CONV_GN 1       /* apply gscale/gshift (folded GroupNorm32) to the input */
+#define TQ_CONV_SILU 2     /* apply SiLU to the (normalised) input */
+#define TQ_CONV_EMB 4      /* add emb[b, co] to the output (ResBlock time embedding, unet.py:141) */
+#define TQ_CONV_RES 8      /* add res[b, t, co] to the output (residual, unet.py:143 / blocks.py:145) */
+#define TQ_CONV_STATS 16   /* emit per-channel partial statistics of the output */
+#define TQ_CONV_DROPOUT 32 /* training-mode dropout on the activated input (unet.py:101) */
+
+typedef struct TqConvDesc {
+    int32_t B, T_in, T_out;
+    int32_t C_in0, C_in1; /* channels of the two concatenated sources (C_in1 = 0: single source) */
+    int32_t C_out;
+    int32_t ktaps, stride, pad;
+    int32_t upsample; /* 1: input is read through nearest x2 upsampling (T_out = 2*T_in) */
+    int32_t flags;
+    int32_t emb_stride; /* floats between consecutive samples in emb */
+    uint32_t dropout_site;
+    float dropout_p;
+    uint64_t dropout_seed;
+} TqConvDesc;
+
+int tq_abi_version(void);
+
+/* ---- weights -------------------------------------------------------------------------------------------- */
+/* Pack a torch Conv1d weight (C_out, C_in, K) fp32 into per-lane bf16 hi/lo MFMA fragments.
+ * mode 0: forward operand; mode 1: data-gradient operand (transposed + tap-flipped). */
+size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode);
+int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* packed, hipStream_t stream);
+int tq_conv_tile_co(int C_out);
+
+/* ---- fused convolution ---------------------------------------------------------------------------------- */
+/* Replaces GroupNorm32 -> SiLU -> Dropout -> Conv1d(k in {1,3,5}) -> +emb -> +residual, the channel concat and the
+ * nearest-x2 upsample of tqdne/unet.py:86-102,131-143,396 and tqdne/blocks.py:56-66,92-101,127-145.
+ * Constraints: C_in0, C_in1, C_out multiples of 32; stride 1 ("same" padding, pad = k/2) or stride 2 (k=3, pad=1). */
+int tq_conv1d_fwd(const TqConvDesc* desc, const float* x0, const float* x1, const float* gscale, const float* gshift,
+                  const void* packed_w, const float* bias, const float* emb, const float* residual, float* y,
+                  float* stats_partial, hipStream_t stream);
+
+/* First conv of the network: (B, C_in<=16, T) fp32 input, scaled per sample by in_scale[b] (EDM c_in, edm.py:107;
+ * NULL = 1), k taps "same" -> (B, T, C_out) channels-last + bias (+ partial statistics).  unet.py:233. */
+int tq_stem_conv_fwd(const float* x_nct, const float* in_scale, const float* w, const float* bias, float* y,
+                     float* stats_partial, int B, int C_in, int T, int C_out, int ktaps, hipStream_t stream);
+
+/* Last conv: GroupNorm32+SiLU (folded scale/shift) -> conv k "same" to C_out<=4 -> (B, C_out, T) output,
+ * then out = c_out[b] * conv + c_skip[b] * skip_src[b, co, t]  (EDM / consistency preconditioning, edm.py:111-113,
+ * consistency_model.py:78); c_out/c_skip/skip_src NULL = plain conv output.  unet.py:355-357,398. */
+int tq_head_conv_fwd(const float* x, const float* gscale, const float* gshift, const float* w, const float* bias,
+                     const float* c_out, const float* c_skip, const float* skip_src, float* y_nct, int B, int T, int C_in,
+                     int C_out, int ktaps, hipStream_t stream);
+
+/* ---- GroupNorm32 statistics -> folded scale/shift ---------------------------------------------------------- */
+/* The normalised tensor is the channel concat of up to two sources whose per-channel partial statistics were
+ * emitted by their producers.  Writes scale/shift (B, C0+C1) and mean/rstd (B, 32, 2).  nn.py:11-13,90-105. */
+int tq_gn_finalize(const float* stats0, int C0, const float* stats1, int C1, int B, int T, const float* gamma,
+                   const float* beta, float* gscale, float* gshift, float* mean_rstd, hipStream_t stream);
+
+/* ---- embeddings ------------------------------------------------------------------------------------------- */
+/* emb = time_mlp(fourier(t)) (+ cond_mlp(cond)); writes emb (B, E) and silu(emb) (B, E).  E = 4*mc.
+ * blocks.py:22-26, unet.py:210-227,383-388.  cond pointers NULL when the model is unconditioned. */
+int tq_embed_fwd(const float* t, const float* cond, const float* fourier_w, const float* w0, const float* b0,
+                 const float* w2, const float* b2, const float* cw0, const float* cb0, const float* cw2, const float* cb2,
+                 float* emb, float* silu_emb, float* hidden /* (B, 2, E) scratch: pre-activations, kept for backward */,
+                 int B, int mc, int ncond, hipStream_t stream);
+
+/* All per-ResBlock projections Linear(SiLU(emb)) (unet.py:91-97) as one GEMM: out (B, N) = silu_emb (B, E) W^T + bias. */
+int tq_linear_fwd(const float* x, const float* w, const float* bias, float* out, int B, int E, int N, hipStream_t stream);
+
+/* ---- attention -------------------------------------------------------------------------------------------- */
+/* QKVAttention (blocks.py:156-190), qkv (B, T, 3*H*D) channels-last with channel order [q heads | k heads | v heads],
+ * q and k each scaled by D^-1/4, softmax over keys in fp32, out (B, T, H*D).  D in {32, 64}. */
+int tq_attention_fwd(const float* qkv, float* out, int B, int T, int H, int D, hipStream_t stream);
+
+/* ---- EDM / sampler elementwise ------------------------------------------------------------------------------ */
+/* per-sample scalars from sigma: c_in, c_out, c_skip, c_noise, loss weight  (edm.py:24-37); sigma_stride 0 = shared */
+int tq_edm_scalars(const float* sigma, int sigma_stride, float sigma_data, float* c_in, float* c_out, float* c_skip,
+                   float* c_noise, float* lweight, int B, hipStream_t stream);
+/* consistency preconditioning scalars (consistency_model.py:69-74) */
+int tq_cm_scalars(const float* sigma, int sigma_stride, float sigma_data, float sigma_min, float* c_out, float* c_skip,
+                  int B, hipStream_t stream);
+/* training noise injection: sigma = exp(eps*P_std + P_mean); x = y + sigma * n   (edm.py:126-129) */
+int tq_edm_noise_inject(const float* y, const float* unit_noise, const float* eps, float P_mean, float P_std,
+                        float* sigma, float* x_noisy, int B, int n_per_sample, hipStream_t stream);
+/* loss = mean(lweight[b] * (pred - y)^2); also d loss / d pred (edm.py:131-134).  loss_out: 1 float (zeroed inside). */
+int tq_edm_loss(const float* pred, const float* y, const float* lweight, float* loss_out, float* dpred, int B,
+                int n_per_sample, hipStream_t stream);
+/* Heun sampler state updates, fp64 state / fp32 network output (edm.py:182-194).
+ * euler:   d = (x - D)/s;  x_next = x + d * (float)(s_next - s);  x32 = (float)x_next
+ * correct: d' = (x_next - D')/s_next;  x_new = x + (float)(s_next - s) * (0.5 d + 0.5 d');  x32 = (float)x_new */
+int tq_heun_euler(const double* x, const float* denoised, const float* sigma, const float* sigma_next, double* d_cur,
+                  double* x_next, float* x32, size_t n, hipStream_t stream);
+int tq_heun_correct(const double* x, const double* x_next, const float* denoised_next, const double* d_cur,
+                    const float* sigma, const float* sigma_next, double* x_out, float* x32, size_t n, hipStream_t stream);
+/* x64 = unit_noise64 * sigma0; x32 = (float)x64   (edm.py:160) */
+int tq_sampler_init(const double* unit_noise, const float* sigma0, double* x, float* x32, size_t n, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TQDNE_HIP_H */

@@ -1,0 +1,139 @@
+"""Whole-path parity (GPU): tqdne_amd modules on MI355X vs the CPU oracle and the committed golden vectors.
+Tolerance 1e-3 relative (north star), measured as max|a-b| / max|b|; observed values are printed."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import cfg_of, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def perturbed_state(model, seed):
+    """zero-init convs re-drawn and GroupNorm affines jittered (same recipe as tools/make_goldens.py)"""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        v = v.clone()
+        is_gn = v.ndim == 1 and (".in_layers.0." in k or ".out_layers.0." in k or ".norm." in k or k.startswith("out.0."))
+        if is_gn and k.endswith("weight"):
+            v = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+        elif is_gn and k.endswith("bias"):
+            v = 0.1 * torch.randn(v.shape, generator=g)
+        elif torch.count_nonzero(v) == 0:
+            v = 0.02 * torch.randn(v.shape, generator=g)
+        sd[k] = v
+    return sd
+
+
+@pytest.mark.parametrize("T", [256, 248])
+def test_unet_vs_golden_and_oracle(T):
+    from oracle import unet as OU
+    from tqdne_amd import UNetModel
+    sd, d = load_golden("micro_unet.npz")
+    cfg = cfg_of(d)
+    m = UNetModel(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev()).eval()
+    x, t, c = (torch.from_numpy(d[f"T{T}:{k}"]) for k in ("x", "t", "cond"))
+    with torch.no_grad():
+        y = m(x.to(dev()), t.to(dev()), c.to(dev())).cpu()
+        yo = OU.unet_forward(sd, cfg, x, t, c)
+    e_gold, e_orc = rel_err(y, d[f"T{T}:y"]), rel_err(y, yo)
+    print(f"micro unet T={T}: rel err vs golden {e_gold:.2e}, vs oracle {e_orc:.2e}")
+    assert e_gold < TOL and e_orc < TOL
+
+
+@pytest.mark.parametrize("which,B,T", [("tiny", 2, 4096), ("paper", 2, 4096), ("paper", 1, 4064)])
+def test_full_size_unet_vs_oracle(which, B, T):
+    from oracle import unet as OU
+    from tqdne_amd import UNetModel, paper_1d_unet_config, tiny_1d_unet_config
+    cfg = paper_1d_unet_config() if which == "paper" else tiny_1d_unet_config()
+    torch.manual_seed(0)
+    m = UNetModel(**cfg)
+    sd = perturbed_state(m, 17)
+    m.load_state_dict(sd)
+    m = m.to(dev()).eval()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, T, generator=g)
+    t = torch.randn(B, generator=g) * 0.5
+    c = torch.randn(B, 5, generator=g) if cfg["cond_features"] else None
+    taps = {}
+    with torch.no_grad():
+        y = m(x.to(dev()), t.to(dev()), c.to(dev()) if c is not None else None).cpu()
+        yo = OU.unet_forward(sd, cfg, x, t, c, taps=taps)
+    e = rel_err(y, yo)
+    print(f"{which} unet B={B} T={T}: rel err vs oracle {e:.2e}")
+    assert e < TOL
+
+
+def _edm_pair(num_steps=18):
+    from tqdne_amd import LightningEDM
+    sd, _ = load_golden("micro_unet.npz")
+    _, d = load_golden("micro_edm.npz")
+    cfg = cfg_of(d)
+    edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0}, num_sampling_steps=num_steps)
+    edm.unet.load_state_dict(sd)
+    return edm.to(dev()).eval(), d
+
+
+@pytest.mark.parametrize("sigma", [0.002, 0.5, 80.0])
+def test_edm_denoise_vs_golden(sigma):
+    edm, d = _edm_pair()
+    x = torch.from_numpy(d[f"denoise:{sigma}:x"]).to(dev())
+    with torch.no_grad():
+        y = edm(x, torch.full((x.shape[0],), sigma, device=dev()), None, torch.from_numpy(d["cond"]).to(dev()))
+    e = rel_err(y.cpu(), d[f"denoise:{sigma}:y"])
+    print(f"denoise sigma={sigma}: {e:.2e}")
+    assert e < TOL
+
+
+def test_edm_sampler_vs_golden():
+    edm, d = _edm_pair(18)
+    from oracle import edm as OE
+    sig = OE.sampling_sigmas(OE.EDMParams(), 18)
+    assert np.array_equal(sig.numpy(), d["sigmas18"])
+    start = torch.from_numpy(d["sample:start"])
+    eps = (start * sig[0]).to(dev())
+    cond = torch.from_numpy(d["cond"]).to(dev())
+    for nsteps, key in ((1, "sample:state1"), (9, "sample:state9")):
+        st = edm.sample_deterministically(eps, sig[: nsteps + 1].to(dev()), None, cond)
+        e = rel_err(st.cpu(), d[key])
+        print(f"sampler state after {nsteps} steps: {e:.2e}")
+        assert e < TOL
+    out = edm.sample_deterministically(eps, sig.to(dev()), None, cond).to(torch.float32)
+    e = rel_err(out.cpu(), d["sample:out"])
+    print(f"18-step sample (35 NFE): {e:.2e}")
+    assert e < TOL
+
+
+def test_edm_loss_value_vs_golden():
+    edm, d = _edm_pair()
+    with torch.no_grad():
+        loss = edm.step_with_noise(torch.from_numpy(d["signal"]).to(dev()), torch.from_numpy(d["step:eps"]).to(dev()),
+                                   torch.from_numpy(d["step:noise"]).to(dev()), cond=torch.from_numpy(d["cond"]).to(dev()))
+    e = rel_err(loss.cpu(), d["step:loss"])
+    print(f"loss: {e:.2e}")
+    assert e < TOL
+
+
+def test_consistency_vs_golden():
+    from tqdne_amd import LithningConsistencyModel, UNetModel
+    sd, _ = load_golden("micro_unet.npz")
+    _, d = load_golden("micro_cm.npz")
+    net = UNetModel(**cfg_of(d))
+    net.load_state_dict(sd)
+    cm = LithningConsistencyModel(net).to(dev()).eval()
+    cond = torch.from_numpy(d["cond"]).to(dev())
+    y1 = cm.sample_from(torch.from_numpy(d["start"]).to(dev()), [], [], cond=cond)
+    y2 = cm.sample_from(torch.from_numpy(d["start"]).to(dev()), [1.0], [torch.from_numpy(d["uniform"]).to(dev())], cond=cond)
+    e1, e2 = rel_err(y1.cpu(), d["one_step"]), rel_err(y2.cpu(), d["refined"])
+    print(f"consistency 1-step {e1:.2e}, refined {e2:.2e}")
+    assert e1 < TOL and e2 < TOL

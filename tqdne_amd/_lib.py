@@ -1,0 +1,100 @@
+"""ctypes binding of libtqdne_hip.so (include/tqdne_hip.h).  Fails loudly: there is no CPU or
+PyTorch fallback for the hot path -- if the library is missing the product raises."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+_LIB = None
+
+c_f32p = C.c_void_p  # device pointers travel as integers
+VP = C.c_void_p
+I = C.c_int
+F = C.c_float
+SZ = C.c_size_t
+
+TQ_CONV_GN, TQ_CONV_SILU, TQ_CONV_EMB, TQ_CONV_RES, TQ_CONV_STATS, TQ_CONV_DROPOUT = 1, 2, 4, 8, 16, 32
+STAT_SLOT = 128
+
+
+class TqConvDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T_in", C.c_int32), ("T_out", C.c_int32),
+        ("C_in0", C.c_int32), ("C_in1", C.c_int32), ("C_out", C.c_int32),
+        ("ktaps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("upsample", C.c_int32), ("flags", C.c_int32), ("emb_stride", C.c_int32),
+        ("dropout_site", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+    ]
+
+
+_PROTOS = {
+    "tq_abi_version": (I, []),
+    "tq_conv_weight_pack_bytes": (SZ, [I, I, I, I]),
+    "tq_pack_conv_weight": (I, [VP, I, I, I, I, VP, VP]),
+    "tq_conv_tile_co": (I, [I]),
+    "tq_conv1d_fwd": (I, [C.POINTER(TqConvDesc)] + [VP] * 11),
+    "tq_stem_conv_fwd": (I, [VP] * 6 + [I] * 5 + [VP]),
+    "tq_head_conv_fwd": (I, [VP] * 9 + [I] * 5 + [VP]),
+    "tq_gn_finalize": (I, [VP, I, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
+    "tq_embed_fwd": (I, [VP] * 14 + [I, I, I, VP]),
+    "tq_linear_fwd": (I, [VP] * 4 + [I, I, I, VP]),
+    "tq_attention_fwd": (I, [VP, VP, I, I, I, I, VP]),
+    "tq_edm_scalars": (I, [VP, I, F, VP, VP, VP, VP, VP, I, VP]),
+    "tq_cm_scalars": (I, [VP, I, F, F, VP, VP, I, VP]),
+    "tq_edm_noise_inject": (I, [VP, VP, VP, F, F, VP, VP, I, I, VP]),
+    "tq_edm_loss": (I, [VP, VP, VP, VP, VP, I, I, VP]),
+    "tq_heun_euler": (I, [VP] * 7 + [SZ, VP]),
+    "tq_heun_correct": (I, [VP] * 8 + [SZ, VP]),
+    "tq_sampler_init": (I, [VP] * 4 + [SZ, VP]),
+}
+
+# entry points of later rounds are optional at load time but listed in the header check
+_OPTIONAL = {}
+
+
+def lib_path() -> str:
+    return _build.LIBPATH
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the tqdne_amd hot path is HIP-only (no CPU / PyTorch fallback). "
+            "Build it with `python -m tqdne_amd._build` (needs hipcc, cross-compiles gfx950 without a GPU)."
+        )
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError = header/library mismatch: loud
+        fn.restype = res
+        fn.argtypes = args
+    for name, (res, args) in _OPTIONAL.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    if lib.tq_abi_version() != 1:
+        raise RuntimeError("libtqdne_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(list(_PROTOS) + list(_OPTIONAL))
+
+
+class TqError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        kind = {-1: "TQ_ERR_ARG", -2: "TQ_ERR_SHAPE"}.get(rc, f"hipError_t {rc}")
+        raise TqError(f"libtqdne_hip: {what} failed with {kind}")

@@ -1,0 +1,69 @@
+"""torch.autograd bridges: the HIP forward/backward of the EDM training step exposed as autograd Functions so
+that ``loss.backward()`` / Lightning / DDP see ordinary parameter gradients.  The arithmetic is entirely in
+libtqdne_hip.so; autograd only routes the resulting gradient tensors."""
+
+from __future__ import annotations
+
+import torch as th
+
+from . import _lib
+from ._lib import check
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+_step_counter = [0]
+
+
+class _EDMLossFn(th.autograd.Function):
+    """loss = mean(lambda(sigma) * (D(y + sigma*n; sigma) - y)^2)   (reference edm.py:126-134)."""
+
+    @staticmethod
+    def forward(ctx, module, sample, eps, unit_noise, cond, *params):
+        lib = _lib.load()
+        B = sample.shape[0]
+        per = sample[0].numel()
+        dev = sample.device
+        stream = th.cuda.current_stream(dev).cuda_stream
+        key = ("train", tuple(sample.shape), str(dev))
+        bufs = module._scal.get(key)
+        if bufs is None:
+            bufs = dict(sigma=th.empty(B, device=dev), x=th.empty_like(sample), loss=th.empty(1, device=dev),
+                        dpred=th.empty_like(sample))
+            module._scal[key] = bufs
+        e = module.edm
+        check(lib.tq_edm_noise_inject(_p(sample), _p(unit_noise), _p(eps), float(e.P_mean), float(e.P_std), _p(bufs["sigma"]),
+                                      _p(bufs["x"]), B, per, stream), "noise inject")
+        train = module.training
+        _step_counter[0] += 1
+        seed = (int(th.initial_seed()) * 1000003 + _step_counter[0]) & 0xFFFFFFFFFFFFFFFF
+        pred = module._denoise_static(bufs["x"], bufs["sigma"], 1, cond, train=train, dropout_seed=seed)
+        sc = module._scalars(B, dev)
+        need_grad = any(p.requires_grad for p in params)
+        check(lib.tq_edm_loss(_p(pred), _p(sample), _p(sc[4]), _p(bufs["loss"]), _p(bufs["dpred"]) if need_grad else None, B,
+                              per, stream), "edm loss")
+        ctx.module, ctx.bufs, ctx.shape, ctx.nparams = module, bufs, tuple(sample.shape), len(params)
+        ctx.cond = cond
+        return bufs["loss"][0].clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        module, bufs = ctx.module, ctx.bufs
+        B, _, T = ctx.shape
+        eng = module.unet._engine(B, T, bufs["x"].device)
+        sc = module._scalars(B, bufs["x"].device)
+        grads = eng.backward(bufs["dpred"], gloss, c_out=sc[1], in_scale=sc[0])
+        return (None, None, None, None, None) + tuple(grads)
+
+
+def edm_loss(module, sample, eps, unit_noise, cond):
+    params = [p for p in module.unet.parameters()]
+    return _EDMLossFn.apply(module, sample, eps, unit_noise, cond, *params)
+
+
+def denoise_with_grad(module, sample, sigma, cond):
+    raise NotImplementedError(
+        "LightningEDM.forward under autograd is only differentiable through LightningEDM.step (fused loss + backward)"
+    )

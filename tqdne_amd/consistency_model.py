@@ -1,0 +1,70 @@
+"""Consistency-model sampler: drop-in for the forward / sample part of ``tqdne.consistency_model``
+(reference tqdne/consistency_model.py:63-106).  The network is a ``tqdne_amd.UNetModel``; the consistency
+skip/out scalings are folded into the head-conv epilogue, and the raw sigma is the network's timestep (line 77).
+Training (``step``, iCT) is not part of BASELINE.json's configs and is not implemented."""
+
+from __future__ import annotations
+
+import torch
+
+from . import _lib, engine
+from ._lib import check
+from .lightning_compat import LightningModule
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class LithningConsistencyModel(LightningModule):  # (sic) the reference's class name
+    def __init__(self, net, sigma_min=0.002, sigma_max=80.0, rho=7.0, sigma_data=0.5, initial_timesteps=10,
+                 final_timesteps=1280, lognormal_mean=-1.1, lognormal_std=2.0, lr=1e-4):
+        super().__init__()
+        self.net = net
+        self.sigma_min, self.sigma_max, self.rho, self.sigma_data = sigma_min, sigma_max, rho, sigma_data
+        self.initial_timesteps, self.final_timesteps = initial_timesteps, final_timesteps
+        self.lognormal_mean, self.lognormal_std, self.lr = lognormal_mean, lognormal_std, lr
+        self._scal = {}
+
+    def _forward_static(self, sample, sigma, cond):
+        lib = _lib.load()
+        B, _, T = sample.shape
+        dev = sample.device
+        key = (B, str(dev))
+        sc = self._scal.get(key)
+        if sc is None:
+            sc = torch.empty(2, B, device=dev)
+            self._scal[key] = sc
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        check(lib.tq_cm_scalars(_p(sigma), 1, float(self.sigma_data), float(self.sigma_min), _p(sc[0]), _p(sc[1]), B, stream),
+              "cm scalars")
+        eng = self.net._engine(B, T, dev)
+        return eng.forward(sample, sigma, cond, in_scale=None, c_out=sc[0], c_skip=sc[1], skip_src=sample)
+
+    def forward(self, sample, sigma, cond_sample=None, cond=None):
+        """consistency_model.py:63-79."""
+        engine.require_device(sample)
+        if cond_sample is not None:
+            raise NotImplementedError("cond_sample concatenation is not used by any 1-D consistency config")
+        return self._forward_static(sample.contiguous(), sigma.contiguous().float(), cond).clone()
+
+    @torch.no_grad()
+    def sample(self, shape, sigmas=[1.0], cond_sample=None, cond=None):
+        """consistency_model.py:81-106 (the refinement noise is uniform, ``rand_like``, as in the reference)."""
+        epsilon = torch.randn(shape, device=self.device)
+        return self.sample_from(epsilon, sigmas, [torch.rand_like(epsilon) for _ in sigmas], cond_sample, cond)
+
+    @torch.no_grad()
+    def sample_from(self, epsilon, sigmas, uniform_noises, cond_sample=None, cond=None):
+        ones = torch.ones(epsilon.shape[0], device=epsilon.device)
+        sample = self(epsilon, ones * self.sigma_max, cond_sample, cond)
+        for sigma, u in zip(sigmas, uniform_noises):
+            sample = sample + u * sigma
+            sample = self(sample, ones * sigma, cond_sample, cond)
+        return sample
+
+    def evaluate(self, batch, sigmas=[1]):
+        sample = batch["signal"]
+        cond_sample = batch["cond_signal"] if "cond_signal" in batch else None
+        cond = batch["cond"] if "cond" in batch else None
+        return self.sample(sample.shape, sigmas, cond_sample, cond)

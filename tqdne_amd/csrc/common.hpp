@@ -1,0 +1,86 @@
+// Shared device helpers for the tqdne gfx950 kernels.
+// Written for CDNA4 (MI355X) only: wave64, MFMA 16x16x32 bf16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tq {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+// Activations live in HBM as (B, T, C) fp32 with C contiguous ("channels-last").
+// GroupNorm always has 32 groups, eps 1e-5 (reference tqdne/nn.py:11-13, 90-105).
+constexpr int GN_GROUPS = 32;
+constexpr float GN_EPS = 1e-5f;
+// Per-channel partial statistics are produced per 128-position slot of T.
+constexpr int STAT_SLOT = 128;
+
+__device__ __forceinline__ float silu_f(float u) {
+    // u * sigmoid(u); v_exp + v_rcp, a few ulp (reference: nn.SiLU in fp32)
+    return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+}
+__device__ __forceinline__ float dsilu_f(float u) {
+    // d/du [u*sigmoid(u)] = s*(1 + u*(1-s))
+    float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+    return s * (1.0f + u * (1.0f - s));
+}
+
+// fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative.  Three bf16 MFMA
+// products (hi*hi + hi*lo + lo*hi) then reproduce an fp32 product to ~2^-16: the
+// "bf16x3" scheme.  gfx950 has no xf32/TF32 MFMA; exact-f32 MFMA runs at 1/16 of the
+// bf16 rate, so three bf16 products are >5x faster at better-than-TF32 accuracy.
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+
+union Frag {
+    bf16x8 v;
+    uint4 u;
+    uint2 h[2];
+};
+
+__device__ __forceinline__ f32x4 mfma_bf16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// 3-product accumulate: c += (ah+al)*(bh+bl) minus the al*bl term.
+__device__ __forceinline__ f32x4 mfma_x3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 c) {
+    c = mfma_bf16(al, bh, c);
+    c = mfma_bf16(ah, bl, c);
+    c = mfma_bf16(ah, bh, c);
+    return c;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// counter-based dropout RNG: keep-decision for element index `idx` of site `site`.
+// (murmur3-style finaliser over a 64-bit counter; same function is re-evaluated in backward)
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint32_t site, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1) + idx * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+
+}  // namespace tq
+
+#define TQ_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)

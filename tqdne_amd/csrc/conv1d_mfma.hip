@@ -1,0 +1,470 @@
+// Fused 1-D convolution for the tqdne UNet on gfx950 (MI355X).
+//
+//   y[b,t,co] = bias[co] + emb[b,co] + res[b,t,co]
+//             + sum_{k,ci} W[co,ci,k] * f(x[b, t*stride + k - pad, ci])
+//   f(v) = dropout(SiLU(gscale[b,ci]*v + gshift[b,ci]))      (each stage optional)
+//
+// replaces, per call, the reference's GroupNorm32 -> SiLU -> Dropout -> Conv1d -> (+emb) -> (+skip)
+// chain (tqdne/unet.py:86-102,131-143; tqdne/blocks.py:56-66,92-101,127-145), the channel concat
+// of unet.py:396 (two source tensors, never materialised) and F.interpolate(nearest, x2) of
+// blocks.py:63 (folded into the gather index).  It also emits per-channel partial sums
+// (sum, sum of squares) of y per 128-position slot so the *next* GroupNorm needs no pass over y.
+//
+// Mapping to CDNA4:
+//   * implicit GEMM D[co][t] += W[co][ci,k] * X[ci,k][t] on v_mfma_f32_16x16x32_bf16, fp32 operands split
+//     into bf16 hi/lo and multiplied as hi*hi + hi*lo + lo*hi (fp32 accumulate): gfx950 has no TF32/xf32,
+//     and exact-f32 MFMA is 16x slower than bf16 MFMA.
+//   * A operand (weights) is pre-packed per lane (tq_pack_conv_weight) and streamed straight from L2 into
+//     registers: waves of a workgroup are split along co, so no wave re-reads another wave's weights.
+//   * B operand (activations) is staged through LDS once per 32-channel chunk: 16-byte coalesced fp32
+//     loads of channels-last rows, GN/SiLU/dropout/split in registers, 8-byte LDS stores into an
+//     XOR-swizzled [row][8 x 8B] image that both ds_write_b64 and the two ds_read_b64 per fragment hit
+//     conflict-free for any tap shift.  The K taps are row shifts of the same LDS image (no im2col).
+//   * double-buffered LDS, global loads for chunk c+1 issued before the MFMAs of chunk c.
+//   * epilogue: accumulator lane = 4 consecutive co at one t -> one 16-byte store per 16x16 tile.
+#include "common.hpp"
+#include "../../include/tqdne_hip.h"
+
+using namespace tq;
+
+namespace {
+
+struct ConvArgs {
+    const float* x0;
+    const float* x1;
+    const float* gscale;
+    const float* gshift;
+    const uint4* wpk;
+    const float* bias;
+    const float* emb;
+    const float* res;
+    float* y;
+    float* stats;
+    int B, T_in, T_out, C0, C1, C_out;
+    int emb_stride, flags, ncob_pad, nslots;
+    uint32_t drop_site;
+    uint32_t drop_thresh;  // keep if hash >= thresh
+    float drop_scale;      // 1/(1-p)
+    uint64_t drop_seed;
+};
+
+template <int KT, int STRIDE, int UPS, int WM, int WN>
+struct Cfg {
+    static constexpr int NTHR = 64 * WM * WN;
+    static constexpr int NT = 128 * WN;  // output positions per workgroup
+    static constexpr int MT = 32 * WM;   // output channels per workgroup
+    static constexpr int ROWS = (STRIDE == 1) ? (NT + KT - 1) : (2 * NT + 1);
+    static constexpr int NIT = (ROWS * 8 + NTHR - 1) / NTHR;
+    static constexpr int PRE = NIT < 5 ? NIT : 5;  // staging iterations prefetched into registers across the MFMA phase
+    static constexpr int SYNC_BATCH = 4;           // the rest is loaded+written synchronously in batches
+    static constexpr int PLANE = ROWS * 64;       // bytes per hi (or lo) plane
+    static constexpr int BUF = 2 * PLANE;         // hi + lo
+    static constexpr int LDS_BYTES = 2 * BUF;     // double buffered
+    static constexpr int PAD = (STRIDE == 1) ? (KT / 2) : 1;
+};
+
+template <int KT, int STRIDE, int UPS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
+    using C = Cfg<KT, STRIDE, UPS, WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+
+    const int n_ttiles = (p.T_out + C::NT - 1) / C::NT;
+    const int n_ctiles = (p.C_out + C::MT - 1) / C::MT;
+    int bid = blockIdx.x;
+    const int ct = bid % n_ctiles;
+    bid /= n_ctiles;
+    const int tt = bid % n_ttiles;
+    const int b = bid / n_ttiles;
+    const int t0 = tt * C::NT;
+    const int co_wave = ct * C::MT + wm * 32;
+    const bool wave_active = co_wave < p.C_out;
+
+    const int Cin = p.C0 + p.C1;
+    const int nchunks = Cin >> 5;
+    const int T_src = UPS ? 2 * p.T_in : p.T_in;  // extent of the (virtually upsampled) input
+
+    // ---- staging bookkeeping: thread owns 4 consecutive channels (m) of rows i = (tid + it*NTHR) >> 3
+    const int m = tid & 7;
+    const int pslot = ((m & 1) << 2) | (m >> 1);  // logical 8-byte slot: half*4 + kq
+    float4 raw[C::PRE];
+    float4 g_a, g_s;
+
+    auto src_pos = [&](int i) -> int __attribute__((always_inline)) {
+        if (STRIDE == 1) return t0 - C::PAD + i;
+        // de-interleaved image: rows [0, NT] hold even offsets v=2*idx, rows [NT+1, 2NT] odd offsets
+        const int par = (i > C::NT) ? 1 : 0;
+        const int idx = i - par * (C::NT + 1);
+        return 2 * t0 - C::PAD + 2 * idx + par;
+    };
+
+    auto chunk_base = [&](int chunk, int& cs) -> const float* __attribute__((always_inline)) {
+        const int cb = chunk << 5;
+        const float* src;
+        int coff;
+        if (cb < p.C0) { src = p.x0; cs = p.C0; coff = cb; }
+        else           { src = p.x1; cs = p.C1; coff = cb - p.C0; }
+        return src + (size_t)b * p.T_in * cs + coff + 4 * m;
+    };
+
+    auto load_one = [&](const float* base, int cs, int it) -> float4 __attribute__((always_inline)) {
+        const int i = (tid + it * C::NTHR) >> 3;
+        const int pos = src_pos(i);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < C::ROWS && pos >= 0 && pos < T_src) {
+            const int srow = UPS ? (pos >> 1) : pos;
+            v = *reinterpret_cast<const float4*>(base + (size_t)srow * cs);
+        }
+        return v;
+    };
+
+    auto write_one = [&](int chunk, int buf, int it, const float4& rv) __attribute__((always_inline)) {
+        unsigned char* hi_plane = lds + buf * C::BUF;
+        unsigned char* lo_plane = hi_plane + C::PLANE;
+        const int cb = chunk << 5;
+        const int i = (tid + it * C::NTHR) >> 3;
+        if (i >= C::ROWS) return;
+        const int pos = src_pos(i);
+        float u[4] = {rv.x, rv.y, rv.z, rv.w};
+        const bool inside = (pos >= 0 && pos < T_src);
+        if (inside) {
+            if (p.flags & TQ_CONV_GN) {
+                u[0] = g_a.x * u[0] + g_s.x; u[1] = g_a.y * u[1] + g_s.y;
+                u[2] = g_a.z * u[2] + g_s.z; u[3] = g_a.w * u[3] + g_s.w;
+            }
+            if (p.flags & TQ_CONV_SILU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = silu_f(u[j]);
+            }
+            if (p.flags & TQ_CONV_DROPOUT) {
+                const uint64_t e0 = ((uint64_t)b * T_src + pos) * Cin + cb + 4 * m;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    u[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? u[j] * p.drop_scale : 0.f;
+            }
+        }
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __bf16 hh, ll;
+            split_bf16(u[j], hh, ll);
+            h[j] = hh; l[j] = ll;
+        }
+        const int off = i * 64 + ((pslot ^ (2 * ((i >> 2) & 3))) << 3);
+        *reinterpret_cast<bf16x4*>(hi_plane + off) = h;
+        *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
+    };
+
+    // phase 1 (before the MFMAs of the previous chunk): issue the first PRE iterations' loads
+    auto stage_load = [&](int chunk) __attribute__((always_inline)) {
+        int cs;
+        const float* base = chunk_base(chunk, cs);
+#pragma unroll
+        for (int it = 0; it < C::PRE; ++it) raw[it] = load_one(base, cs, it);
+        if (p.flags & TQ_CONV_GN) {
+            const int cb = chunk << 5;
+            g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
+            g_s = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cb + 4 * m);
+        }
+    };
+
+    // phase 2 (after them): transform + LDS write; iterations beyond PRE are loaded here in small batches
+    auto stage_write = [&](int chunk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < C::PRE; ++it) write_one(chunk, buf, it, raw[it]);
+        if (C::NIT > C::PRE) {
+            int cs;
+            const float* base = chunk_base(chunk, cs);
+#pragma unroll 1
+            for (int it0 = C::PRE; it0 < C::NIT; it0 += C::SYNC_BATCH) {
+                float4 tmp[C::SYNC_BATCH];
+#pragma unroll
+                for (int j = 0; j < C::SYNC_BATCH; ++j) tmp[j] = load_one(base, cs, it0 + j);
+#pragma unroll
+                for (int j = 0; j < C::SYNC_BATCH; ++j) write_one(chunk, buf, it0 + j, tmp[j]);
+            }
+        }
+    };
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int kq = lane >> 4;
+    const int tl_lane = wn * 128 + (lane & 15);
+    const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * 2) * 64 + lane;
+    const size_t wstep = (size_t)p.ncob_pad * 2 * 64;  // uint4 per (chunk, tap)
+
+    auto load_w = [&](int step, Frag (&ah)[2], Frag (&al)[2]) __attribute__((always_inline)) {
+        const uint4* wp = wbase + (size_t)step * wstep;
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+            ah[cbk].u = wp[(cbk * 2 + 0) * 64];
+            al[cbk].u = wp[(cbk * 2 + 1) * 64];
+        }
+    };
+    const int nsteps = nchunks * KT;
+
+    auto mma_tap = [&](int k, const unsigned char* hi_plane, const unsigned char* lo_plane, const Frag (&ah)[2],
+                       const Frag (&al)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tb = 0; tb < 8; ++tb) {
+            const int tl = tl_lane + tb * 16;
+            const int row = (STRIDE == 1) ? (tl + k) : ((k & 1) * (C::NT + 1) + tl + (k >> 1));
+            const int sw = 2 * ((row >> 2) & 3);
+            const int o0 = row * 64 + ((kq ^ sw) << 3);
+            const int o1 = row * 64 + (((4 + kq) ^ sw) << 3);
+            Frag bh, bl;
+            bh.h[0] = *reinterpret_cast<const uint2*>(hi_plane + o0);
+            bh.h[1] = *reinterpret_cast<const uint2*>(hi_plane + o1);
+            bl.h[0] = *reinterpret_cast<const uint2*>(lo_plane + o0);
+            bl.h[1] = *reinterpret_cast<const uint2*>(lo_plane + o1);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = mfma_x3(ah[cbk].v, al[cbk].v, bh.v, bl.v, acc[cbk][tb]);
+        }
+    };
+
+    // weight fragments for step s = chunk*KT + tap are prefetched one step ahead (register double buffer)
+    Frag wa_h[2], wa_l[2], wb_h[2], wb_l[2];
+    auto compute = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const unsigned char* hi_plane = lds + buf * C::BUF;
+        const unsigned char* lo_plane = hi_plane + C::PLANE;
+        const int s0 = chunk * KT;
+        if (KT == 1) {
+            load_w(s0, wa_h, wa_l);
+            mma_tap(0, hi_plane, lo_plane, wa_h, wa_l);
+        } else {
+            // KT odd: taps 0..KT-2 in pairs (a,b), last tap alone on buffer a
+            load_w(s0, wa_h, wa_l);
+#pragma unroll 1
+            for (int k = 0; k + 1 < KT; k += 2) {
+                load_w(s0 + k + 1, wb_h, wb_l);
+                mma_tap(k, hi_plane, lo_plane, wa_h, wa_l);
+                load_w(s0 + k + 2, wa_h, wa_l);
+                mma_tap(k + 1, hi_plane, lo_plane, wb_h, wb_l);
+            }
+            mma_tap(KT - 1, hi_plane, lo_plane, wa_h, wa_l);
+        }
+    };
+    (void)nsteps;
+
+    // ---- main loop over 32-channel chunks
+    stage_load(0);
+    stage_write(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1) < nchunks;
+        if (more) stage_load(c + 1);
+        if (wave_active) compute(c, c & 1);
+        if (more) stage_write(c + 1, (c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    if (!wave_active) return;
+    const int slot = (t0 >> 7) + wn;
+    const float* emb_b = (p.flags & TQ_CONV_EMB) ? p.emb + (size_t)b * p.emb_stride : nullptr;
+#pragma unroll
+    for (int cbk = 0; cbk < 2; ++cbk) {
+        const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+        float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) add = *reinterpret_cast<const float4*>(p.bias + co);
+        if (emb_b) {
+            const float4 e = *reinterpret_cast<const float4*>(emb_b + co);
+            add.x += e.x; add.y += e.y; add.z += e.z; add.w += e.w;
+        }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tb = 0; tb < 8; ++tb) {
+            const int t = t0 + wn * 128 + tb * 16 + (lane & 15);
+            if (t < p.T_out) {
+                const size_t o = ((size_t)b * p.T_out + t) * p.C_out + co;
+                float4 v = make_float4(acc[cbk][tb][0] + add.x, acc[cbk][tb][1] + add.y,
+                                       acc[cbk][tb][2] + add.z, acc[cbk][tb][3] + add.w);
+                if (p.flags & TQ_CONV_RES) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                *reinterpret_cast<float4*>(p.y + o) = v;
+                s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+                s2[0] += v.x * v.x; s2[1] += v.y * v.y; s2[2] += v.z * v.z; s2[3] += v.w * v.w;
+            }
+        }
+        if (p.flags & TQ_CONV_STATS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[j] += __shfl_xor(s1[j], o);
+                    s2[j] += __shfl_xor(s2[j], o);
+                }
+            }
+            if ((lane & 15) == 0) {
+                float* st = p.stats + (((size_t)b * p.nslots + slot) * p.C_out + co) * 2;
+                *reinterpret_cast<float4*>(st) = make_float4(s1[0], s2[0], s1[1], s2[1]);
+                *reinterpret_cast<float4*>(st + 4) = make_float4(s1[2], s2[2], s1[3], s2[3]);
+            }
+        }
+    }
+}
+
+template <int KT, int STRIDE, int UPS, int WM, int WN>
+int launch(const ConvArgs& a, hipStream_t stream) {
+    using C = Cfg<KT, STRIDE, UPS, WM, WN>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int n_ttiles = (a.T_out + C::NT - 1) / C::NT;
+    const int n_ctiles = (a.C_out + C::MT - 1) / C::MT;
+    const unsigned grid = (unsigned)(a.B * n_ttiles * n_ctiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, a);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int KT, int STRIDE, int UPS>
+int dispatch_tile(const ConvArgs& a, hipStream_t s) {
+    if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1>(a, s);
+    if constexpr (STRIDE == 1) {
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 2>(a, s);
+    } else {
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 1>(a, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int tq_conv_tile_co(int C_out) {
+    // output-channel tile the dispatcher will use; packed weights are padded to it
+    if (C_out % 128 == 0) return 128;
+    if (C_out % 64 == 0) return 64;
+    return 32;
+}
+
+extern "C" int tq_conv1d_fwd(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale,
+                             const float* gshift, const void* wpk, const float* bias, const float* emb,
+                             const float* res, float* y, float* stats, hipStream_t stream) {
+    if (!d || !x0 || !wpk || !y) return TQ_ERR_ARG;
+    if (d->C_in0 <= 0 || d->C_in0 % 32 || d->C_in1 < 0 || d->C_in1 % 32 || d->C_out <= 0 || d->C_out % 32) return TQ_ERR_SHAPE;
+    if (d->C_in1 > 0 && !x1) return TQ_ERR_ARG;
+    if ((d->flags & TQ_CONV_GN) && (!gscale || !gshift)) return TQ_ERR_ARG;
+    if ((d->flags & TQ_CONV_EMB) && !emb) return TQ_ERR_ARG;
+    if ((d->flags & TQ_CONV_RES) && !res) return TQ_ERR_ARG;
+    if ((d->flags & TQ_CONV_STATS) && !stats) return TQ_ERR_ARG;
+    if (d->B <= 0 || d->T_in <= 0 || d->T_out <= 0) return TQ_ERR_SHAPE;
+    if (d->stride == 1) {
+        const int Tsrc = d->upsample ? 2 * d->T_in : d->T_in;
+        if (d->T_out != Tsrc || d->pad != d->ktaps / 2) return TQ_ERR_SHAPE;
+    } else if (d->stride == 2) {
+        if (d->ktaps != 3 || d->pad != 1 || d->upsample || d->T_out != (d->T_in + 2 - 3) / 2 + 1) return TQ_ERR_SHAPE;
+    } else {
+        return TQ_ERR_SHAPE;
+    }
+    ConvArgs a;
+    a.x0 = x0; a.x1 = x1; a.gscale = gscale; a.gshift = gshift;
+    a.wpk = reinterpret_cast<const uint4*>(wpk);
+    a.bias = bias; a.emb = emb; a.res = res; a.y = y; a.stats = stats;
+    a.B = d->B; a.T_in = d->T_in; a.T_out = d->T_out; a.C0 = d->C_in0; a.C1 = d->C_in1; a.C_out = d->C_out;
+    a.emb_stride = d->emb_stride; a.flags = d->flags;
+    const int tile = tq_conv_tile_co(d->C_out);
+    a.ncob_pad = ((d->C_out + tile - 1) / tile) * tile / 16;
+    a.nslots = (d->T_out + STAT_SLOT - 1) / STAT_SLOT;
+    a.drop_site = d->dropout_site;
+    a.drop_seed = d->dropout_seed;
+    float pdrop = d->dropout_p;
+    if (!(d->flags & TQ_CONV_DROPOUT) || pdrop <= 0.f) { a.flags &= ~TQ_CONV_DROPOUT; pdrop = 0.f; }
+    if (pdrop >= 1.f) return TQ_ERR_ARG;
+    a.drop_thresh = (uint32_t)((double)pdrop * 4294967296.0);
+    a.drop_scale = 1.0f / (1.0f - pdrop);
+
+    if (d->stride == 2) return dispatch_tile<3, 2, 0>(a, stream);
+    if (d->upsample) {
+        if (d->ktaps == 5) return dispatch_tile<5, 1, 1>(a, stream);
+        if (d->ktaps == 3) return dispatch_tile<3, 1, 1>(a, stream);
+        return TQ_ERR_SHAPE;
+    }
+    switch (d->ktaps) {
+        case 1: return dispatch_tile<1, 1, 0>(a, stream);
+        case 3: return dispatch_tile<3, 1, 0>(a, stream);
+        case 5: return dispatch_tile<5, 1, 0>(a, stream);
+        default: return TQ_ERR_SHAPE;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing: torch Conv1d weight (C_out, C_in, K) fp32 -> per-lane MFMA A fragments, bf16 hi/lo.
+//   packed[((chunk*K + tap) * ncob_pad + cob) * 2 + hl][lane][8]   (8 bf16 = 16 bytes)
+//   lane l holds A[row = cob*16 + (l&15)][k = chunk*32 + 8*(l>>4) + j], j = 0..7
+// mode 0: A[row=co][k=ci] = W[co][ci][tap]                           (forward)
+// mode 1: A[row=ci][k=co] = W[co][ci][K-1-tap]                       (data gradient: transposed, flipped)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int mode,
+                                        int rows, int kdim, int ncob_pad, uint4* __restrict__ out) {
+    const int nchunks = (kdim + 31) / 32;
+    const size_t total = (size_t)nchunks * K * ncob_pad * 64;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int lane = gid & 63;
+    size_t r = gid >> 6;
+    const int cob = r % ncob_pad; r /= ncob_pad;
+    const int tap = r % K;
+    const int chunk = r / K;
+    const int row = cob * 16 + (lane & 15);
+    Frag hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kk = chunk * 32 + 8 * (lane >> 4) + j;
+        float v = 0.f;
+        if (row < rows && kk < kdim) {
+            if (mode == 0) v = w[((size_t)row * C_in + kk) * K + tap];
+            else           v = w[((size_t)kk * C_in + row) * K + (K - 1 - tap)];
+        }
+        __bf16 h, l;
+        split_bf16(v, h, l);
+        hi.v[j] = h; lo.v[j] = l;
+    }
+    const size_t o = ((((size_t)chunk * K + tap) * ncob_pad + cob) * 2) * 64 + lane;
+    out[o] = hi.u;
+    out[o + 64] = lo.u;
+}
+}  // namespace
+
+extern "C" size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode) {
+    const int rows = mode == 0 ? C_out : C_in;
+    const int kdim = mode == 0 ? C_in : C_out;
+    const int tile = tq_conv_tile_co(rows);
+    const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
+    const int nchunks = (kdim + 31) / 32;
+    return (size_t)nchunks * K * ncob_pad * 2 * 64 * 16;
+}
+
+extern "C" int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* out, hipStream_t stream) {
+    if (!w || !out || C_out <= 0 || C_in <= 0 || K <= 0 || (mode != 0 && mode != 1)) return TQ_ERR_ARG;
+    const int rows = mode == 0 ? C_out : C_in;
+    const int kdim = mode == 0 ? C_in : C_out;
+    const int tile = tq_conv_tile_co(rows);
+    const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
+    const int nchunks = (kdim + 31) / 32;
+    const size_t total = (size_t)nchunks * K * ncob_pad * 64;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid), dim3(256), 0, stream, w, C_out, C_in, K, mode, rows, kdim,
+                       ncob_pad, reinterpret_cast<uint4*>(out));
+    TQ_CHECK_LAUNCH();
+    return 0;
+}

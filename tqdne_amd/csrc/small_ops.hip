@@ -1,0 +1,586 @@
+// Memory-bound side kernels of the tqdne hot path on gfx950: GroupNorm statistics finalisation, the
+// NCW<->channels-last boundary convolutions (3-channel stem and head), embedding MLPs, EDM scalar maps,
+// noise injection / loss, and the fp64 Heun state updates.  All are plain wave64 VALU kernels with
+// 16-byte coalesced accesses; none is GEMM-shaped enough to be worth MFMA.
+#include "common.hpp"
+#include "../../include/tqdne_hip.h"
+
+using namespace tq;
+
+extern "C" int tq_abi_version(void) { return TQ_ABI_VERSION; }
+
+// =================================================================================================
+// GroupNorm32 finalisation: per-channel partial (sum, sumsq) of up to two concatenated sources ->
+// folded per-(b,c) scale/shift.  One workgroup per sample.  Sums are combined in fp64 so that
+// var = E[x^2] - mean^2 does not cancel (the partials themselves are fp32 sums over <= 128 positions).
+// =================================================================================================
+namespace {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ st0, int C0,
+                                                          const float* __restrict__ st1, int C1, int T, int nslots,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ gscale, float* __restrict__ gshift,
+                                                          float* __restrict__ mean_rstd) {
+    extern __shared__ double sh[];  // [C][2] channel sums, then [32][2] group mean/rstd
+    const int C = C0 + C1;
+    const int b = blockIdx.x;
+    double* csum = sh;
+    double* gstat = sh + 2 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float* st;
+        int cs, cc;
+        if (c < C0) { st = st0; cs = C0; cc = c; } else { st = st1; cs = C1; cc = c - C0; }
+        const float* pp = st + ((size_t)b * nslots * cs + cc) * 2;
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < nslots; ++s) {
+            const float2 v = *reinterpret_cast<const float2*>(pp + (size_t)s * cs * 2);
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+        csum[2 * c] = s1;
+        csum[2 * c + 1] = s2;
+    }
+    __syncthreads();
+    const int G = C / GN_GROUPS;
+    if (threadIdx.x < GN_GROUPS) {
+        const int g = threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        for (int j = 0; j < G; ++j) { s1 += csum[2 * (g * G + j)]; s2 += csum[2 * (g * G + j) + 1]; }
+        const double n = (double)G * (double)T;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)GN_EPS);
+        gstat[2 * g] = mean;
+        gstat[2 * g + 1] = rstd;
+        if (mean_rstd) {
+            mean_rstd[((size_t)b * GN_GROUPS + g) * 2] = (float)mean;
+            mean_rstd[((size_t)b * GN_GROUPS + g) * 2 + 1] = (float)rstd;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / G;
+        const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
+        const float a = gamma[c] * rstd;
+        gscale[(size_t)b * C + c] = a;
+        gshift[(size_t)b * C + c] = beta[c] - mean * a;
+    }
+}
+}  // namespace
+
+extern "C" int tq_gn_finalize(const float* stats0, int C0, const float* stats1, int C1, int B, int T, const float* gamma,
+                              const float* beta, float* gscale, float* gshift, float* mean_rstd, hipStream_t stream) {
+    if (!stats0 || !gamma || !beta || !gscale || !gshift || (C1 > 0 && !stats1)) return TQ_ERR_ARG;
+    const int C = C0 + C1;
+    if (B <= 0 || T <= 0 || C <= 0 || C % GN_GROUPS) return TQ_ERR_SHAPE;
+    const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
+    const size_t shbytes = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(double);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), shbytes, stream, stats0, C0, stats1, C1, T, nslots, gamma,
+                       beta, gscale, gshift, mean_rstd);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================
+// Stem: (B, C_in<=16, T) NCW -> conv k "same" -> (B, T, C_out) channels-last, + bias, + partial stats.
+// One workgroup per (b, 128-position slot).  Thread = (4 output channels, 128/(256/(C_out/4)) positions).
+// =================================================================================================
+namespace {
+template <int KT>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y, float* __restrict__ stats, int C_in, int T,
+                                                        int C_out, int nslots) {
+    extern __shared__ float shm[];
+    constexpr int PAD = KT / 2;
+    constexpr int TW = STAT_SLOT + KT - 1;
+    float* xs = shm;                        // [C_in][TW]
+    float* ws = xs + C_in * TW;             // [KT][C_in][C_out]
+    float* red = ws + KT * C_in * C_out;    // [nrow][C_out][2]
+    const int slot = blockIdx.x % nslots;
+    const int b = blockIdx.x / nslots;
+    const int t0 = slot * STAT_SLOT;
+    const float sc = in_scale ? in_scale[b] : 1.0f;
+    for (int i = threadIdx.x; i < C_in * TW; i += 256) {
+        const int c = i / TW, j = i % TW;
+        const int t = t0 - PAD + j;
+        xs[i] = (t >= 0 && t < T) ? x[((size_t)b * C_in + c) * T + t] * sc : 0.f;
+    }
+    for (int i = threadIdx.x; i < KT * C_in * C_out; i += 256) {
+        const int co = i % C_out, r = i / C_out;
+        const int ci = r % C_in, k = r / C_in;
+        ws[i] = w[((size_t)co * C_in + ci) * KT + k];
+    }
+    __syncthreads();
+    const int ngrp = C_out >> 2;            // groups of 4 output channels
+    const int nrow = 256 / ngrp;            // positions processed per pass
+    const int cg = threadIdx.x % ngrp;
+    const int tr = threadIdx.x / ngrp;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * cg);
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (tr < nrow) {
+        for (int tl = tr; tl < STAT_SLOT; tl += nrow) {
+            const int t = t0 + tl;
+            if (t >= T) break;
+            float4 a = bv;
+            for (int k = 0; k < KT; ++k)
+                for (int ci = 0; ci < C_in; ++ci) {
+                    const float xv = xs[ci * TW + tl + k];
+                    const float4 wv = *reinterpret_cast<const float4*>(ws + (k * C_in + ci) * C_out + 4 * cg);
+                    a.x = fmaf(wv.x, xv, a.x); a.y = fmaf(wv.y, xv, a.y);
+                    a.z = fmaf(wv.z, xv, a.z); a.w = fmaf(wv.w, xv, a.w);
+                }
+            *reinterpret_cast<float4*>(y + ((size_t)b * T + t) * C_out + 4 * cg) = a;
+            s1[0] += a.x; s1[1] += a.y; s1[2] += a.z; s1[3] += a.w;
+            s2[0] += a.x * a.x; s2[1] += a.y * a.y; s2[2] += a.z * a.z; s2[3] += a.w * a.w;
+        }
+    }
+    if (stats) {
+        if (tr < nrow) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[(tr * C_out + 4 * cg + j) * 2] = s1[j];
+                red[(tr * C_out + 4 * cg + j) * 2 + 1] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C_out; c += 256) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int r = 0; r < nrow; ++r) { a1 += red[(r * C_out + c) * 2]; a2 += red[(r * C_out + c) * 2 + 1]; }
+            float* st = stats + (((size_t)b * nslots + slot) * C_out + c) * 2;
+            st[0] = a1; st[1] = a2;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int tq_stem_conv_fwd(const float* x, const float* in_scale, const float* w, const float* bias, float* y,
+                                float* stats, int B, int C_in, int T, int C_out, int ktaps, hipStream_t stream) {
+    if (!x || !w || !y) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C_in <= 0 || C_in > 16 || C_out < 4 || C_out % 4 || C_out > 1024 || 256 % (C_out / 4)) return TQ_ERR_SHAPE;
+    const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
+    const int ngrp = C_out / 4, nrow = 256 / ngrp;
+    const size_t sh = ((size_t)C_in * (STAT_SLOT + ktaps - 1) + (size_t)ktaps * C_in * C_out + (size_t)nrow * C_out * 2) * sizeof(float);
+    if (sh > 160 * 1024) return TQ_ERR_SHAPE;
+#define TQ_STEM(K)                                                                                          \
+    {                                                                                                       \
+        auto kern = stem_conv_kernel<K>;                                                                    \
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL(kern, dim3(B * nslots), dim3(256), sh, stream, x, in_scale, w, bias, y, stats, C_in, T, C_out, nslots); \
+    }
+    if (ktaps == 5) TQ_STEM(5)
+    else if (ktaps == 3) TQ_STEM(3)
+    else if (ktaps == 1) TQ_STEM(1)
+    else return TQ_ERR_SHAPE;
+#undef TQ_STEM
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================
+// Head: GroupNorm+SiLU (folded) -> conv k "same" to C_out<=4 -> NCW output with the EDM / consistency
+// skip connection folded in.  One workgroup per (b, 128 positions); the activated tile is transposed
+// into LDS as [ci][t] so that lanes (consecutive t) read consecutive words.
+// =================================================================================================
+namespace {
+template <int KT>
+__global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ gscale,
+                                                        const float* __restrict__ gshift, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ c_out,
+                                                        const float* __restrict__ c_skip, const float* __restrict__ skip_src,
+                                                        float* __restrict__ y, int T, int C_in, int C_out, int ntiles) {
+    extern __shared__ float shm[];
+    constexpr int PAD = KT / 2;
+    constexpr int TW = 128 + KT - 1;
+    constexpr int LD = TW + 1;  // odd leading dimension: conflict-free transposed writes
+    float* xs = shm;             // [C_in][LD]
+    float* part = xs + C_in * LD;  // [2][128][4]
+    const int tile = blockIdx.x % ntiles;
+    const int b = blockIdx.x / ntiles;
+    const int t0 = tile * 128;
+    const int nc4 = C_in >> 2;
+    for (int i = threadIdx.x; i < TW * nc4; i += 256) {
+        const int c4 = i % nc4, j = i / nc4;
+        const int t = t0 - PAD + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) {
+            v = *reinterpret_cast<const float4*>(x + ((size_t)b * T + t) * C_in + 4 * c4);
+            if (gscale) {
+                const float4 a = *reinterpret_cast<const float4*>(gscale + (size_t)b * C_in + 4 * c4);
+                const float4 s = *reinterpret_cast<const float4*>(gshift + (size_t)b * C_in + 4 * c4);
+                v.x = silu_f(a.x * v.x + s.x); v.y = silu_f(a.y * v.y + s.y);
+                v.z = silu_f(a.z * v.z + s.z); v.w = silu_f(a.w * v.w + s.w);
+            }
+        }
+        xs[(4 * c4 + 0) * LD + j] = v.x; xs[(4 * c4 + 1) * LD + j] = v.y;
+        xs[(4 * c4 + 2) * LD + j] = v.z; xs[(4 * c4 + 3) * LD + j] = v.w;
+    }
+    __syncthreads();
+    const int tl = threadIdx.x & 127;
+    const int half = threadIdx.x >> 7;
+    const int c_lo = half * (C_in >> 1), c_hi = c_lo + (C_in >> 1);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ci = c_lo; ci < c_hi; ++ci) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const float xv = xs[ci * LD + tl + k];
+#pragma unroll
+            for (int co = 0; co < 4; ++co)
+                if (co < C_out) acc[co] = fmaf(w[((size_t)co * C_in + ci) * KT + k], xv, acc[co]);
+        }
+    }
+    if (half == 1) {
+#pragma unroll
+        for (int co = 0; co < 4; ++co) part[tl * 4 + co] = acc[co];
+    }
+    __syncthreads();
+    if (half == 0) {
+        const int t = t0 + tl;
+        if (t < T) {
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+                if (co >= C_out) break;
+                float v = acc[co] + part[tl * 4 + co] + (bias ? bias[co] : 0.f);
+                const size_t o = ((size_t)b * C_out + co) * T + t;
+                if (c_out) v = v * c_out[b] + c_skip[b] * skip_src[o];
+                y[o] = v;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float* gshift, const float* w, const float* bias,
+                                const float* c_out, const float* c_skip, const float* skip_src, float* y, int B, int T,
+                                int C_in, int C_out, int ktaps, hipStream_t stream) {
+    if (!x || !w || !y) return TQ_ERR_ARG;
+    if ((gscale == nullptr) != (gshift == nullptr)) return TQ_ERR_ARG;
+    if (c_out && (!c_skip || !skip_src)) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || C_out < 1 || C_out > 4) return TQ_ERR_SHAPE;
+    const int ntiles = (T + 127) / 128;
+    const size_t sh = ((size_t)C_in * (128 + ktaps) + 128 * 4) * sizeof(float);
+    if (sh > 160 * 1024) return TQ_ERR_SHAPE;
+#define TQ_HEAD(K)                                                                                          \
+    {                                                                                                       \
+        auto kern = head_conv_kernel<K>;                                                                    \
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL(kern, dim3(B * ntiles), dim3(256), sh, stream, x, gscale, gshift, w, bias, c_out, c_skip, skip_src, y, T, C_in, C_out, ntiles); \
+    }
+    if (ktaps == 5) TQ_HEAD(5)
+    else if (ktaps == 3) TQ_HEAD(3)
+    else if (ktaps == 1) TQ_HEAD(1)
+    else return TQ_ERR_SHAPE;
+#undef TQ_HEAD
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================
+// Embedding: Fourier features -> time MLP (+ cond MLP).  One workgroup per sample; each wave owns
+// outputs o = wave, wave+4, ... and its 64 lanes split the input dimension (coalesced weight rows).
+// hidden[b][0][:] = pre-activation of time_mlp.0, hidden[b][1][:] = pre-activation of cond_mlp.0.
+// =================================================================================================
+namespace {
+__device__ __forceinline__ void gemv_rows(const float* __restrict__ w, const float* __restrict__ bias,
+                                          const float* in_sh, int n_in, int n_out, float* out_sh, bool accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = wave; o < n_out; o += 4) {
+        float a = 0.f;
+        for (int i = lane; i < n_in; i += 64) a = fmaf(w[(size_t)o * n_in + i], in_sh[i], a);
+        a = wave_sum(a);
+        if (lane == 0) {
+            a += bias[o];
+            out_sh[o] = accumulate ? out_sh[o] + a : a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ t, const float* __restrict__ cond,
+                                                    const float* __restrict__ fw, const float* __restrict__ w0,
+                                                    const float* __restrict__ b0, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, const float* __restrict__ cw0,
+                                                    const float* __restrict__ cb0, const float* __restrict__ cw2,
+                                                    const float* __restrict__ cb2, float* __restrict__ emb,
+                                                    float* __restrict__ silu_emb, float* __restrict__ hidden, int mc,
+                                                    int ncond) {
+    extern __shared__ float shm[];
+    const int E = 4 * mc;
+    float* four = shm;        // [mc]
+    float* h = four + mc;     // [E]
+    float* e = h + E;         // [E]
+    float* cs = e + E;        // [ncond]
+    const int b = blockIdx.x;
+    const float tv = t[b];
+    const int half = mc >> 1;
+    for (int i = threadIdx.x; i < half; i += 256) {
+        // blocks.py:23: ((x * W) * 2) * pi in fp32, then sin | cos
+        const float arg = ((tv * fw[i]) * 2.0f) * 3.14159265358979323846f;
+        four[i] = sinf(arg);
+        four[half + i] = cosf(arg);
+    }
+    for (int i = threadIdx.x; i < ncond; i += 256) cs[i] = cond[(size_t)b * ncond + i];
+    __syncthreads();
+    gemv_rows(w0, b0, four, mc, E, h, false);
+    __syncthreads();
+    for (int i = threadIdx.x; i < E; i += 256) {
+        if (hidden) hidden[((size_t)b * 2 + 0) * E + i] = h[i];
+        h[i] = silu_f(h[i]);
+    }
+    __syncthreads();
+    gemv_rows(w2, b2, h, E, E, e, false);
+    __syncthreads();
+    if (ncond > 0) {
+        gemv_rows(cw0, cb0, cs, ncond, E, h, false);
+        __syncthreads();
+        for (int i = threadIdx.x; i < E; i += 256) {
+            if (hidden) hidden[((size_t)b * 2 + 1) * E + i] = h[i];
+            h[i] = silu_f(h[i]);
+        }
+        __syncthreads();
+        gemv_rows(cw2, cb2, h, E, E, e, true);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < E; i += 256) {
+        emb[(size_t)b * E + i] = e[i];
+        silu_emb[(size_t)b * E + i] = silu_f(e[i]);
+    }
+}
+
+// out (B, N) = x (B, E) W^T (N, E) + bias.  Workgroup = 64 outputs x 16 samples; W tile in LDS with an odd
+// leading dimension (lanes = consecutive outputs -> conflict-free), x rows broadcast from LDS.
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int B, int E,
+                                                     int N) {
+    extern __shared__ float shm[];
+    const int LDW = E + 1;
+    float* ws = shm;            // [64][LDW]
+    float* xs = ws + 64 * LDW;  // [16][E]
+    const int n0 = blockIdx.x * 64;
+    const int b0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < 64 * E; i += 256) {
+        const int r = i / E, c = i % E;
+        ws[r * LDW + c] = (n0 + r < N) ? w[(size_t)(n0 + r) * E + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 16 * E; i += 256) {
+        const int r = i / E, c = i % E;
+        xs[i] = (b0 + r < B) ? x[(size_t)(b0 + r) * E + c] : 0.f;
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 63;
+    const int bq = threadIdx.x >> 6;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < E; ++i) {
+        const float wv = ws[j * LDW + i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = fmaf(wv, xs[(bq + 4 * q) * E + i], a[q]);
+    }
+    if (n0 + j < N) {
+        const float bv = bias ? bias[n0 + j] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = b0 + bq + 4 * q;
+            if (b < B) out[(size_t)b * N + n0 + j] = a[q] + bv;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int tq_embed_fwd(const float* t, const float* cond, const float* fourier_w, const float* w0, const float* b0,
+                            const float* w2, const float* b2, const float* cw0, const float* cb0, const float* cw2,
+                            const float* cb2, float* emb, float* silu_emb, float* hidden, int B, int mc, int ncond,
+                            hipStream_t stream) {
+    if (!t || !fourier_w || !w0 || !b0 || !w2 || !b2 || !emb || !silu_emb) return TQ_ERR_ARG;
+    if (ncond > 0 && (!cond || !cw0 || !cb0 || !cw2 || !cb2)) return TQ_ERR_ARG;
+    if (B <= 0 || mc <= 0 || mc % 2 || ncond < 0) return TQ_ERR_SHAPE;
+    const size_t sh = (size_t)(mc + 8 * mc + ncond) * sizeof(float);
+    hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), sh, stream, t, cond, fourier_w, w0, b0, w2, b2, cw0, cb0, cw2, cb2,
+                       emb, silu_emb, hidden, mc, ncond);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_linear_fwd(const float* x, const float* w, const float* bias, float* out, int B, int E, int N,
+                             hipStream_t stream) {
+    if (!x || !w || !out) return TQ_ERR_ARG;
+    if (B <= 0 || E <= 0 || N <= 0) return TQ_ERR_SHAPE;
+    const size_t sh = ((size_t)64 * (E + 1) + (size_t)16 * E) * sizeof(float);
+    if (sh > 160 * 1024) return TQ_ERR_SHAPE;
+    auto kern = linear_kernel;
+    if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(kern, dim3((N + 63) / 64, (B + 15) / 16), dim3(256), sh, stream, x, w, bias, out, B, E, N);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================
+// EDM scalar maps, noise injection, loss, Heun updates
+// =================================================================================================
+namespace {
+__global__ void edm_scalars_kernel(const float* __restrict__ sigma, int sstride, float sd, float* c_in, float* c_out,
+                                   float* c_skip, float* c_noise, float* lw, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float s = sigma[(size_t)b * sstride];
+    const float sd2 = sd * sd;
+    const float q = s * s + sd2;
+    if (c_in) c_in[b] = 1.0f / sqrtf(q);              // edm.py:33-34
+    if (c_out) c_out[b] = (s * sd) / sqrtf(q);        // edm.py:30-31
+    if (c_skip) c_skip[b] = sd2 / q;                  // edm.py:27-28
+    if (c_noise) c_noise[b] = 0.25f * logf(s);        // edm.py:36-37
+    if (lw) { const float ssd = s * sd; lw[b] = q / (ssd * ssd); }  // edm.py:24-25
+}
+
+__global__ void cm_scalars_kernel(const float* __restrict__ sigma, int sstride, float sd, float smin, float* c_out,
+                                  float* c_skip, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float s = sigma[(size_t)b * sstride];
+    const float d = s - smin;
+    c_skip[b] = (sd * sd) / (d * d + sd * sd);               // consistency_model.py:69
+    c_out[b] = (sd * d) / sqrtf(sd * sd + s * s);            // consistency_model.py:71-73
+}
+
+__global__ void noise_inject_kernel(const float* __restrict__ y, const float* __restrict__ n, const float* __restrict__ eps,
+                                    float pmean, float pstd, float* __restrict__ sigma, float* __restrict__ x, int per) {
+    const int b = blockIdx.y;
+    const float s = expf(eps[b] * pstd + pmean);  // edm.py:21-22
+    if (blockIdx.x == 0 && threadIdx.x == 0) sigma[b] = s;
+    const size_t base = (size_t)b * per;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x)
+        x[base + i] = y[base + i] + n[base + i] * s;  // edm.py:128-129
+}
+
+__global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                       const float* __restrict__ lw, float* __restrict__ loss,
+                                                       float* __restrict__ dpred, int per, float inv_n) {
+    const int b = blockIdx.y;
+    const float wgt = lw[b];
+    const size_t base = (size_t)b * per;
+    float a = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+        const float d = pred[base + i] - y[base + i];
+        a += wgt * d * d;
+        if (dpred) dpred[base + i] = 2.0f * wgt * d * inv_n;
+    }
+    a = wave_sum(a);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (ws[0] + ws[1] + ws[2] + ws[3]) * inv_n);
+}
+
+__global__ void heun_euler_kernel(const double* __restrict__ x, const float* __restrict__ den, const float* __restrict__ sig,
+                                  const float* __restrict__ sign, double* __restrict__ dcur, double* __restrict__ xn,
+                                  float* __restrict__ x32, size_t n) {
+    const float s = *sig, s2 = *sign;
+    const double sd = (double)s;
+    const double dt = (double)(s2 - s);  // fp32 subtraction of two 0-dim fp32 tensors, then promoted (edm.py:183)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double xv = x[i];
+        const double d = (xv - (double)den[i]) / sd;
+        const double r = xv + d * dt;
+        dcur[i] = d;
+        xn[i] = r;
+        x32[i] = (float)r;
+    }
+}
+
+__global__ void heun_correct_kernel(const double* __restrict__ x, const double* __restrict__ xn,
+                                    const float* __restrict__ den2, const double* __restrict__ dcur,
+                                    const float* __restrict__ sig, const float* __restrict__ sign, double* __restrict__ xo,
+                                    float* __restrict__ x32, size_t n) {
+    const float s = *sig, s2 = *sign;
+    const double sn = (double)s2;
+    const double dt = (double)(s2 - s);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double dp = (xn[i] - (double)den2[i]) / sn;          // edm.py:193
+        const double r = x[i] + dt * (0.5 * dcur[i] + 0.5 * dp);   // edm.py:194
+        xo[i] = r;
+        x32[i] = (float)r;
+    }
+}
+
+__global__ void sampler_init_kernel(const double* __restrict__ z, const float* __restrict__ s0, double* __restrict__ x,
+                                    float* __restrict__ x32, size_t n) {
+    const double s = (double)*s0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double r = z[i] * s;
+        x[i] = r;
+        x32[i] = (float)r;
+    }
+}
+
+inline unsigned ew_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g > 2048 ? 2048 : (g ? g : 1));
+}
+}  // namespace
+
+extern "C" int tq_edm_scalars(const float* sigma, int sigma_stride, float sigma_data, float* c_in, float* c_out,
+                              float* c_skip, float* c_noise, float* lweight, int B, hipStream_t stream) {
+    if (!sigma || B <= 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(edm_scalars_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, sigma, sigma_stride, sigma_data, c_in,
+                       c_out, c_skip, c_noise, lweight, B);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_cm_scalars(const float* sigma, int sigma_stride, float sigma_data, float sigma_min, float* c_out,
+                             float* c_skip, int B, hipStream_t stream) {
+    if (!sigma || !c_out || !c_skip || B <= 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(cm_scalars_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, sigma, sigma_stride, sigma_data, sigma_min,
+                       c_out, c_skip, B);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_edm_noise_inject(const float* y, const float* unit_noise, const float* eps, float P_mean, float P_std,
+                                   float* sigma, float* x_noisy, int B, int n_per_sample, hipStream_t stream) {
+    if (!y || !unit_noise || !eps || !sigma || !x_noisy || B <= 0 || n_per_sample <= 0) return TQ_ERR_ARG;
+    const unsigned gx = (unsigned)((n_per_sample + 255) / 256 > 64 ? 64 : (n_per_sample + 255) / 256);
+    hipLaunchKernelGGL(noise_inject_kernel, dim3(gx, B), dim3(256), 0, stream, y, unit_noise, eps, P_mean, P_std, sigma,
+                       x_noisy, n_per_sample);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_edm_loss(const float* pred, const float* y, const float* lweight, float* loss_out, float* dpred, int B,
+                           int n_per_sample, hipStream_t stream) {
+    if (!pred || !y || !lweight || !loss_out || B <= 0 || n_per_sample <= 0) return TQ_ERR_ARG;
+    hipError_t e = hipMemsetAsync(loss_out, 0, sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    const unsigned gx = (unsigned)((n_per_sample + 255) / 256 > 16 ? 16 : (n_per_sample + 255) / 256);
+    const float inv_n = (float)(1.0 / ((double)B * (double)n_per_sample));
+    hipLaunchKernelGGL(edm_loss_kernel, dim3(gx, B), dim3(256), 0, stream, pred, y, lweight, loss_out, dpred, n_per_sample,
+                       inv_n);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_heun_euler(const double* x, const float* denoised, const float* sigma, const float* sigma_next,
+                             double* d_cur, double* x_next, float* x32, size_t n, hipStream_t stream) {
+    if (!x || !denoised || !sigma || !sigma_next || !d_cur || !x_next || !x32 || n == 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(heun_euler_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, denoised, sigma, sigma_next, d_cur,
+                       x_next, x32, n);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_heun_correct(const double* x, const double* x_next, const float* denoised_next, const double* d_cur,
+                               const float* sigma, const float* sigma_next, double* x_out, float* x32, size_t n,
+                               hipStream_t stream) {
+    if (!x || !x_next || !denoised_next || !d_cur || !sigma || !sigma_next || !x_out || !x32 || n == 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(heun_correct_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, x_next, denoised_next, d_cur, sigma,
+                       sigma_next, x_out, x32, n);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_sampler_init(const double* unit_noise, const float* sigma0, double* x, float* x32, size_t n,
+                               hipStream_t stream) {
+    if (!unit_noise || !sigma0 || !x || !x32 || n == 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(sampler_init_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, unit_noise, sigma0, x, x32, n);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}

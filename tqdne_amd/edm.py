@@ -1,0 +1,298 @@
+"""EDM diffusion wrapper: drop-in for ``tqdne.edm`` (reference tqdne/edm.py:9-251).
+
+``EDM`` carries the constants and scalar maps; ``LightningEDM`` keeps the reference's constructor, attributes and
+method names (``forward``, ``step``, ``training_step``, ``validation_step``, ``sample``,
+``sample_deterministically``, ``sample_stochastically``, ``evaluate``, ``configure_optimizers``) and runs them on
+the HIP kernels:
+
+  forward   edm_scalars -> UNet with c_in folded into the stem load and c_out/c_skip folded into the head epilogue
+  step      noise-inject kernel -> forward -> weighted-MSE kernel (loss + dL/dpred) -> hand-written backward
+  sample    fp64 state, fp32 network; per step one Euler and one Heun-correction elementwise fp64 kernel;
+            sigma stays on the device (no host sync inside the loop)
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch as th
+
+from . import _lib, engine
+from ._lib import check
+from .lightning_compat import LightningModule
+from .unet import UNetModel
+
+
+def _append_dims(x, target_dims):  # reference nn.py:78-83
+    extra = target_dims - x.ndim
+    if extra < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {target_dims}, which is less")
+    return x[(...,) + (None,) * extra]
+
+
+class EDM:
+    """Constants and scalar maps of Karras et al. as used by the reference (edm.py:9-52)."""
+
+    sigma_min: float = 0.002
+    sigma_max: float = 80.0
+    rho: float = 7.0
+    sigma_data: float = 0.5
+    P_mean: float = -1.2
+    P_std: float = 1.2
+    S_churn: float = 40
+    S_min: float = 0.05
+    S_max: float = 50
+    S_noise: float = 1.003
+
+    def sigma(self, eps):
+        return (eps * self.P_std + self.P_mean).exp()
+
+    def loss_weight(self, sigma):
+        return (sigma**2 + self.sigma_data**2) / (sigma * self.sigma_data) ** 2
+
+    def skip_scaling(self, sigma):
+        return self.sigma_data**2 / (sigma**2 + self.sigma_data**2)
+
+    def out_scaling(self, sigma):
+        return sigma * self.sigma_data / (sigma**2 + self.sigma_data**2) ** 0.5
+
+    def in_scaling(self, sigma):
+        return 1 / (sigma**2 + self.sigma_data**2) ** 0.5
+
+    def noise_conditioning(self, sigma):
+        return 0.25 * sigma.log()
+
+    def sampling_sigmas(self, num_steps, device=None):
+        inv = 1 / self.rho
+        idx = th.arange(num_steps, dtype=th.float32, device=device)
+        s = (self.sigma_max**inv + idx / (num_steps - 1) * (self.sigma_min**inv - self.sigma_max**inv)) ** self.rho
+        return th.cat([s, th.zeros_like(s[:1])])
+
+    def sigma_hat(self, sigma, num_steps):
+        gamma = min(self.S_churn / num_steps, 2**0.5 - 1) if self.S_min <= sigma <= self.S_max else 0
+        return sigma + gamma * sigma
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class LightningEDM(LightningModule):
+    def __init__(
+        self,
+        unet_config: dict,
+        optimizer_params: dict,
+        num_sampling_steps: int = 25,
+        deterministic_sampling: bool = True,
+        edm: EDM = EDM(),
+        autoencoder=None,
+    ):
+        super().__init__()
+        self.unet = UNetModel(**unet_config)
+        self.optimizer_params = optimizer_params
+        self.num_sampling_steps = num_sampling_steps
+        self.deterministic_sampling = deterministic_sampling
+        self.edm = edm
+        self.autoencoder = autoencoder.eval() if autoencoder else None
+        self.config = unet_config
+        if self.autoencoder:
+            for param in self.autoencoder.parameters():
+                param.requires_grad = False
+        self.save_hyperparameters(ignore=("autoencoder"))
+        self._scal = {}
+
+    # ------------------------------------------------------------------ preconditioned network
+    def _scalars(self, B, device):
+        key = (B, str(device))
+        s = self._scal.get(key)
+        if s is None:
+            s = th.empty(5, B, dtype=th.float32, device=device)  # c_in, c_out, c_skip, c_noise, loss weight
+            self._scal[key] = s
+        return s
+
+    def _denoise_static(self, sample, sigma, sigma_stride, cond, train=False, dropout_seed=0):
+        """Fused preconditioned forward (edm.py:105-113); returns the engine's static output buffer.
+        ``sigma``: device tensor; ``sigma_stride`` 1 (per-sample) or 0 (one value shared by the batch)."""
+        lib = _lib.load()
+        B, _, T = sample.shape
+        dev = sample.device
+        sc = self._scalars(B, dev)
+        stream = th.cuda.current_stream(dev).cuda_stream
+        check(lib.tq_edm_scalars(_p(sigma), sigma_stride, float(self.edm.sigma_data), _p(sc[0]), _p(sc[1]), _p(sc[2]),
+                                 _p(sc[3]), _p(sc[4]), B, stream), "edm scalars")
+        eng = self.unet._engine(B, T, dev)
+        return eng.forward(sample, sc[3], cond, in_scale=sc[0], c_out=sc[1], c_skip=sc[2], skip_src=sample, train=train,
+                           dropout_seed=dropout_seed)
+
+    def forward(self, sample, sigma, cond_sample=None, cond=None):
+        """Make a forward pass through the network with skip connection (edm.py:105-113)."""
+        engine.require_device(sample)
+        sample = sample.contiguous()
+        sigma = sigma.contiguous().float()
+        assert (cond is not None) == (self.unet.cond_features is not None), (
+            "must specify cond if and only if the model is conditioned"
+        )
+        if cond_sample is None:
+            if self.training and th.is_grad_enabled():
+                from .autograd import denoise_with_grad
+                return denoise_with_grad(self, sample, sigma, cond)
+            return self._denoise_static(sample, sigma, 1, cond).clone()
+        # conditioning signal concatenated on the channel axis (edm.py:109): the pre-scale cannot be folded into the
+        # stem (only the first channels are scaled), so the tiny glue ops run as torch elementwise kernels
+        dim = sample.dim()
+        x_in = th.cat((sample * _append_dims(self.edm.in_scaling(sigma), dim), cond_sample), dim=1)
+        out = self.unet(x_in, self.edm.noise_conditioning(sigma), cond=cond)
+        skip = _append_dims(self.edm.skip_scaling(sigma), dim) * sample
+        return out * _append_dims(self.edm.out_scaling(sigma), dim) + skip
+
+    # ------------------------------------------------------------------ training
+    def step(self, batch, batch_idx):
+        """A single step in the training loop (edm.py:115-134)."""
+        sample = batch["signal"]
+        cond_sample = batch["cond_signal"] if "cond_signal" in batch else None
+        cond = batch["cond"] if "cond" in batch else None
+        if self.autoencoder:
+            sample = self.autoencoder.encode(sample)
+            if cond_sample is not None:
+                cond_sample = self.autoencoder.encode(cond_sample)
+        eps = th.randn(sample.shape[0], device=self.device)
+        unit_noise = th.randn_like(sample)
+        return self.step_with_noise(sample, eps, unit_noise, cond=cond, cond_sample=cond_sample)
+
+    def step_with_noise(self, sample, eps, unit_noise, cond=None, cond_sample=None):
+        """``step`` with the two random draws of edm.py:126,128 supplied by the caller (tests inject CPU draws)."""
+        if cond_sample is not None:
+            sigma = self.edm.sigma(eps)
+            noise = unit_noise * _append_dims(sigma, sample.dim())
+            pred = self(sample + noise, sigma, cond_sample, cond)
+            loss = (pred - sample) ** 2
+            return th.mean(loss * _append_dims(self.edm.loss_weight(sigma), loss.dim()))
+        from .autograd import edm_loss
+        return edm_loss(self, sample.contiguous(), eps.contiguous().float(), unit_noise.contiguous(), cond)
+
+    def training_step(self, batch, batch_idx):
+        loss = self.step(batch, batch_idx)
+        self.log("training/loss", loss.item(), sync_dist=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        loss = self.step(batch, batch_idx)
+        self.log("validation/loss", loss.item(), sync_dist=True)
+        return loss
+
+    # ------------------------------------------------------------------ sampling
+    @th.no_grad()
+    def sample(self, shape, cond_sample=None, cond=None):
+        """Sample using Heun's second order method (edm.py:146-169)."""
+        dtype = th.float64
+        if self.autoencoder:
+            if cond_sample is not None:
+                cond_sample = self.autoencoder.encode(cond_sample)
+            dummy = th.zeros(shape, device=self.device)
+            shape = self.autoencoder.encode(dummy).shape
+        # schedule built on the host in fp32 exactly like the reference's CPU path, then moved (pow differs by ulps on device)
+        sigmas = self.edm.sampling_sigmas(self.num_sampling_steps).to(self.device)
+        eps = th.randn(shape, device=self.device, dtype=dtype) * sigmas[0]
+        if self.deterministic_sampling:
+            sample = self.sample_deterministically(eps, sigmas, cond_sample, cond)
+        else:
+            sample = self.sample_stochastically(eps, sigmas, cond_sample, cond)
+        sample = sample.to(th.float32)
+        if self.autoencoder:
+            return self.autoencoder.decode(sample)
+        return sample
+
+    def _sampler_buffers(self, eps):
+        key = ("smp", tuple(eps.shape), str(eps.device))
+        bufs = self._scal.get(key)
+        if bufs is None:
+            f64 = lambda: th.empty(eps.shape, dtype=th.float64, device=eps.device)
+            bufs = dict(x=f64(), xn=f64(), d=f64(), x32=th.empty(eps.shape, dtype=th.float32, device=eps.device))
+            self._scal[key] = bufs
+        return bufs
+
+    @th.no_grad()
+    def sample_deterministically(self, eps, sigmas, cond_sample=None, cond=None):
+        """Deterministic Heun sampler (edm.py:171-196): ``eps`` is the fp64 start state (already scaled by sigmas[0]),
+        ``sigmas`` the fp32 schedule ending in 0.  NFE = 2*len(sigmas) - 3 when the last sigma is the appended 0."""
+        if cond_sample is not None:
+            return self._sample_generic(eps, sigmas, cond_sample, cond, stochastic=False)
+        lib = _lib.load()
+        if not eps.is_cuda:
+            raise RuntimeError("tqdne_amd samples on MI355X HIP kernels only; got a CPU start state")
+        dev = eps.device
+        sigmas = sigmas.to(device=dev, dtype=th.float32).contiguous()
+        if cond is not None:
+            cond = cond.contiguous().float()
+        bufs = self._sampler_buffers(eps)
+        x, xn, d, x32 = bufs["x"], bufs["xn"], bufs["d"], bufs["x32"]
+        x.copy_(eps)
+        x32.copy_(eps)  # fp64 -> fp32 rounding, as sample_curr.to(self.dtype)
+        n = x.numel()
+        nsteps = sigmas.numel() - 1
+        sp = sigmas.data_ptr()
+        stream = th.cuda.current_stream(dev).cuda_stream
+        for i in range(nsteps):
+            s_i, s_n = sp + 4 * i, sp + 4 * (i + 1)
+            den = self._denoise_static(x32, _RawPtr(s_i), 0, cond)
+            check(lib.tq_heun_euler(_p(x), _p(den), s_i, s_n, _p(d), _p(xn), _p(x32), n, stream), "heun euler")
+            if i < self.num_sampling_steps - 1:
+                den = self._denoise_static(x32, _RawPtr(s_n), 0, cond)
+                check(lib.tq_heun_correct(_p(x), _p(xn), _p(den), _p(d), s_i, s_n, _p(x), _p(x32), n, stream), "heun correct")
+            else:
+                x, xn = xn, x
+        return x.clone()
+
+    @th.no_grad()
+    def sample_stochastically(self, eps, sigmas, cond_sample=None, cond=None):
+        """Stochastic (churned) sampler (edm.py:198-230).  The churn bookkeeping is a handful of fp64 elementwise torch
+        ops per step around the fused HIP denoiser; sigma_hat is resolved on the host exactly as the reference does."""
+        return self._sample_generic(eps, sigmas, cond_sample, cond, stochastic=True)
+
+    def _sample_generic(self, eps, sigmas, cond_sample, cond, stochastic):
+        dtype = th.float64
+        sample_next = eps
+        for i, (sigma, sigma_next) in enumerate(zip(sigmas[:-1], sigmas[1:])):
+            sample_curr = sample_next
+            if stochastic:
+                sigma_hat = self.edm.sigma_hat(sigma, self.num_sampling_steps)
+                noise = th.randn_like(sample_curr) * self.edm.S_noise
+                sample_hat = sample_curr + noise * (sigma_hat**2 - sigma**2) ** 0.5
+            else:
+                sigma_hat, sample_hat = sigma, sample_curr
+            pred_hat = self(sample_hat.to(th.float32), sigma_hat.to(th.float32).repeat(len(sample_hat)), cond_sample, cond).to(dtype)
+            d_cur = (sample_hat - pred_hat) / sigma_hat
+            sample_next = sample_hat + d_cur * (sigma_next - sigma_hat)
+            if i < self.num_sampling_steps - 1:
+                pred_next = self(sample_next.to(th.float32), sigma_next.to(th.float32).repeat(len(sample_hat)), cond_sample, cond).to(dtype)
+                d_prime = (sample_next - pred_next) / sigma_next
+                sample_next = sample_hat + (sigma_next - sigma_hat) * (0.5 * d_cur + 0.5 * d_prime)
+        return sample_next
+
+    @th.no_grad()
+    def evaluate(self, batch):
+        """Evaluate the model on a batch of data (edm.py:232-238)."""
+        sample = batch["signal"]
+        cond_sample = batch["cond_signal"] if "cond_signal" in batch else None
+        cond = batch["cond"] if "cond" in batch else None
+        return self.sample(sample.shape, cond_sample, cond)
+
+    def configure_optimizers(self):
+        optimizer = th.optim.Adam(self.parameters(), lr=self.optimizer_params["learning_rate"])
+        lr_scheduler = th.optim.lr_scheduler.CosineAnnealingLR(
+            optimizer, T_max=self.optimizer_params["max_steps"], eta_min=self.optimizer_params["eta_min"]
+        )
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": lr_scheduler, "interval": "step"}}
+
+
+class _RawPtr:
+    """A bare device address standing in for a tensor where only ``data_ptr()`` is needed."""
+
+    __slots__ = ("ptr",)
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def data_ptr(self):
+        return self.ptr

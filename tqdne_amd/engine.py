@@ -1,0 +1,309 @@
+"""Execution plans that drive libtqdne_hip.so for one (model, batch, length, device).
+
+A plan is built once: every intermediate tensor gets a static buffer in HBM ((B, T, C) fp32 channels-last plus
+per-channel partial statistics), every kernel launch becomes a pre-bound ``(function, argument tuple)`` and a
+forward pass is a flat loop of C-ABI calls on torch's current HIP stream (so it can be captured in a HIP graph).
+PyTorch is used for device memory and streams only.
+
+Fusion map (reference op chain -> launches), per block:
+  ResBlock (unet.py:131-143):  gn_finalize | conv1[GN+SiLU -> k5 -> +bias +emb, stats] | gn_finalize |
+                               (1x1 skip conv) | conv2[GN+SiLU(+dropout) -> k5 -> +bias +skip, stats]
+  AttentionBlock (blocks.py:139-145): gn_finalize | qkv conv[GN -> k1] | flash attention | proj conv[k1 + x, stats]
+  Downsample / Upsample (blocks.py:29-108): one conv (stride 2 / nearest-x2 folded into the gather)
+  th.cat([h, hs.pop()]) (unet.py:396): never materialised, consumers read two sources.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (TQ_CONV_DROPOUT, TQ_CONV_EMB, TQ_CONV_GN, TQ_CONV_RES, TQ_CONV_SILU, TQ_CONV_STATS, STAT_SLOT,
+                   TqConvDesc, check)
+
+
+def require_device(x: torch.Tensor):
+    if not x.is_cuda:
+        raise RuntimeError(
+            "tqdne_amd runs its hot path on MI355X HIP kernels only; got a CPU tensor. "
+            "(The CPU restatement lives in oracle/ and is test infrastructure, not a fallback.)"
+        )
+    if x.dtype != torch.float32:
+        raise TypeError("tqdne_amd expects fp32 tensors at the boundary, like the reference (precision 32)")
+
+
+def nslots(T: int) -> int:
+    return (T + STAT_SLOT - 1) // STAT_SLOT
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Act:
+    """A channels-last activation (B, T, C) and, optionally, its per-channel partial statistics."""
+
+    __slots__ = ("buf", "stats", "C", "T")
+
+    def __init__(self, buf, stats, C, T):
+        self.buf, self.stats, self.C, self.T = buf, stats, C, T
+
+
+class ConvSite:
+    """One convolution's weights: torch parameter + packed bf16 hi/lo MFMA fragments."""
+
+    __slots__ = ("weight", "bias", "packed", "C_out", "C_in", "K", "version", "name")
+
+    def __init__(self, name, weight, bias, device, lib):
+        self.name = name
+        self.weight, self.bias = weight, bias
+        self.C_out, self.C_in, self.K = weight.shape
+        nbytes = lib.tq_conv_weight_pack_bytes(self.C_out, self.C_in, self.K, 0)
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.version = -1
+
+
+class UNetEngine:
+    def __init__(self, model, B: int, T: int, device: torch.device):
+        self.lib = _lib.load()
+        self.m = model
+        self.B, self.T, self.dev = B, T, device
+        self.E = 4 * model.model_channels
+        self._keep = []          # ctypes structs / tensors referenced by raw pointers
+        self.ops: List[Tuple] = []
+        self.conv_sites: List[ConvSite] = []
+        self.dropout_descs: List[TqConvDesc] = []
+        self.acts: List[Act] = []
+        self._build()
+        self._w_version = None
+
+    # ------------------------------------------------------------------ allocation helpers
+    def _empty(self, *shape, dtype=torch.float32):
+        t = torch.empty(*shape, dtype=dtype, device=self.dev)
+        self._keep.append(t)
+        return t
+
+    def _act(self, C_: int, T_: int, stats: bool = True) -> Act:
+        a = Act(self._empty(self.B, T_, C_), self._empty(self.B, nslots(T_), C_, 2) if stats else None, C_, T_)
+        self.acts.append(a)
+        return a
+
+    def _site(self, name: str, conv: torch.nn.Module) -> ConvSite:
+        s = ConvSite(name, conv.weight, conv.bias, self.dev, self.lib)
+        self.conv_sites.append(s)
+        return s
+
+    # ------------------------------------------------------------------ op builders
+    def _gn(self, srcs: Sequence[Act], norm: torch.nn.GroupNorm):
+        C_ = sum(s.C for s in srcs)
+        gscale, gshift = self._empty(self.B, C_), self._empty(self.B, C_)
+        mean_rstd = self._empty(self.B, 32, 2)
+        s0 = srcs[0]
+        s1 = srcs[1] if len(srcs) > 1 else None
+        self.ops.append((self.lib.tq_gn_finalize, (
+            _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
+            _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize"))
+        return gscale, gshift, mean_rstd
+
+    def _conv(self, srcs: Sequence[Act], site: ConvSite, *, gn=None, silu=False, emb_ptr=None, res: Optional[Act] = None,
+              stats=True, stride=1, upsample=False, dropout_site: Optional[int] = None) -> Act:
+        s0 = srcs[0]
+        s1 = srcs[1] if len(srcs) > 1 else None
+        T_in = s0.T
+        if stride == 2:
+            T_out = (T_in + 2 - site.K) // 2 + 1
+            pad = site.K // 2
+        else:
+            T_out = 2 * T_in if upsample else T_in
+            pad = site.K // 2
+        out = self._act(site.C_out, T_out, stats)
+        d = TqConvDesc()
+        d.B, d.T_in, d.T_out = self.B, T_in, T_out
+        d.C_in0, d.C_in1, d.C_out = s0.C, (s1.C if s1 else 0), site.C_out
+        assert d.C_in0 + d.C_in1 == site.C_in, (site.name, d.C_in0, d.C_in1, site.C_in)
+        d.ktaps, d.stride, d.pad, d.upsample = site.K, stride, pad, int(upsample)
+        flags = 0
+        if gn is not None:
+            flags |= TQ_CONV_GN
+        if silu:
+            flags |= TQ_CONV_SILU
+        if emb_ptr is not None:
+            flags |= TQ_CONV_EMB
+        if res is not None:
+            flags |= TQ_CONV_RES
+            assert res.C == site.C_out and res.T == T_out
+        if stats:
+            flags |= TQ_CONV_STATS
+        d.flags = flags
+        d.emb_stride = self.emb_total
+        d.dropout_site = dropout_site or 0
+        d.dropout_p = 0.0
+        d.dropout_seed = 0
+        if dropout_site is not None:
+            self.dropout_descs.append(d)
+        self._keep.append(d)
+        self.ops.append((self.lib.tq_conv1d_fwd, (
+            C.byref(d), _p(s0.buf), _p(s1.buf) if s1 else None, _p(gn[0]) if gn else None, _p(gn[1]) if gn else None,
+            _p(site.packed), _p(site.bias), emb_ptr, _p(res.buf) if res else None, _p(out.buf), _p(out.stats)),
+            "conv:" + site.name))
+        return out
+
+    # ------------------------------------------------------------------ graph construction
+    def _build(self):
+        m, B, T = self.m, self.B, self.T
+        lib = self.lib
+        # all ResBlocks, in execution order, for the batched embedding projection
+        self.res_blocks = []
+        for blk in list(m.input_blocks) + [m.middle_block] + list(m.output_blocks):
+            for layer in blk:
+                if getattr(layer, "kind", None) == "res":
+                    self.res_blocks.append(layer)
+        self.emb_offsets = {}
+        off = 0
+        for rb in self.res_blocks:
+            self.emb_offsets[id(rb)] = off
+            off += rb.out_channels
+        self.emb_total = off
+        self.emb = self._empty(B, self.E)
+        self.silu_emb = self._empty(B, self.E)
+        self.emb_hidden = self._empty(B, 2, self.E)
+        self.emb_w = self._empty(self.emb_total, self.E)
+        self.emb_b = self._empty(self.emb_total)
+        self.emb_all = self._empty(B, self.emb_total)
+
+        # stem (dynamic args: x, in_scale) -------------------------------------------------------
+        stem = m.input_blocks[0][0]
+        self.stem_out = self._act(stem.out_channels, T, True)
+        hs = [self.stem_out]
+        h = self.stem_out
+        self._site_counter = 0
+
+        def run_layers(layers, h, name):
+            for li, layer in enumerate(layers):
+                kind = getattr(layer, "kind", None)
+                pfx = f"{name}.{li}"
+                if kind == "res":
+                    h = self._res_block(h, layer, pfx)
+                elif kind == "attn":
+                    h = self._attention(h[0] if isinstance(h, tuple) else h, layer, pfx)
+                elif kind == "down":
+                    h = self._conv([h], self._site(pfx + ".op", layer.op), stride=2)
+                elif kind == "up":
+                    h = self._conv([h], self._site(pfx + ".conv", layer.conv), upsample=True)
+                else:
+                    raise RuntimeError(f"unexpected layer {type(layer)} in {name}")
+            return h
+
+        for i, blk in enumerate(m.input_blocks):
+            if i == 0:
+                continue
+            h = run_layers(blk, h, f"input_blocks.{i}")
+            hs.append(h)
+        h = run_layers(m.middle_block, h, "middle_block")
+        for i, blk in enumerate(m.output_blocks):
+            skip = hs.pop()
+            h = run_layers(blk, (h, skip), f"output_blocks.{i}")
+        self.final = h
+        self.head_gn = self._gn([h], m.out[0])
+        self.out_nct = self._empty(B, m.out_channels, T)
+
+    def _res_block(self, x, rb, name: str) -> Act:
+        srcs = list(x) if isinstance(x, tuple) else [x]
+        emb_ptr = self.emb_all.data_ptr() + 4 * self.emb_offsets[id(rb)] if hasattr(rb, "emb_layers") else None
+        g1 = self._gn(srcs, rb.in_layers[0])
+        h1 = self._conv(srcs, self._site(name + ".in_layers.2", rb.in_layers[2]), gn=g1, silu=True, emb_ptr=emb_ptr)
+        g2 = self._gn([h1], rb.out_layers[0])
+        if isinstance(rb.skip_connection, torch.nn.Identity):
+            assert len(srcs) == 1
+            res = srcs[0]
+        else:
+            res = self._conv(srcs, self._site(name + ".skip_connection", rb.skip_connection), stats=False)
+        self._site_counter += 1
+        return self._conv([h1], self._site(name + ".out_layers.3", rb.out_layers[3]), gn=g2, silu=True, res=res,
+                          dropout_site=self._site_counter)
+
+    def _attention(self, x: Act, ab, name: str) -> Act:
+        g = self._gn([x], ab.norm)
+        qkv = self._conv([x], self._site(name + ".qkv", ab.qkv), gn=g, silu=False, stats=False)
+        att = self._act(ab.channels, x.T, False)
+        D = ab.channels // ab.num_heads
+        if D not in (32, 64):
+            raise NotImplementedError(f"attention head dim {D} (kernels exist for 32 and 64)")
+        self.ops.append((self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), self.B, x.T, ab.num_heads, D), "attention"))
+        return self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
+
+    # ------------------------------------------------------------------ weights
+    def _weights_version(self):
+        v = 0
+        for s in self.conv_sites:
+            v += s.weight._version
+        for rb in self.res_blocks:
+            if hasattr(rb, "emb_layers"):
+                v += rb.emb_layers[1].weight._version + rb.emb_layers[1].bias._version
+        return v
+
+    def repack(self, stream: int, force: bool = False):
+        """(Re)build packed conv weights and the concatenated emb projection when parameters changed."""
+        v = self._weights_version()
+        if not force and v == self._w_version:
+            return
+        lib = self.lib
+        for s in self.conv_sites:
+            check(lib.tq_pack_conv_weight(s.weight.data_ptr(), s.C_out, s.C_in, s.K, 0, s.packed.data_ptr(), stream),
+                  "pack " + s.name)
+        with torch.no_grad():
+            for rb in self.res_blocks:
+                if hasattr(rb, "emb_layers"):
+                    o = self.emb_offsets[id(rb)]
+                    self.emb_w[o:o + rb.out_channels].copy_(rb.emb_layers[1].weight)
+                    self.emb_b[o:o + rb.out_channels].copy_(rb.emb_layers[1].bias)
+        self._w_version = v
+
+    # ------------------------------------------------------------------ run
+    def forward(self, x, timesteps, cond=None, *, in_scale=None, c_out=None, c_skip=None, skip_src=None,
+                train: bool = False, dropout_seed: int = 0):
+        """Run the UNet.  Returns the static (B, C_out, T) output buffer (overwritten by the next call)."""
+        m, lib, B, T = self.m, self.lib, self.B, self.T
+        if tuple(x.shape) != (B, m.in_channels, T):
+            raise ValueError(f"plan was built for {(B, m.in_channels, T)}, got {tuple(x.shape)}")
+        x = x.contiguous()
+        timesteps = timesteps.contiguous().float()
+        if timesteps.shape != (B,):
+            raise ValueError("timesteps must have shape (N,)")
+        ncond = 0
+        if cond is not None:
+            cond = cond.contiguous().float()
+            ncond = cond.shape[1]
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.repack(stream)
+        p = float(m.dropout) if train else 0.0
+        for d in self.dropout_descs:
+            if p > 0.0:
+                d.flags |= TQ_CONV_DROPOUT
+                d.dropout_p, d.dropout_seed = p, dropout_seed
+            else:
+                d.flags &= ~TQ_CONV_DROPOUT
+        tm, cm = m.time_mlp, (m.cond_mlp if m.cond_features is not None else None)
+        check(lib.tq_embed_fwd(
+            _p(timesteps), _p(cond), _p(m.time_embed.W), _p(tm[0].weight), _p(tm[0].bias), _p(tm[2].weight), _p(tm[2].bias),
+            _p(cm[0].weight) if cm else None, _p(cm[0].bias) if cm else None, _p(cm[2].weight) if cm else None,
+            _p(cm[2].bias) if cm else None, _p(self.emb), _p(self.silu_emb), _p(self.emb_hidden), B, m.model_channels,
+            ncond, stream), "embed")
+        check(lib.tq_linear_fwd(_p(self.silu_emb), _p(self.emb_w), _p(self.emb_b), _p(self.emb_all), B, self.E,
+                                self.emb_total, stream), "emb projections")
+        stem = m.input_blocks[0][0]
+        check(lib.tq_stem_conv_fwd(_p(x), _p(in_scale), _p(stem.weight), _p(stem.bias), _p(self.stem_out.buf),
+                                   _p(self.stem_out.stats), B, m.in_channels, T, stem.out_channels, stem.kernel_size[0],
+                                   stream), "stem conv")
+        for fn, args, what in self.ops:
+            rc = fn(*args, stream)
+            if rc:
+                check(rc, what)
+        head = m.out[2]
+        check(lib.tq_head_conv_fwd(_p(self.final.buf), _p(self.head_gn[0]), _p(self.head_gn[1]), _p(head.weight),
+                                   _p(head.bias), _p(c_out), _p(c_skip), _p(skip_src), _p(self.out_nct), B, T,
+                                   self.final.C, m.out_channels, head.kernel_size[0], stream), "head conv")
+        return self.out_nct

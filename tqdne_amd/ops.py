@@ -1,0 +1,119 @@
+"""Thin functional wrappers over the C ABI (allocate outputs, pack weights, launch on the current stream).
+Used by the parity tests and handy for experiments; the engine binds the same entry points directly."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (TQ_CONV_DROPOUT, TQ_CONV_EMB, TQ_CONV_GN, TQ_CONV_RES, TQ_CONV_SILU, TQ_CONV_STATS, STAT_SLOT,
+                   TqConvDesc, check)
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def nslots(T):
+    return (T + STAT_SLOT - 1) // STAT_SLOT
+
+
+def pack_conv_weight(w: torch.Tensor, mode: int = 0) -> torch.Tensor:
+    lib = _lib.load()
+    co, ci, k = w.shape
+    out = torch.empty(lib.tq_conv_weight_pack_bytes(co, ci, k, mode), dtype=torch.uint8, device=w.device)
+    check(lib.tq_pack_conv_weight(_p(w.contiguous()), co, ci, k, mode, _p(out), _stream(w.device)), "pack")
+    return out
+
+
+def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=False, emb=None, residual=None,
+           stride=1, upsample=False, stats=True, dropout_p=0.0, dropout_seed=0, dropout_site=0):
+    """x0/x1 (B, T, C) channels-last fp32; weight (C_out, C_in, K) torch layout.  Returns (y, stats|None)."""
+    lib = _lib.load()
+    B, T_in, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[2]
+    C_out, C_in, K = weight.shape
+    assert C_in == C0 + C1
+    T_out = (T_in + 2 * (K // 2) - K) // 2 + 1 if stride == 2 else (2 * T_in if upsample else T_in)
+    y = torch.empty(B, T_out, C_out, device=x0.device)
+    st = torch.empty(B, nslots(T_out), C_out, 2, device=x0.device) if stats else None
+    d = TqConvDesc()
+    d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T_in, T_out, C0, C1, C_out
+    d.ktaps, d.stride, d.pad, d.upsample = K, stride, K // 2, int(upsample)
+    f = 0
+    if gscale is not None:
+        f |= TQ_CONV_GN
+    if silu:
+        f |= TQ_CONV_SILU
+    if emb is not None:
+        f |= TQ_CONV_EMB
+    if residual is not None:
+        f |= TQ_CONV_RES
+    if stats:
+        f |= TQ_CONV_STATS
+    if dropout_p > 0:
+        f |= TQ_CONV_DROPOUT
+    d.flags = f
+    d.emb_stride = 0 if emb is None else emb.stride(0)
+    d.dropout_site, d.dropout_p, d.dropout_seed = dropout_site, dropout_p, dropout_seed
+    wp = pack_conv_weight(weight, 0)
+    check(lib.tq_conv1d_fwd(C.byref(d), _p(x0), _p(x1), _p(gscale), _p(gshift), _p(wp), _p(bias), _p(emb), _p(residual),
+                            _p(y), _p(st), _stream(x0.device)), "conv1d")
+    return y, st
+
+
+def gn_finalize(stats0, C0, T, gamma, beta, stats1=None, C1=0):
+    lib = _lib.load()
+    B = stats0.shape[0]
+    Cn = C0 + C1
+    gs, gh = torch.empty(B, Cn, device=gamma.device), torch.empty(B, Cn, device=gamma.device)
+    mr = torch.empty(B, 32, 2, device=gamma.device)
+    check(lib.tq_gn_finalize(_p(stats0), C0, _p(stats1), C1, B, T, _p(gamma), _p(beta), _p(gs), _p(gh), _p(mr),
+                             _stream(gamma.device)), "gn_finalize")
+    return gs, gh, mr
+
+
+def stem_conv(x_nct, weight, bias, in_scale=None, stats=True):
+    lib = _lib.load()
+    B, Cin, T = x_nct.shape
+    Cout, _, K = weight.shape
+    y = torch.empty(B, T, Cout, device=x_nct.device)
+    st = torch.empty(B, nslots(T), Cout, 2, device=x_nct.device) if stats else None
+    check(lib.tq_stem_conv_fwd(_p(x_nct.contiguous()), _p(in_scale), _p(weight.contiguous()), _p(bias), _p(y), _p(st), B, Cin,
+                               T, Cout, K, _stream(x_nct.device)), "stem")
+    return y, st
+
+
+def head_conv(x, weight, bias, gscale=None, gshift=None, c_out=None, c_skip=None, skip_src=None):
+    lib = _lib.load()
+    B, T, Cin = x.shape
+    Cout, _, K = weight.shape
+    y = torch.empty(B, Cout, T, device=x.device)
+    check(lib.tq_head_conv_fwd(_p(x), _p(gscale), _p(gshift), _p(weight.contiguous()), _p(bias), _p(c_out), _p(c_skip),
+                               _p(skip_src), _p(y), B, T, Cin, Cout, K, _stream(x.device)), "head")
+    return y
+
+
+def attention(qkv, heads):
+    lib = _lib.load()
+    B, T, C3 = qkv.shape
+    D = C3 // (3 * heads)
+    out = torch.empty(B, T, heads * D, device=qkv.device)
+    check(lib.tq_attention_fwd(_p(qkv), _p(out), B, T, heads, D, _stream(qkv.device)), "attention")
+    return out
+
+
+def linear(x, w, b=None):
+    lib = _lib.load()
+    B, E = x.shape
+    N = w.shape[0]
+    out = torch.empty(B, N, device=x.device)
+    check(lib.tq_linear_fwd(_p(x), _p(w.contiguous()), _p(b), _p(out), B, E, N, _stream(x.device)), "linear")
+    return out

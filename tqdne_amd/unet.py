@@ -1,0 +1,207 @@
+"""UNetModel: drop-in for ``tqdne.unet.UNetModel`` (reference tqdne/unet.py:146-398) whose forward runs on
+hand-written gfx950 kernels through the C ABI of ``libtqdne_hip.so``.
+
+Same constructor keywords, same ``forward(x, timesteps, cond=None)`` contract (incl. the assert of
+unet.py:378-380), same ``state_dict`` keys / shapes / registration order, and the same
+default initialisation (parameters are created by the same torch initialisers in the same order, so
+``torch.manual_seed(s); UNetModel(**cfg)`` yields bit-identical weights to the reference).
+
+The torch ``nn.Conv1d`` / ``nn.GroupNorm`` / ``nn.Linear`` objects below are *parameter containers only*: their
+``forward`` is never called.  There is no CPU or ATen fallback: tensors must live on a ROCm device and the
+HIP library must be built, otherwise ``forward`` raises.
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import engine
+
+GN_GROUPS = 32
+
+
+def _gn(ch: int) -> nn.GroupNorm:  # reference nn.py:90-105 (GroupNorm32(32, ch))
+    return nn.GroupNorm(GN_GROUPS, ch)
+
+
+def _zero(m: nn.Module) -> nn.Module:  # reference nn.py:59-63
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+class FourierParams(nn.Module):
+    """blocks.py:15-26: frozen W ~ N(0,1)*scale."""
+
+    def __init__(self, channels: int, scale: float = 0.02):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(channels // 2) * scale, requires_grad=False)
+
+
+class ResBlockParams(nn.Module):
+    """Parameters of the time-conditioned ResBlock (unet.py:42-143) / plain ResBlock (blocks.py:233-260)."""
+
+    kind = "res"
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, kernel_size=3):
+        super().__init__()
+        out_channels = out_channels or channels
+        self.channels, self.out_channels, self.kernel_size, self.dropout = channels, out_channels, kernel_size, dropout
+        self.in_layers = nn.Sequential(_gn(channels), nn.SiLU(), nn.Conv1d(channels, out_channels, kernel_size, padding="same"))
+        if emb_channels is not None:
+            self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, out_channels))
+        self.out_layers = nn.Sequential(
+            _gn(out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+            _zero(nn.Conv1d(out_channels, out_channels, kernel_size, padding="same")),
+        )
+        if out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = nn.Conv1d(channels, out_channels, 1)
+
+
+class AttentionParams(nn.Module):
+    """blocks.py:111-145 (QKVAttention variant; the flash_attn variant needs a package the reference never enables)."""
+
+    kind = "attn"
+
+    def __init__(self, channels, num_heads=1):
+        super().__init__()
+        self.channels, self.num_heads = channels, num_heads
+        self.norm = _gn(channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.proj_out = _zero(nn.Conv1d(channels, channels, 1))
+
+
+class DownsampleParams(nn.Module):
+    """blocks.py:69-108 with use_conv=True: conv k (default 3), stride 2, padding k//2."""
+
+    kind = "down"
+
+    def __init__(self, channels, out_channels=None, kernel_size=3):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.op = nn.Conv1d(channels, self.out_channels, kernel_size, stride=2, padding=kernel_size // 2)
+
+
+class UpsampleParams(nn.Module):
+    """blocks.py:29-66 with use_conv=True: nearest x2 then "same" conv."""
+
+    kind = "up"
+
+    def __init__(self, channels, out_channels=None, kernel_size=3):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.conv = nn.Conv1d(channels, self.out_channels, kernel_size, padding="same")
+
+
+class BlockSeq(nn.Sequential):
+    """Stands where the reference has TimestepEmbedSequential (unet.py:27-39): an indexable list of layers."""
+
+
+class UNetModel(nn.Module):
+    def __init__(
+        self,
+        in_channels,
+        model_channels,
+        out_channels,
+        num_res_blocks,
+        attention_resolutions=(8, 16, 32),
+        dropout=0,
+        channel_mult=(1, 2, 4, 8),
+        conv_kernel_size=3,
+        conv_resample=True,
+        dims=2,
+        cond_features=None,
+        cond_emb_scale=None,
+        use_checkpoint=False,
+        num_heads=1,
+        use_scale_shift_norm=False,
+        flash_attention=True,
+        use_causal_mask=False,
+    ):
+        super().__init__()
+        if dims != 1:
+            raise NotImplementedError(
+                "tqdne_amd.UNetModel implements the 1-D hot path (dims=1); the 2-D spectrogram family is out of scope"
+            )
+        if use_scale_shift_norm or cond_emb_scale is not None or not conv_resample or use_causal_mask:
+            raise NotImplementedError("option unused by every reference 1-D config and not implemented on the HIP path")
+        # flash_attention is accepted and ignored: the fused kernel is always flash-style (blocks.py:193-230 needs flash_attn)
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions = num_res_blocks, tuple(attention_resolutions)
+        self.dropout, self.channel_mult, self.conv_kernel_size = dropout, tuple(channel_mult), conv_kernel_size
+        self.num_heads, self.use_checkpoint = num_heads, use_checkpoint
+
+        embed_dim = model_channels * 4
+        self.time_embed = FourierParams(model_channels)
+        self.time_mlp = nn.Sequential(nn.Linear(model_channels, embed_dim), nn.SiLU(), nn.Linear(embed_dim, embed_dim))
+        self.cond_features = cond_features
+        if cond_features is not None:
+            self.cond_embed = None
+            self.cond_mlp = nn.Sequential(nn.Linear(cond_features, embed_dim), nn.SiLU(), nn.Linear(embed_dim, embed_dim))
+
+        k = conv_kernel_size
+        ch = input_ch = int(channel_mult[0] * model_channels)
+        self.input_blocks = nn.ModuleList([BlockSeq(nn.Conv1d(in_channels, ch, k, padding="same"))])
+        skip_chans = [ch]
+        ds = 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlockParams(ch, embed_dim, dropout, int(mult * model_channels), k)]
+                ch = int(mult * model_channels)
+                if ds in self.attention_resolutions:
+                    layers.append(AttentionParams(ch, num_heads))
+                self.input_blocks.append(BlockSeq(*layers))
+                skip_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(BlockSeq(DownsampleParams(ch, ch)))  # kernel 3: unet.py:273 passes none
+                skip_chans.append(ch)
+                ds *= 2
+
+        self.middle_block = BlockSeq(
+            ResBlockParams(ch, embed_dim, dropout, None, k), AttentionParams(ch, num_heads),
+            ResBlockParams(ch, embed_dim, dropout, None, k),
+        )
+
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = skip_chans.pop()
+                layers = [ResBlockParams(ch + ich, embed_dim, dropout, int(model_channels * mult), k)]
+                ch = int(model_channels * mult)
+                if ds in self.attention_resolutions:
+                    layers.append(AttentionParams(ch, num_heads))
+                if level and i == num_res_blocks:
+                    layers.append(UpsampleParams(ch, ch, k))
+                    ds //= 2
+                self.output_blocks.append(BlockSeq(*layers))
+
+        self.out = nn.Sequential(_gn(ch), nn.SiLU(), _zero(nn.Conv1d(input_ch, out_channels, k, padding="same")))
+        self._engine_cache = {}
+
+    # ------------------------------------------------------------------ execution
+    def _engine(self, B: int, T: int, device: torch.device) -> "engine.UNetEngine":
+        key = (B, T, str(device))
+        eng = self._engine_cache.get(key)
+        if eng is None:
+            eng = engine.UNetEngine(self, B, T, device)
+            self._engine_cache[key] = eng
+        return eng
+
+    def forward(self, x, timesteps, cond=None):
+        """x (N, C, T) fp32 on a ROCm device, timesteps (N,), cond (N, cond_features) or None -> (N, C_out, T)."""
+        assert (cond is not None) == (self.cond_features is not None), (
+            "must specify cond if and only if the model is conditioned"
+        )
+        engine.require_device(x)
+        eng = self._engine(x.shape[0], x.shape[2], x.device)
+        y = eng.forward(x, timesteps, cond, train=self.training and torch.is_grad_enabled())
+        return y.clone()
+
+    def _apply(self, fn, *a, **k):  # parameters moved (.to / .cuda): compiled plans hold stale pointers
+        self._engine_cache = {}
+        return super()._apply(fn, *a, **k)
