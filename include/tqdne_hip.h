@@ -51,6 +51,24 @@ typedef struct TqConvDesc {
     uint64_t dropout_seed;
 } TqConvDesc;
 
+/* flags of TqConvBwdDesc.flags: which stages the FORWARD conv applied to its input */
+#define TQ_BWD_GN 1       /* forward input was GroupNorm-folded (gscale/gshift given) */
+#define TQ_BWD_SILU 2     /* forward applied SiLU: multiply by silu'(gscale*x+gshift) */
+#define TQ_BWD_DROPOUT 4  /* forward applied dropout: re-generate the same mask */
+#define TQ_BWD_ACCUM 8    /* add to dx instead of overwriting (tensor consumed by several ops) */
+#define TQ_BWD_STATS 16   /* emit per-channel partial sums {sum g, sum g*x} for the GroupNorm backward */
+
+typedef struct TqConvBwdDesc {
+    int32_t B, T;
+    int32_t C_dy;         /* channels of the incoming gradient (= forward C_out) */
+    int32_t C_dx0, C_dx1; /* channel split of the produced gradient (= forward C_in0, C_in1) */
+    int32_t ktaps;        /* stride-1 "same" convs only; strided / upsampled ones are composed with tq_zero_stuff / tq_pair_sum */
+    int32_t flags;
+    uint32_t dropout_site;
+    float dropout_p;
+    uint64_t dropout_seed;
+} TqConvBwdDesc;
+
 int tq_abi_version(void);
 
 /* ---- weights -------------------------------------------------------------------------------------------- */
@@ -67,6 +85,20 @@ int tq_conv_tile_co(int C_out);
 int tq_conv1d_fwd(const TqConvDesc* desc, const float* x0, const float* x1, const float* gscale, const float* gshift,
                   const void* packed_w, const float* bias, const float* emb, const float* residual, float* y,
                   float* stats_partial, hipStream_t stream);
+
+/* Data gradient of tq_conv1d_fwd (stride 1): g = (W^T * dy) chained through the forward prologue (dropout, SiLU,
+ * folded GN scale); packed_w_t from tq_pack_conv_weight(mode 1).  x0/x1/gscale/gshift are the FORWARD conv's inputs.
+ * Autograd counterpart of the ATen conv/SiLU/dropout backward chain Lightning runs for edm.py:136 training_step. */
+int tq_conv1d_bwd_data(const TqConvBwdDesc* desc, const float* dy, const void* packed_w_t, const float* x0, const float* x1,
+                       const float* gscale, const float* gshift, float* dx0, float* dx1, float* gstats_partial,
+                       hipStream_t stream);
+
+/* Weight gradient of tq_conv1d_fwd: dw (C_out, C_in, K) fp32 (overwritten) = sum_{b,t} dy * xhat, xhat recomputed from the
+ * FORWARD conv's inputs exactly as the forward prologue does (same desc, incl. dropout seed).  workspace: >=
+ * tq_conv1d_bwd_weight_workspace(desc) bytes of scratch (partial slabs of the (b,t) splits). */
+size_t tq_conv1d_bwd_weight_workspace(const TqConvDesc* desc);
+int tq_conv1d_bwd_weight(const TqConvDesc* desc, const float* dy, const float* x0, const float* x1, const float* gscale,
+                         const float* gshift, float* dw, void* workspace, size_t ws_bytes, hipStream_t stream);
 
 /* First conv of the network: (B, C_in<=16, T) fp32 input, scaled per sample by in_scale[b] (EDM c_in, edm.py:107;
  * NULL = 1), k taps "same" -> (B, T, C_out) channels-last + bias (+ partial statistics).  unet.py:233. */
@@ -86,6 +118,31 @@ int tq_head_conv_fwd(const float* x, const float* gscale, const float* gshift, c
 int tq_gn_finalize(const float* stats0, int C0, const float* stats1, int C1, int B, int T, const float* gamma,
                    const float* beta, float* gscale, float* gshift, float* mean_rstd, hipStream_t stream);
 
+/* GroupNorm32 backward, step 1: per-channel partial sums {sum g, sum g*x} (from tq_conv1d_bwd_data / tq_head_conv_bwd)
+ * + saved mean/rstd + gamma -> coefficients with dx = A*g + Bc*x + Cc, and dgamma/dbeta (atomically added: zero them first). */
+int tq_gn_bwd_finalize(const float* gstats_partial, const float* mean_rstd, const float* gamma, int B, int C, int T,
+                       float* coef_a, float* coef_b, float* coef_c, float* dgamma, float* dbeta, hipStream_t stream);
+/* step 2, per concat source (channels [c_offset, c_offset+C_src) of the coefficients):
+ * dx (+)= A*g + Bc*x + Cc (+ r);  r = gradient arriving over the residual path (NULL: none). */
+int tq_gn_bwd_apply(const float* g, const float* x, const float* r, const float* coef_a, const float* coef_b,
+                    const float* coef_c, float* dx, int B, int T, int C_src, int C_total, int c_offset, int accumulate,
+                    hipStream_t stream);
+/* out_bc[b*bc_stride + c] += bscale[b] * sum_t dy[b,t,c];  out_c[c] += sum_{b,t} (...)   (bias / embedding gradients) */
+int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, const float* bscale,
+              hipStream_t stream);
+/* gradient plumbing of the strided / upsampled convs: out[b,u,:] = (u even) ? dy[b,u/2,:] : 0 for u < T_in;
+ * dx[b,t,:] (+)= d_up[b,2t,:] + d_up[b,2t+1,:] */
+int tq_zero_stuff(const float* dy, float* out, int B, int T_out, int T_in, int C, hipStream_t stream);
+int tq_pair_sum(const float* d_up, float* dx, int B, int T, int C, int accumulate, hipStream_t stream);
+/* stem conv weight gradient (atomically added into zeroed dw (C_out, C_in, K)) */
+int tq_stem_conv_bwd_weight(const float* dy, const float* x_nct, const float* in_scale, float* dw, int B, int C_in, int T,
+                            int C_out, int ktaps, hipStream_t stream);
+/* head conv backward: dF = c_out[b]*dpred; g_out (B,T,C_in) = (W^T*dF)*silu'(gscale*x+gshift) with GN partial sums;
+ * dw, db atomically added (zero them first) */
+int tq_head_conv_bwd(const float* dpred_nct, const float* c_out, const float* x, const float* gscale, const float* gshift,
+                     const float* w, float* g_out, float* gstats_partial, float* dw, float* db, int B, int T, int C_in,
+                     int C_out, int ktaps, hipStream_t stream);
+
 /* ---- embeddings ------------------------------------------------------------------------------------------- */
 /* emb = time_mlp(fourier(t)) (+ cond_mlp(cond)); writes emb (B, E) and silu(emb) (B, E).  E = 4*mc.
  * blocks.py:22-26, unet.py:210-227,383-388.  cond pointers NULL when the model is unconditioned. */
@@ -99,7 +156,7 @@ int tq_linear_fwd(const float* x, const float* w, const float* bias, float* out,
 
 /* ---- attention -------------------------------------------------------------------------------------------- */
 /* QKVAttention (blocks.py:156-190), qkv (B, T, 3*H*D) channels-last with channel order [q heads | k heads | v heads],
- * q and k each scaled by D^-1/4, softmax over keys in fp32, out (B, T, H*D).  D in {32, 64}. */
+ * q and k each scaled by D^-1/4, softmax over keys in fp32, out (B, T, H*D).  D in {32, 64, 128}. */
 int tq_attention_fwd(const float* qkv, float* out, int B, int T, int H, int D, hipStream_t stream);
 
 /* ---- EDM / sampler elementwise ------------------------------------------------------------------------------ */

@@ -1,0 +1,233 @@
+"""Backward-kernel parity (GPU): each gradient kernel against torch autograd of the same op chain on the CPU (fp32)."""
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def cl(x):
+    return x.permute(0, 2, 1).contiguous().to(dev())
+
+
+def ncw(y):
+    return y.permute(0, 2, 1).cpu()
+
+
+def ref_slot_sums(a, b):
+    B, C, T = a.shape
+    ns = (T + 127) // 128
+    out = torch.zeros(B, ns, C, 2)
+    for s in range(ns):
+        sa, sb = a[:, :, s * 128:(s + 1) * 128].double(), b[:, :, s * 128:(s + 1) * 128].double()
+        out[:, s, :, 0] = sa.sum(-1)
+        out[:, s, :, 1] = (sa * sb).sum(-1)
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,k,T", [(64, 64, 5, 256), (128, 256, 5, 200), (256, 128, 3, 127), (32, 64, 1, 300), (512, 256, 1, 100)])
+def test_dgrad_plain(cin, cout, k, T):
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + k + T)
+    x = torch.randn(2, cin, T, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    dy = torch.randn(2, cout, T, generator=g)
+    F.conv1d(x, w, None, padding=k // 2).backward(dy)
+    g0, _, _ = ops.conv1d_bwd_data(cl(dy), w.to(dev()))
+    assert rel_err(ncw(g0), x.grad) < TOL
+
+
+def test_dgrad_activation_chain_concat_and_stats():
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, C0, C1, Co, T = 2, 128, 64, 128, 333
+    x0, x1 = torch.randn(B, C0, T, generator=g), torch.randn(B, C1, T, generator=g) + 0.5
+    a, s = torch.randn(B, C0 + C1, generator=g), torch.randn(B, C0 + C1, generator=g)
+    w = torch.randn(Co, C0 + C1, 5, generator=g) / 30
+    dy = torch.randn(B, Co, T, generator=g)
+    x = torch.cat([x0, x1], 1)
+    u = (x * a[:, :, None] + s[:, :, None]).requires_grad_(True)
+    F.conv1d(F.silu(u), w, None, padding=2).backward(dy)
+    d = dev()
+    g0, g1, st = ops.conv1d_bwd_data(cl(dy), w.to(d), x0=cl(x0), x1=cl(x1), gscale=a.to(d), gshift=s.to(d), silu=True,
+                                     stats=True, split=C0)
+    got = torch.cat([ncw(g0), ncw(g1)], 1)
+    assert rel_err(got, u.grad) < TOL
+    assert rel_err(st.cpu(), ref_slot_sums(u.grad, x)) < TOL
+    # accumulate flag
+    base0, base1 = torch.ones_like(g0), torch.ones_like(g1)
+    ops.conv1d_bwd_data(cl(dy), w.to(d), x0=cl(x0), x1=cl(x1), gscale=a.to(d), gshift=s.to(d), silu=True, split=C0,
+                        accumulate_into=(base0, base1))
+    assert rel_err(torch.cat([ncw(base0), ncw(base1)], 1), u.grad + 1) < TOL
+
+
+@pytest.mark.parametrize("cin,cout,k,T,B", [(64, 64, 5, 256, 3), (128, 256, 5, 200, 2), (256, 128, 3, 127, 2), (32, 64, 1, 300, 2),
+                                            (512, 256, 1, 64, 2), (96, 32, 5, 130, 5), (256, 768, 1, 512, 2)])
+def test_wgrad_plain(cin, cout, k, T, B):
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + k + T)
+    x = torch.randn(B, cin, T, generator=g)
+    w = (torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)).requires_grad_(True)
+    dy = torch.randn(B, cout, T, generator=g)
+    F.conv1d(x, w, None, padding=k // 2).backward(dy)
+    dw = ops.conv1d_bwd_weight(cl(dy), cl(x), w.shape)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+
+
+def test_wgrad_fused_prologue_concat():
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, C0, C1, Co, T = 3, 128, 64, 128, 333
+    x0, x1 = torch.randn(B, C0, T, generator=g), torch.randn(B, C1, T, generator=g)
+    a, s = torch.randn(B, C0 + C1, generator=g), torch.randn(B, C0 + C1, generator=g)
+    w = (torch.randn(Co, C0 + C1, 5, generator=g) / 30).requires_grad_(True)
+    dy = torch.randn(B, Co, T, generator=g)
+    xh = F.silu(torch.cat([x0, x1], 1) * a[:, :, None] + s[:, :, None])
+    F.conv1d(xh, w, None, padding=2).backward(dy)
+    d = dev()
+    dw = ops.conv1d_bwd_weight(cl(dy), cl(x0), w.shape, x1=cl(x1), gscale=a.to(d), gshift=s.to(d), silu=True)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+
+
+@pytest.mark.parametrize("C,T", [(64, 256), (128, 251), (32, 130)])
+def test_downsample_backward(C, T):
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(2, C, T, generator=g, requires_grad=True)
+    w = (torch.randn(C, C, 3, generator=g) / math.sqrt(3 * C)).requires_grad_(True)
+    y = F.conv1d(x, w, None, stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dyz = ops.zero_stuff(cl(dy), T)
+    g0, _, _ = ops.conv1d_bwd_data(dyz, w.detach().to(dev()))
+    assert rel_err(ncw(g0), x.grad) < TOL
+    dw = ops.conv1d_bwd_weight(cl(dy), cl(x.detach()), w.shape, stride=2)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+
+
+@pytest.mark.parametrize("C,T,k", [(128, 64, 5), (64, 100, 3), (256, 127, 5)])
+def test_upsample_backward(C, T, k):
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(2, C, T, generator=g, requires_grad=True)
+    w = (torch.randn(C, C, k, generator=g) / math.sqrt(k * C)).requires_grad_(True)
+    y = F.conv1d(F.interpolate(x, scale_factor=2, mode="nearest"), w, None, padding=k // 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    gup, _, _ = ops.conv1d_bwd_data(cl(dy), w.detach().to(dev()))
+    dx = ops.pair_sum(gup)
+    assert rel_err(ncw(dx), x.grad) < TOL
+    dw = ops.conv1d_bwd_weight(cl(dy), cl(x.detach()), w.shape, upsample=True)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+
+
+@pytest.mark.parametrize("C0,C1,Co,T", [(64, 0, 64, 256), (128, 64, 128, 200), (64, 32, 64, 130)])
+def test_groupnorm_silu_conv_full_backward(C0, C1, Co, T):
+    """GN32 (over a virtual concat, groups may straddle) -> SiLU -> conv: dx, dgamma, dbeta, dW vs autograd."""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(C0 + C1 + T)
+    B = 2
+    d = dev()
+    x0 = (torch.randn(B, C0, T, generator=g) * 2 + 0.3)
+    x1 = (torch.randn(B, C1, T, generator=g) - 1) if C1 else None
+    gamma = (1 + 0.2 * torch.randn(C0 + C1, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C0 + C1, generator=g)).requires_grad_(True)
+    w = (torch.randn(Co, C0 + C1, 5, generator=g) / 20).requires_grad_(True)
+    dy = torch.randn(B, Co, T, generator=g)
+    x = (torch.cat([x0, x1], 1) if C1 else x0).clone().requires_grad_(True)
+    F.conv1d(F.silu(F.group_norm(x, 32, gamma, beta, 1e-5)), w, None, padding=2).backward(dy)
+    # HIP: forward statistics come from the producers; emulate them with identity 1x1 convs
+    def stats_of(t):
+        eye = torch.zeros(t.shape[1], t.shape[1], 1)
+        eye[torch.arange(t.shape[1]), torch.arange(t.shape[1]), 0] = 1
+        return ops.conv1d(cl(t), eye.to(d), None)[1]
+    s0 = stats_of(x0)
+    s1 = stats_of(x1) if C1 else None
+    gs, gh, mr = ops.gn_finalize(s0, C0, T, gamma.detach().to(d), beta.detach().to(d), s1, C1)
+    g0, g1, st = ops.conv1d_bwd_data(cl(dy), w.detach().to(d), x0=cl(x0), x1=cl(x1) if C1 else None, gscale=gs, gshift=gh,
+                                     silu=True, stats=True, split=C0)
+    ca, cb, cc, dgam, dbet = ops.gn_bwd_finalize(st, mr, gamma.detach().to(d), T)
+    dx0 = ops.gn_bwd_apply(g0, cl(x0), (ca, cb, cc), C0 + C1, 0)
+    got = ncw(dx0)
+    if C1:
+        dx1 = ops.gn_bwd_apply(g1, cl(x1), (ca, cb, cc), C0 + C1, C0)
+        got = torch.cat([got, ncw(dx1)], 1)
+    assert rel_err(got, x.grad) < TOL
+    assert rel_err(dgam.cpu(), gamma.grad) < TOL
+    assert rel_err(dbet.cpu(), beta.grad) < TOL
+    dw = ops.conv1d_bwd_weight(cl(dy), cl(x0), w.shape, x1=cl(x1) if C1 else None, gscale=gs, gshift=gh, silu=True)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+
+
+def test_colsum():
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for C in (32, 64, 256, 768):
+        dy = torch.randn(3, C, 300, generator=g)
+        sc = torch.rand(3, generator=g)
+        obc, oc = ops.colsum(cl(dy), bscale=sc.to(dev()))
+        ref = dy.sum(-1) * sc[:, None]
+        assert rel_err(obc.cpu(), ref) < 1e-5 and rel_err(oc.cpu(), ref.sum(0)) < 1e-5
+
+
+def test_stem_and_head_backward():
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(3)
+    d = dev()
+    B, T = 2, 300
+    # stem
+    x = torch.randn(B, 3, T, generator=g)
+    sc = torch.rand(B, generator=g) + 0.5
+    w = (torch.randn(64, 3, 5, generator=g) / 4).requires_grad_(True)
+    dy = torch.randn(B, 64, T, generator=g)
+    F.conv1d(x * sc[:, None, None], w, None, padding=2).backward(dy)
+    dw = ops.stem_conv_bwd_weight(cl(dy), x.to(d), w.shape, in_scale=sc.to(d))
+    assert rel_err(dw.cpu(), w.grad) < 1e-5
+    # head
+    h = torch.randn(B, 64, T, generator=g)
+    a, s = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+    wh = (torch.randn(3, 64, 5, generator=g) / 10).requires_grad_(True)
+    bh = torch.randn(3, generator=g).requires_grad_(True)
+    co = torch.rand(B, generator=g) + 0.5
+    dpred = torch.randn(B, 3, T, generator=g)
+    u = (h * a[:, :, None] + s[:, :, None]).requires_grad_(True)
+    (F.conv1d(F.silu(u), wh, bh, padding=2) * co[:, None, None]).backward(dpred)
+    G, st, dwh, dbh = ops.head_conv_bwd(dpred.to(d), cl(h), wh.detach().to(d), a.to(d), s.to(d), co.to(d))
+    assert rel_err(ncw(G), u.grad) < 1e-5
+    assert rel_err(dwh.cpu(), wh.grad) < 1e-5 and rel_err(dbh.cpu(), bh.grad) < 1e-5
+    assert rel_err(st.cpu(), ref_slot_sums(u.grad, h)) < 1e-5
+
+
+def test_dropout_forward_backward_consistency():
+    """the mask regenerated in dgrad/wgrad equals the forward mask: finite-difference-free check via linearity"""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(4)
+    d = dev()
+    B, C, T = 2, 64, 256
+    x = torch.randn(B, C, T, generator=g)
+    w = torch.randn(C, C, 5, generator=g) / 18
+    dy = torch.randn(B, C, T, generator=g)
+    kw = dict(dropout_p=0.25, dropout_seed=99, dropout_site=7)
+    ones, zeros = torch.ones(B, C, device=d), torch.zeros(B, C, device=d)
+    eye = torch.zeros(C, C, 1); eye[torch.arange(C), torch.arange(C), 0] = 1
+    mask = ncw(ops.conv1d(torch.ones(B, T, C, device=d), eye.to(d), None, **kw)[0])  # mask/(1-p)
+    y, _ = ops.conv1d(cl(x), w.to(d), None, gscale=ones, gshift=zeros, **kw)
+    xm = (x * mask).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv1d(xm, wr, None, padding=2)
+    assert rel_err(ncw(y), yr) < TOL
+    yr.backward(dy)
+    g0, _, _ = ops.conv1d_bwd_data(cl(dy), w.to(d), x0=cl(x), gscale=ones, gshift=zeros, **kw)
+    assert rel_err(ncw(g0), xm.grad * mask) < TOL
+    dw = ops.conv1d_bwd_weight(cl(dy), cl(x), w.shape, gscale=ones, gshift=zeros, **kw)
+    assert rel_err(dw.cpu(), wr.grad) < TOL

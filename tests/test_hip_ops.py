@@ -40,6 +40,7 @@ def ref_stats(y_nct):
 @pytest.mark.parametrize("cin,cout,k,T", [
     (64, 64, 5, 256), (64, 128, 5, 384), (128, 256, 5, 200), (256, 256, 5, 127), (32, 32, 5, 300),
     (32, 96, 3, 130), (64, 64, 1, 256), (256, 768, 1, 512), (512, 256, 1, 100), (96, 64, 5, 508),
+    (64, 64, 5, 64), (32, 32, 5, 62), (64, 32, 3, 31), (128, 64, 5, 129),
 ])
 def test_conv_plain(cin, cout, k, T):
     from tqdne_amd import ops
@@ -118,7 +119,7 @@ def test_group_norm_via_stats(C0, C1, T):
     assert rel_err(got, ref) < 2e-5
 
 
-@pytest.mark.parametrize("H,D,T", [(4, 64, 512), (2, 32, 62), (1, 64, 127), (4, 64, 508)])
+@pytest.mark.parametrize("H,D,T", [(4, 64, 512), (2, 32, 62), (1, 64, 127), (4, 64, 508), (1, 128, 512), (2, 128, 100)])
 def test_attention(H, D, T):
     from tqdne_amd import ops
     g = torch.Generator().manual_seed(H * D + T)

@@ -17,6 +17,7 @@ F = C.c_float
 SZ = C.c_size_t
 
 TQ_CONV_GN, TQ_CONV_SILU, TQ_CONV_EMB, TQ_CONV_RES, TQ_CONV_STATS, TQ_CONV_DROPOUT = 1, 2, 4, 8, 16, 32
+TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_DROPOUT, TQ_BWD_ACCUM, TQ_BWD_STATS = 1, 2, 4, 8, 16
 STAT_SLOT = 128
 
 
@@ -27,6 +28,14 @@ class TqConvDesc(C.Structure):
         ("ktaps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("upsample", C.c_int32), ("flags", C.c_int32), ("emb_stride", C.c_int32),
         ("dropout_site", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+    ]
+
+
+class TqConvBwdDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("C_dy", C.c_int32), ("C_dx0", C.c_int32), ("C_dx1", C.c_int32),
+        ("ktaps", C.c_int32), ("flags", C.c_int32), ("dropout_site", C.c_uint32), ("dropout_p", C.c_float),
+        ("dropout_seed", C.c_uint64),
     ]
 
 
@@ -49,6 +58,16 @@ _PROTOS = {
     "tq_heun_euler": (I, [VP] * 7 + [SZ, VP]),
     "tq_heun_correct": (I, [VP] * 8 + [SZ, VP]),
     "tq_sampler_init": (I, [VP] * 4 + [SZ, VP]),
+    "tq_conv1d_bwd_data": (I, [VP] * 11),
+    "tq_conv1d_bwd_weight_workspace": (SZ, [VP]),
+    "tq_conv1d_bwd_weight": (I, [VP] * 8 + [SZ, VP]),
+    "tq_gn_bwd_finalize": (I, [VP, VP, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
+    "tq_gn_bwd_apply": (I, [VP] * 7 + [I] * 6 + [VP]),
+    "tq_colsum": (I, [VP, I, I, I, VP, I, VP, VP, VP]),
+    "tq_zero_stuff": (I, [VP, VP, I, I, I, I, VP]),
+    "tq_pair_sum": (I, [VP, VP, I, I, I, I, VP]),
+    "tq_stem_conv_bwd_weight": (I, [VP] * 4 + [I] * 5 + [VP]),
+    "tq_head_conv_bwd": (I, [VP] * 10 + [I] * 5 + [VP]),
 }
 
 # entry points of later rounds are optional at load time but listed in the header check

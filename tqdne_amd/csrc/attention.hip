@@ -207,6 +207,8 @@ template <int D>
 int launch_attn(const float* qkv, float* out, int B, int T, int H, hipStream_t stream) {
     constexpr int KROW = D * 2 + 16, VROW = KTILE * 2 + 16, PROW = KTILE * 2 + 16;
     const size_t sh = 2 * KTILE * KROW + 2 * D * VROW + 4 * 2 * 16 * PROW;
+    if (sh > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int nqt = (T + QT - 1) / QT;
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));  // blocks.py:173 (python double, then fp32)
     hipLaunchKernelGGL(attention_kernel<D>, dim3(B * H * nqt), dim3(256), sh, stream, qkv, out, T, H, scale);
@@ -220,5 +222,6 @@ extern "C" int tq_attention_fwd(const float* qkv, float* out, int B, int T, int 
     if (B <= 0 || T <= 0 || H <= 0) return TQ_ERR_SHAPE;
     if (D == 64) return launch_attn<64>(qkv, out, B, T, H, stream);
     if (D == 32) return launch_attn<32>(qkv, out, B, T, H, stream);
+    if (D == 128) return launch_attn<128>(qkv, out, B, T, H, stream);
     return TQ_ERR_SHAPE;
 }

@@ -1,0 +1,698 @@
+// Backward kernels of the tqdne 1-D UNet training step on gfx950 (the autograd work Lightning runs for
+// reference edm.py:136 training_step):
+//   * weight gradient of the fused conv (MFMA, bf16x3, transposed LDS reads) + slab reduction
+//   * GroupNorm32 backward (finalise group sums -> per-(b,c) coefficients; elementwise apply)
+//   * column sums (bias / time-embedding gradients), zero-stuffing and pair-sum (strided / upsampled convs)
+//   * stem weight gradient and head (last conv) backward
+#include "common.hpp"
+#include "../../include/tqdne_hip.h"
+
+using namespace tq;
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of (row q, cols 4p..4p+3); lane i receives
+// column i of rows 0..3.  Two reads (rows +0, +4) give the 8 consecutive k of one MFMA operand fragment.
+__device__ __forceinline__ uint2 lds_tr_read(const unsigned char* p) {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    union { s16x4 s; uint2 u; } c;
+    c.s = v;
+    return c.u;
+}
+
+// =================================================================================================
+// Weight gradient:  dW[co, ci, k] = sum_{b,t} dy[b, t, co] * xhat[b, t*stride + k - pad, ci]
+//   xhat = dropout(SiLU(gscale*x + gshift)) is re-computed while staging, exactly as in the forward kernel.
+// GEMM view: M = co (128 per workgroup, 32 per wave), N = (tap, ci chunk of 32), reduction over (b, t).
+// Both operands need the reduction index contiguous per lane, i.e. a transposed view of the channels-last
+// tiles: the LDS images stay channels-last ([t][c], written with 8-byte stores) and are read with
+// ds_read_b64_tr_b16.  Taps are row offsets of the xhat image.  Partial results of the (b,t) splits go to
+// slabs [split][k][co][ci] with plain 64-byte-segment stores and are summed by wgrad_reduce_kernel
+// (scattered fp32 atomics would run an order of magnitude slower).
+// =================================================================================================
+struct WgArgs {
+    const float* dy;
+    const float* x0;
+    const float* x1;
+    const float* gscale;
+    const float* gshift;
+    float* slab;
+    int B, T_in, T_out, C0, C1, C_out;
+    int flags, nsplit, units_per_split, n_ttiles, n_cotiles, n_cichunks;
+    uint32_t drop_site, drop_thresh;
+    float drop_scale;
+    uint64_t drop_seed;
+};
+
+constexpr int WG_TT = 64;        // reduction positions per staged tile
+constexpr int WG_DY_STRIDE = 272;  // bytes per dy image row (128 co * 2 B + 16 pad)
+constexpr int WG_X_STRIDE = 64;    // bytes per xhat image row (32 ci * 2 B)
+
+template <int KT, int STRIDE, int UPS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
+    constexpr int PAD = (STRIDE == 1) ? KT / 2 : 1;
+    constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
+    constexpr int XIT = (XR * 8 + 255) / 256;
+    constexpr int DY_PLANE = WG_TT * WG_DY_STRIDE;
+    constexpr int X_PLANE = XR * WG_X_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* dy_hi = lds;
+    unsigned char* dy_lo = dy_hi + DY_PLANE;
+    unsigned char* x_hi = dy_lo + DY_PLANE;
+    unsigned char* x_lo = x_hi + X_PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int ct = bid % p.n_cotiles; bid /= p.n_cotiles;
+    const int cc = bid % p.n_cichunks;
+    const int sp = bid / p.n_cichunks;
+    const int co0 = ct * 128;
+    const int cb = cc * 32;
+    const int Cin = p.C0 + p.C1;
+    const int T_src = UPS ? 2 * p.T_in : p.T_in;
+    const int U = p.B * p.n_ttiles;
+    const int u_begin = sp * p.units_per_split;
+    const int u_end = min(U, u_begin + p.units_per_split);
+    const bool wave_active = (co0 + wave * 32) < p.C_out;
+    const int cvalid4 = min(128, p.C_out - co0) >> 2;  // float4 columns of dy actually present
+
+    // xhat source (one concat source per 32-channel chunk)
+    const float* xsrc; int xcs, xoff;
+    if (cb < p.C0) { xsrc = p.x0; xcs = p.C0; xoff = cb; } else { xsrc = p.x1; xcs = p.C1; xoff = cb - p.C0; }
+    const int m = tid & 7;  // float4 column of the xhat tile owned by this thread
+
+    float4 dyr[8];
+    float4 xr[XIT];
+    float4 g_a = make_float4(1.f, 1.f, 1.f, 1.f), g_s = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto xpos = [&](int t0, int i) -> int __attribute__((always_inline)) {
+        if (STRIDE == 1) return t0 - PAD + i;
+        const int par = (i > WG_TT) ? 1 : 0;
+        const int idx = i - par * (WG_TT + 1);
+        return 2 * t0 - PAD + 2 * idx + par;
+    };
+
+    auto load_unit = [&](int u) __attribute__((always_inline)) {
+        const int b = u / p.n_ttiles;
+        const int t0 = (u % p.n_ttiles) * WG_TT;
+        const float* dyb = p.dy + ((size_t)b * p.T_out) * p.C_out + co0;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int task = tid + it * 256;
+            const int row = task >> 5, c4 = task & 31;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + row < p.T_out && c4 < cvalid4) v = *reinterpret_cast<const float4*>(dyb + (size_t)(t0 + row) * p.C_out + 4 * c4);
+            dyr[it] = v;
+        }
+        const float* xb = xsrc + (size_t)b * p.T_in * xcs + xoff + 4 * m;
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = (tid + it * 256) >> 3;
+            const int pos = xpos(t0, i);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < XR && pos >= 0 && pos < T_src) v = *reinterpret_cast<const float4*>(xb + (size_t)(UPS ? (pos >> 1) : pos) * xcs);
+            xr[it] = v;
+        }
+        if (p.flags & TQ_CONV_GN) {
+            g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
+            g_s = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cb + 4 * m);
+        }
+    };
+
+    auto write_unit = [&](int u) __attribute__((always_inline)) {
+        const int b = u / p.n_ttiles;
+        const int t0 = (u % p.n_ttiles) * WG_TT;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int task = tid + it * 256;
+            const int row = task >> 5, c4 = task & 31;
+            const float v[4] = {dyr[it].x, dyr[it].y, dyr[it].z, dyr[it].w};
+            bf16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { __bf16 hh, ll; split_bf16(v[j], hh, ll); h[j] = hh; l[j] = ll; }
+            const int off = row * WG_DY_STRIDE + c4 * 8;
+            *reinterpret_cast<bf16x4*>(dy_hi + off) = h;
+            *reinterpret_cast<bf16x4*>(dy_lo + off) = l;
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = (tid + it * 256) >> 3;
+            if (i >= XR) continue;
+            const int pos = xpos(t0, i);
+            float v[4] = {xr[it].x, xr[it].y, xr[it].z, xr[it].w};
+            if (pos >= 0 && pos < T_src) {
+                if (p.flags & TQ_CONV_GN) {
+                    v[0] = g_a.x * v[0] + g_s.x; v[1] = g_a.y * v[1] + g_s.y;
+                    v[2] = g_a.z * v[2] + g_s.z; v[3] = g_a.w * v[3] + g_s.w;
+                }
+                if (p.flags & TQ_CONV_SILU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+                }
+                if (p.flags & TQ_CONV_DROPOUT) {
+                    const uint64_t e0 = ((uint64_t)b * T_src + pos) * Cin + cb + 4 * m;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+                }
+            }
+            bf16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { __bf16 hh, ll; split_bf16(v[j], hh, ll); h[j] = hh; l[j] = ll; }
+            const int off = i * WG_X_STRIDE + m * 8;
+            *reinterpret_cast<bf16x4*>(x_hi + off) = h;
+            *reinterpret_cast<bf16x4*>(x_lo + off) = l;
+        }
+    };
+
+    f32x4 acc[2][2][KT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+
+    auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < WG_TT / 32; ++ks) {
+            const int r0 = ks * 32 + 8 * g + q;  // reduction row supplied by this lane (first read; +4 second)
+            Frag ah[2], al[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int off = r0 * WG_DY_STRIDE + (wave * 32 + mb * 16 + 4 * pp) * 2;
+                ah[mb].h[0] = lds_tr_read(dy_hi + off);
+                ah[mb].h[1] = lds_tr_read(dy_hi + off + 4 * WG_DY_STRIDE);
+                al[mb].h[0] = lds_tr_read(dy_lo + off);
+                al[mb].h[1] = lds_tr_read(dy_lo + off + 4 * WG_DY_STRIDE);
+            }
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int xrow = (STRIDE == 1) ? (r0 + k) : ((k & 1) * (WG_TT + 1) + r0 + (k >> 1));
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int off = xrow * WG_X_STRIDE + (nb * 16 + 4 * pp) * 2;
+                    Frag bh, bl;
+                    bh.h[0] = lds_tr_read(x_hi + off);
+                    bh.h[1] = lds_tr_read(x_hi + off + 4 * WG_X_STRIDE);
+                    bl.h[0] = lds_tr_read(x_lo + off);
+                    bl.h[1] = lds_tr_read(x_lo + off + 4 * WG_X_STRIDE);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+                        acc[mb][nb][k] = mfma_x3(ah[mb].v, al[mb].v, bh.v, bl.v, acc[mb][nb][k]);
+                }
+            }
+        }
+    };
+
+    if (u_begin < u_end) load_unit(u_begin);
+    for (int u = u_begin; u < u_end; ++u) {
+        __syncthreads();
+        write_unit(u);
+        __syncthreads();
+        if (u + 1 < u_end) load_unit(u + 1);
+        if (wave_active) compute();
+    }
+
+    // ---- partial result -> slab[sp][k][co][ci]
+    if (!wave_active) return;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wave * 32 + mb * 16 + 4 * (lane >> 4) + r;
+                    const int ci = cb + nb * 16 + (lane & 15);
+                    p.slab[(((size_t)sp * KT + k) * p.C_out + co) * Cin + ci] = acc[mb][nb][k][r];
+                }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int KT, int C_out,
+                                    int C_in) {
+    const size_t n = (size_t)C_out * C_in;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < KT; ++k) {
+        float a = 0.f;
+        for (int s = 0; s < nsplit; ++s) a += slab[((size_t)s * KT + k) * n + i];
+        dw[i * KT + k] = a;
+    }
+}
+
+void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_ttiles, int& nsplit, int& ups) {
+    n_cotiles = (d->C_out + 127) / 128;
+    n_cichunks = (d->C_in0 + d->C_in1) / 32;
+    n_ttiles = (d->T_out + WG_TT - 1) / WG_TT;
+    const int U = d->B * n_ttiles;
+    const int ntiles = n_cotiles * n_cichunks;
+    int want = (768 + ntiles - 1) / ntiles;
+    if (want < 1) want = 1;
+    if (want > U) want = U;
+    ups = (U + want - 1) / want;
+    nsplit = (U + ups - 1) / ups;
+}
+
+template <int KT, int STRIDE, int UPS>
+int launch_wgrad(const WgArgs& a, hipStream_t stream) {
+    constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
+    const size_t sh = 2 * WG_TT * WG_DY_STRIDE + 2 * XR * WG_X_STRIDE;
+    const unsigned grid = (unsigned)(a.n_cotiles * a.n_cichunks * a.nsplit);
+    hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS>), dim3(grid), dim3(256), sh, stream, a);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t tq_conv1d_bwd_weight_workspace(const TqConvDesc* d) {
+    if (!d) return 0;
+    int a, b, c, nsplit, ups;
+    wgrad_plan(d, a, b, c, nsplit, ups);
+    return (size_t)nsplit * d->ktaps * d->C_out * (d->C_in0 + d->C_in1) * sizeof(float);
+}
+
+extern "C" int tq_conv1d_bwd_weight(const TqConvDesc* d, const float* dy, const float* x0, const float* x1,
+                                    const float* gscale, const float* gshift, float* dw, void* workspace, size_t ws_bytes,
+                                    hipStream_t stream) {
+    if (!d || !dy || !x0 || !dw || !workspace) return TQ_ERR_ARG;
+    if (d->C_in0 <= 0 || d->C_in0 % 32 || d->C_in1 < 0 || d->C_in1 % 32 || d->C_out <= 0 || d->C_out % 32) return TQ_ERR_SHAPE;
+    if (d->C_in1 > 0 && !x1) return TQ_ERR_ARG;
+    if ((d->flags & TQ_CONV_GN) && (!gscale || !gshift)) return TQ_ERR_ARG;
+    if (ws_bytes < tq_conv1d_bwd_weight_workspace(d)) return TQ_ERR_ARG;
+    WgArgs a;
+    a.dy = dy; a.x0 = x0; a.x1 = x1; a.gscale = gscale; a.gshift = gshift; a.slab = reinterpret_cast<float*>(workspace);
+    a.B = d->B; a.T_in = d->T_in; a.T_out = d->T_out; a.C0 = d->C_in0; a.C1 = d->C_in1; a.C_out = d->C_out;
+    a.flags = d->flags;
+    wgrad_plan(d, a.n_cotiles, a.n_cichunks, a.n_ttiles, a.nsplit, a.units_per_split);
+    a.drop_site = d->dropout_site; a.drop_seed = d->dropout_seed;
+    float pdrop = d->dropout_p;
+    if (!(d->flags & TQ_CONV_DROPOUT) || pdrop <= 0.f) { a.flags &= ~TQ_CONV_DROPOUT; pdrop = 0.f; }
+    a.drop_thresh = (uint32_t)((double)pdrop * 4294967296.0);
+    a.drop_scale = 1.0f / (1.0f - pdrop);
+    int rc;
+    if (d->stride == 2) {
+        if (d->ktaps != 3) return TQ_ERR_SHAPE;
+        rc = launch_wgrad<3, 2, 0>(a, stream);
+    } else if (d->upsample) {
+        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 1>(a, stream);
+        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 1>(a, stream);
+        else return TQ_ERR_SHAPE;
+    } else {
+        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 0>(a, stream);
+        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 0>(a, stream);
+        else if (d->ktaps == 1) rc = launch_wgrad<1, 1, 0>(a, stream);
+        else return TQ_ERR_SHAPE;
+    }
+    if (rc) return rc;
+    const size_t n = (size_t)d->C_out * (d->C_in0 + d->C_in1);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dw, a.nsplit,
+                       d->ktaps, d->C_out, d->C_in0 + d->C_in1);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================
+// GroupNorm32 backward.  With u = a_c*x + s_c, g = dL/du (already chained through SiLU/dropout by the dgrad
+// epilogue) and per-channel sums S1 = sum_t g, S2 = sum_t g*x:
+//   P1 = sum_{c in grp} gamma_c*S1_c,  P2 = rstd * sum_{c in grp} gamma_c*(S2_c - mean*S1_c),  N = (C/32)*T
+//   dx = (rstd*gamma_c) * g  -  (rstd^2 * P2 / N) * x  +  (rstd^2 * P2 * mean / N - rstd * P1 / N)
+//   dgamma_c += rstd*(S2_c - mean*S1_c),  dbeta_c += S1_c          (atomics over the batch)
+// =================================================================================================
+namespace {
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ gst, const float* __restrict__ mr,
+                                                              const float* __restrict__ gamma, int C, int T, int nslots,
+                                                              float* __restrict__ cA, float* __restrict__ cB,
+                                                              float* __restrict__ cC, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    extern __shared__ double sh[];  // [C][2] then [32][2]
+    const int b = blockIdx.x;
+    double* cs = sh;
+    double* gp = sh + 2 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float* pp = gst + ((size_t)b * nslots * C + c) * 2;
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < nslots; ++s) {
+            const float2 v = *reinterpret_cast<const float2*>(pp + (size_t)s * C * 2);
+            s1 += (double)v.x; s2 += (double)v.y;
+        }
+        cs[2 * c] = s1; cs[2 * c + 1] = s2;
+    }
+    __syncthreads();
+    const int G = C / GN_GROUPS;
+    if (threadIdx.x < GN_GROUPS) {
+        const int g = threadIdx.x;
+        const double mean = (double)mr[((size_t)b * GN_GROUPS + g) * 2], rstd = (double)mr[((size_t)b * GN_GROUPS + g) * 2 + 1];
+        double p1 = 0.0, p2 = 0.0;
+        for (int j = 0; j < G; ++j) {
+            const int c = g * G + j;
+            const double gm = (double)gamma[c];
+            p1 += gm * cs[2 * c];
+            p2 += gm * (cs[2 * c + 1] - mean * cs[2 * c]);
+        }
+        p2 *= rstd;
+        const double n = (double)G * (double)T;
+        gp[2 * g] = -rstd * rstd * p2 / n;                             // coefficient of x
+        gp[2 * g + 1] = rstd * rstd * p2 * mean / n - rstd * p1 / n;   // constant
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / G;
+        const float mean = mr[((size_t)b * GN_GROUPS + g) * 2], rstd = mr[((size_t)b * GN_GROUPS + g) * 2 + 1];
+        cA[(size_t)b * C + c] = rstd * gamma[c];
+        cB[(size_t)b * C + c] = (float)gp[2 * g];
+        cC[(size_t)b * C + c] = (float)gp[2 * g + 1];
+        atomicAdd(dgamma + c, (float)((double)rstd * (cs[2 * c + 1] - (double)mean * cs[2 * c])));
+        atomicAdd(dbeta + c, (float)cs[2 * c]);
+    }
+}
+
+// dx (+)= A[b,c]*g + Bc[b,c]*x + Cc[b,c] (+ r)   for one concat source occupying channels [coff, coff+Cs) of the coefficients
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ r,
+                                    const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
+                                    float* __restrict__ dx, int T, int Cs, int Ctot, int coff, int accum, size_t n4) {
+    const int c4n = Cs >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const size_t bt = i / c4n;
+        const int b = (int)(bt / T);
+        const size_t ko = (size_t)b * Ctot + coff + 4 * c4;
+        const float4 a = *reinterpret_cast<const float4*>(cA + ko);
+        const float4 bb = *reinterpret_cast<const float4*>(cB + ko);
+        const float4 cc = *reinterpret_cast<const float4*>(cC + ko);
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 o = make_float4(a.x * gv.x + bb.x * xv.x + cc.x, a.y * gv.y + bb.y * xv.y + cc.y,
+                               a.z * gv.z + bb.z * xv.z + cc.z, a.w * gv.w + bb.w * xv.w + cc.w);
+        if (r) { const float4 rv = reinterpret_cast<const float4*>(r)[i]; o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w; }
+        if (accum) { const float4 ov = reinterpret_cast<const float4*>(dx)[i]; o.x += ov.x; o.y += ov.y; o.z += ov.z; o.w += ov.w; }
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
+// out_bc[b*stride + c] += sum_t dy[b,t,c];  out_c[c] += sum_{b,t} dy   (both optional; atomics into zeroed buffers)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int T, int C, float* __restrict__ out_bc,
+                                                     int bc_stride, float* __restrict__ out_c, float scale_by_b,
+                                                     const float* __restrict__ bscale) {
+    extern __shared__ float red[];
+    const int nsl = (T + STAT_SLOT - 1) / STAT_SLOT;
+    const int slot = blockIdx.x % nsl, b = blockIdx.x / nsl;
+    const int c4n = C >> 2;
+    const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
+    const int c4 = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tr < nrow && threadIdx.x < nrow * c4n) {
+        for (int tl = tr; tl < STAT_SLOT; tl += nrow) {
+            const int t = slot * STAT_SLOT + tl;
+            if (t >= T) break;
+            const float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)b * T + t) * C + 4 * c4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(red + (tr * c4n + c4) * 4) = a;
+    }
+    __syncthreads();
+    const float sc = bscale ? bscale[b] : 1.0f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int r2 = 0; r2 < nrow; ++r2) s += red[(r2 * c4n + (c >> 2)) * 4 + (c & 3)];
+        s *= sc;
+        if (out_bc) atomicAdd(out_bc + (size_t)b * bc_stride + c, s);
+        if (out_c) atomicAdd(out_c + c, s);
+    }
+    (void)scale_by_b;
+}
+
+__global__ void zero_stuff_kernel(const float* __restrict__ dy, float* __restrict__ out, int T_out, int T_in, int C, size_t n4) {
+    const int c4n = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const size_t bu = i / c4n;
+        const int u = (int)(bu % T_in);
+        const size_t b = bu / T_in;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(u & 1) && (u >> 1) < T_out) v = reinterpret_cast<const float4*>(dy)[(b * T_out + (u >> 1)) * c4n + c4];
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+__global__ void pair_sum_kernel(const float* __restrict__ dup, float* __restrict__ dx, int T, int C, int accum, size_t n4) {
+    const int c4n = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const size_t bt = i / c4n;
+        const int t = (int)(bt % T);
+        const size_t b = bt / T;
+        const float4 a = reinterpret_cast<const float4*>(dup)[(b * 2 * T + 2 * t) * c4n + c4];
+        const float4 c = reinterpret_cast<const float4*>(dup)[(b * 2 * T + 2 * t + 1) * c4n + c4];
+        float4 o = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+        if (accum) { const float4 ov = reinterpret_cast<const float4*>(dx)[i]; o.x += ov.x; o.y += ov.y; o.z += ov.z; o.w += ov.w; }
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
+inline unsigned ew_grid4(size_t n4) {
+    size_t g = (n4 + 255) / 256;
+    return (unsigned)(g > 4096 ? 4096 : (g ? g : 1));
+}
+}  // namespace
+
+extern "C" int tq_gn_bwd_finalize(const float* gstats, const float* mean_rstd, const float* gamma, int B, int C, int T,
+                                  float* coef_a, float* coef_b, float* coef_c, float* dgamma, float* dbeta,
+                                  hipStream_t stream) {
+    if (!gstats || !mean_rstd || !gamma || !coef_a || !coef_b || !coef_c || !dgamma || !dbeta) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C <= 0 || C % GN_GROUPS) return TQ_ERR_SHAPE;
+    const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
+    const size_t sh = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(double);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), sh, stream, gstats, mean_rstd, gamma, C, T, nslots, coef_a,
+                       coef_b, coef_c, dgamma, dbeta);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_gn_bwd_apply(const float* g, const float* x, const float* r, const float* coef_a, const float* coef_b,
+                               const float* coef_c, float* dx, int B, int T, int C_src, int C_total, int c_offset, int accumulate,
+                               hipStream_t stream) {
+    if (!g || !x || !coef_a || !coef_b || !coef_c || !dx) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C_src <= 0 || C_src % 4 || c_offset % 4 || c_offset + C_src > C_total) return TQ_ERR_SHAPE;
+    const size_t n4 = (size_t)B * T * (C_src / 4);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid4(n4)), dim3(256), 0, stream, g, x, r, coef_a, coef_b, coef_c, dx, T,
+                       C_src, C_total, c_offset, accumulate, n4);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c,
+                         const float* bscale, hipStream_t stream) {
+    if (!dy || (!out_bc && !out_c)) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C < 4 || C % 4 || C > 1024) return TQ_ERR_SHAPE;
+    const int nsl = (T + STAT_SLOT - 1) / STAT_SLOT;
+    const int c4n = C / 4;
+    const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
+    const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float);
+    hipLaunchKernelGGL(colsum_kernel, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, 0.f, bscale);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_zero_stuff(const float* dy, float* out, int B, int T_out, int T_in, int C, hipStream_t stream) {
+    if (!dy || !out || B <= 0 || T_out <= 0 || T_in <= 0 || C % 4) return TQ_ERR_ARG;
+    const size_t n4 = (size_t)B * T_in * (C / 4);
+    hipLaunchKernelGGL(zero_stuff_kernel, dim3(ew_grid4(n4)), dim3(256), 0, stream, dy, out, T_out, T_in, C, n4);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_pair_sum(const float* d_up, float* dx, int B, int T, int C, int accumulate, hipStream_t stream) {
+    if (!d_up || !dx || B <= 0 || T <= 0 || C % 4) return TQ_ERR_ARG;
+    const size_t n4 = (size_t)B * T * (C / 4);
+    hipLaunchKernelGGL(pair_sum_kernel, dim3(ew_grid4(n4)), dim3(256), 0, stream, d_up, dx, T, C, accumulate, n4);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================
+// Stem weight gradient: dW[co,ci,k] += sum_{b,t} dy[b,t,co] * in_scale[b]*x[b,ci,t+k-pad];  db via tq_colsum.
+// One workgroup per (b, 128-position slot); thread per output element; fp32 atomics into the zeroed gradient.
+// =================================================================================================
+namespace {
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ in_scale, float* __restrict__ dw,
+                                                         int C_in, int T, int C_out, int KT, int nslots) {
+    extern __shared__ float shm[];
+    const int PAD = KT / 2;
+    const int TW = STAT_SLOT + KT - 1;
+    float* xs = shm;                 // [C_in][TW]
+    float* ds = xs + C_in * TW;      // [128][C_out + 1]
+    const int LD = C_out + 1;
+    const int slot = blockIdx.x % nslots, b = blockIdx.x / nslots;
+    const int t0 = slot * STAT_SLOT;
+    const float sc = in_scale ? in_scale[b] : 1.0f;
+    for (int i = threadIdx.x; i < C_in * TW; i += 256) {
+        const int c = i / TW, j = i % TW;
+        const int t = t0 - PAD + j;
+        xs[i] = (t >= 0 && t < T) ? x[((size_t)b * C_in + c) * T + t] * sc : 0.f;
+    }
+    for (int i = threadIdx.x; i < STAT_SLOT * C_out; i += 256) {
+        const int tl = i / C_out, c = i % C_out;
+        ds[tl * LD + c] = (t0 + tl < T) ? dy[((size_t)b * T + t0 + tl) * C_out + c] : 0.f;
+    }
+    __syncthreads();
+    const int nout = C_out * C_in * KT;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int co = o % C_out, r = o / C_out;
+        const int ci = r % C_in, k = r / C_in;
+        float a = 0.f;
+        for (int tl = 0; tl < STAT_SLOT; ++tl) a = fmaf(ds[tl * LD + co], xs[ci * TW + tl + k], a);
+        atomicAdd(dw + ((size_t)co * C_in + ci) * KT + k, a);
+    }
+}
+
+// Head backward.  dF = c_out[b]*dpred (B,Co,T).  Produces: G = (W^T * dF) * silu'(a*h+s) (B,T,Ci) with GN partial sums,
+// and accumulates dW, db (atomics into zeroed gradients).
+template <int KT>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ c_out,
+                                                       const float* __restrict__ h, const float* __restrict__ gscale,
+                                                       const float* __restrict__ gshift, const float* __restrict__ w,
+                                                       float* __restrict__ G, float* __restrict__ gstats,
+                                                       float* __restrict__ dw, float* __restrict__ db, int T, int C_in,
+                                                       int C_out, int nslots) {
+    extern __shared__ float shm[];
+    constexpr int PAD = KT / 2;
+    constexpr int TW = STAT_SLOT + KT - 1;
+    const int LDZ = TW + 1;
+    float* dfs = shm;                    // [C_out][TW]   dF with halo
+    float* zs = dfs + 4 * TW;            // [C_in][LDZ]   activated input with halo (transposed)
+    float* red = zs + C_in * LDZ;        // [nrow][C_in][2]
+    const int slot = blockIdx.x % nslots, b = blockIdx.x / nslots;
+    const int t0 = slot * STAT_SLOT;
+    const float co_s = c_out ? c_out[b] : 1.0f;
+    for (int i = threadIdx.x; i < C_out * TW; i += 256) {
+        const int c = i / TW, j = i % TW;
+        const int t = t0 - PAD + j;
+        dfs[c * TW + j] = (t >= 0 && t < T) ? dpred[((size_t)b * C_out + c) * T + t] * co_s : 0.f;
+    }
+    const int nc4 = C_in >> 2;
+    for (int i = threadIdx.x; i < TW * nc4; i += 256) {
+        const int c4 = i % nc4, j = i / nc4;
+        const int t = t0 - PAD + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) {
+            v = *reinterpret_cast<const float4*>(h + ((size_t)b * T + t) * C_in + 4 * c4);
+            if (gscale) {
+                const float4 a = *reinterpret_cast<const float4*>(gscale + (size_t)b * C_in + 4 * c4);
+                const float4 s = *reinterpret_cast<const float4*>(gshift + (size_t)b * C_in + 4 * c4);
+                v.x = silu_f(a.x * v.x + s.x); v.y = silu_f(a.y * v.y + s.y);
+                v.z = silu_f(a.z * v.z + s.z); v.w = silu_f(a.w * v.w + s.w);
+            }
+        }
+        zs[(4 * c4 + 0) * LDZ + j] = v.x; zs[(4 * c4 + 1) * LDZ + j] = v.y;
+        zs[(4 * c4 + 2) * LDZ + j] = v.z; zs[(4 * c4 + 3) * LDZ + j] = v.w;
+    }
+    __syncthreads();
+    // ---- weight / bias gradient: thread per (co, ci, k); the reduction runs over the slot's valid positions
+    const int nout = C_out * C_in * KT;
+    const int tvalid = min(STAT_SLOT, T - t0);
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int k = o % KT, r = o / KT;
+        const int ci = r % C_in, co = r / C_in;
+        float a = 0.f;
+        for (int tl = 0; tl < tvalid; ++tl) a = fmaf(dfs[co * TW + tl + PAD], zs[ci * LDZ + tl + k], a);
+        atomicAdd(dw + o, a);
+    }
+    if (threadIdx.x < C_out) {
+        float a = 0.f;
+        for (int tl = 0; tl < tvalid; ++tl) a += dfs[threadIdx.x * TW + tl + PAD];
+        atomicAdd(db + threadIdx.x, a);
+    }
+    // ---- data gradient: thread = (4 input channels, rows tr, tr+nrow, ...)
+    const int nrow = 256 / nc4;
+    const int c4 = threadIdx.x % nc4, tr = threadIdx.x / nc4;
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (tr < nrow) {
+        float4 ga = make_float4(1, 1, 1, 1), gs = make_float4(0, 0, 0, 0);
+        if (gscale) {
+            ga = *reinterpret_cast<const float4*>(gscale + (size_t)b * C_in + 4 * c4);
+            gs = *reinterpret_cast<const float4*>(gshift + (size_t)b * C_in + 4 * c4);
+        }
+        const float a4[4] = {ga.x, ga.y, ga.z, ga.w}, h4[4] = {gs.x, gs.y, gs.z, gs.w};
+        for (int tl = tr; tl < tvalid; tl += nrow) {
+            const size_t o = ((size_t)b * T + t0 + tl) * C_in + 4 * c4;
+            const float4 hv4 = *reinterpret_cast<const float4*>(h + o);
+            const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
+            float gq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ci = 4 * c4 + j;
+                float a = 0.f;
+                for (int co = 0; co < C_out; ++co)
+#pragma unroll
+                    for (int k = 0; k < KT; ++k)
+                        a = fmaf(w[((size_t)co * C_in + ci) * KT + k], dfs[co * TW + tl + 2 * PAD - k], a);  // dF[t + pad - k]
+                if (gscale) a *= dsilu_f(a4[j] * hv[j] + h4[j]);
+                gq[j] = a;
+                s1[j] += a; s2[j] += a * hv[j];
+            }
+            *reinterpret_cast<float4*>(G + o) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        }
+    }
+    if (gstats) {
+        __syncthreads();
+        if (tr < nrow) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { red[(tr * C_in + 4 * c4 + j) * 2] = s1[j]; red[(tr * C_in + 4 * c4 + j) * 2 + 1] = s2[j]; }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C_in; c += 256) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int r2 = 0; r2 < nrow; ++r2) { a1 += red[(r2 * C_in + c) * 2]; a2 += red[(r2 * C_in + c) * 2 + 1]; }
+            float* st = gstats + (((size_t)b * nslots + slot) * C_in + c) * 2;
+            st[0] = a1; st[1] = a2;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int tq_stem_conv_bwd_weight(const float* dy, const float* x_nct, const float* in_scale, float* dw, int B, int C_in,
+                                       int T, int C_out, int ktaps, hipStream_t stream) {
+    if (!dy || !x_nct || !dw) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C_in <= 0 || C_in > 16 || C_out <= 0 || (ktaps != 1 && ktaps != 3 && ktaps != 5)) return TQ_ERR_SHAPE;
+    const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
+    const size_t sh = ((size_t)C_in * (STAT_SLOT + ktaps - 1) + (size_t)STAT_SLOT * (C_out + 1)) * sizeof(float);
+    if (sh > 160 * 1024) return TQ_ERR_SHAPE;
+    auto kern = stem_wgrad_kernel;
+    if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(kern, dim3(B * nslots), dim3(256), sh, stream, dy, x_nct, in_scale, dw, C_in, T, C_out, ktaps, nslots);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_head_conv_bwd(const float* dpred_nct, const float* c_out, const float* x, const float* gscale,
+                                const float* gshift, const float* w, float* g_out, float* gstats, float* dw, float* db, int B,
+                                int T, int C_in, int C_out, int ktaps, hipStream_t stream) {
+    if (!dpred_nct || !x || !w || !g_out || !dw || !db) return TQ_ERR_ARG;
+    if ((gscale == nullptr) != (gshift == nullptr)) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || 256 % (C_in / 4) || C_out < 1 || C_out > 4) return TQ_ERR_SHAPE;
+    const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
+    const int nrow = 256 / (C_in / 4);
+    const size_t sh = ((size_t)4 * (STAT_SLOT + ktaps - 1) + (size_t)C_in * (STAT_SLOT + ktaps) + (size_t)nrow * C_in * 2) * sizeof(float);
+    if (sh > 160 * 1024) return TQ_ERR_SHAPE;
+#define TQ_HB(K)                                                                                             \
+    {                                                                                                        \
+        auto kern = head_bwd_kernel<K>;                                                                      \
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL(kern, dim3(B * nslots), dim3(256), sh, stream, dpred_nct, c_out, x, gscale, gshift, w, g_out, gstats, dw, db, T, C_in, C_out, nslots); \
+    }
+    if (ktaps == 5) TQ_HB(5)
+    else if (ktaps == 3) TQ_HB(3)
+    else if (ktaps == 1) TQ_HB(1)
+    else return TQ_ERR_SHAPE;
+#undef TQ_HB
+    TQ_CHECK_LAUNCH();
+    return 0;
+}

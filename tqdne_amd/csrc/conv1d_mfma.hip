@@ -46,6 +46,14 @@ struct ConvArgs {
     uint32_t drop_thresh;  // keep if hash >= thresh
     float drop_scale;      // 1/(1-p)
     uint64_t drop_seed;
+    // data-gradient epilogue (EPI == 1): forward inputs / folded GN of the forward conv, split destination
+    const float* fx0;
+    const float* fx1;
+    const float* fgs;
+    const float* fgh;
+    float* y1;
+    int OC0;     // output channels [0, OC0) -> y (row stride OC0), [OC0, C_out) -> y1 (row stride C_out - OC0)
+    int bflags;  // TQ_BWD_*
 };
 
 template <int KT, int STRIDE, int UPS, int WM, int WN>
@@ -63,7 +71,7 @@ struct Cfg {
     static constexpr int PAD = (STRIDE == 1) ? (KT / 2) : 1;
 };
 
-template <int KT, int STRIDE, int UPS, int WM, int WN>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -270,6 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     // ---- epilogue
     if (!wave_active) return;
+    if constexpr (EPI == 0) {
     const int slot = (t0 >> 7) + wn;
     const float* emb_b = (p.flags & TQ_CONV_EMB) ? p.emb + (size_t)b * p.emb_stride : nullptr;
 #pragma unroll
@@ -307,19 +316,85 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                     s2[j] += __shfl_xor(s2[j], o);
                 }
             }
-            if ((lane & 15) == 0) {
+            if ((lane & 15) == 0 && slot < p.nslots) {
                 float* st = p.stats + (((size_t)b * p.nslots + slot) * p.C_out + co) * 2;
                 *reinterpret_cast<float4*>(st) = make_float4(s1[0], s2[0], s1[1], s2[1]);
                 *reinterpret_cast<float4*>(st + 4) = make_float4(s1[2], s2[2], s1[3], s2[3]);
             }
         }
     }
+    } else {
+        // data gradient: acc = d loss / d xhat.  Chain through dropout, SiLU and the folded GroupNorm scale of the
+        // FORWARD conv's prologue:  g = acc * mask/(1-p) * silu'(u), u = a*x + s  (the GN statistics' own dependence
+        // on x is handled by tq_gn_bwd_finalize / tq_gn_bwd_apply from the partial sums (sum g, sum g*x) emitted here)
+        const int slot = (t0 >> 7) + wn;
+        const int Ctot = p.C_out;
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+            const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+            float* dst; const float* fx; int cs, cc;
+            if (co < p.OC0) { dst = p.y; fx = p.fx0; cs = p.OC0; cc = co; }
+            else            { dst = p.y1; fx = p.fx1; cs = Ctot - p.OC0; cc = co - p.OC0; }
+            float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), gs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bflags & TQ_BWD_GN) {
+                ga = *reinterpret_cast<const float4*>(p.fgs + (size_t)b * Ctot + co);
+                gs = *reinterpret_cast<const float4*>(p.fgh + (size_t)b * Ctot + co);
+            }
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tb = 0; tb < 8; ++tb) {
+                const int t = t0 + wn * 128 + tb * 16 + (lane & 15);
+                if (t < p.T_out) {
+                    const size_t o = ((size_t)b * p.T_out + t) * cs + cc;
+                    float v[4] = {acc[cbk][tb][0], acc[cbk][tb][1], acc[cbk][tb][2], acc[cbk][tb][3]};
+                    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bflags & (TQ_BWD_GN | TQ_BWD_SILU | TQ_BWD_STATS)) {
+                        const float4 x4 = *reinterpret_cast<const float4*>(fx + o);
+                        xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                    }
+                    if (p.bflags & TQ_BWD_SILU) {
+                        const float a4[4] = {ga.x, ga.y, ga.z, ga.w}, h4[4] = {gs.x, gs.y, gs.z, gs.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= dsilu_f(a4[j] * xv[j] + h4[j]);
+                    }
+                    if (p.bflags & TQ_BWD_DROPOUT) {
+                        const uint64_t e0 = ((uint64_t)b * p.T_out + t) * Ctot + co;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+                    }
+                    if (p.bflags & TQ_BWD_ACCUM) {
+                        const float4 r = *reinterpret_cast<const float4*>(dst + o);
+                        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                    }
+                    *reinterpret_cast<float4*>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * xv[j]; }
+                }
+            }
+            if (p.bflags & TQ_BWD_STATS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        s1[j] += __shfl_xor(s1[j], o);
+                        s2[j] += __shfl_xor(s2[j], o);
+                    }
+                }
+                if ((lane & 15) == 0 && slot < p.nslots) {
+                    float* st = p.stats + (((size_t)b * p.nslots + slot) * Ctot + co) * 2;
+                    *reinterpret_cast<float4*>(st) = make_float4(s1[0], s2[0], s1[1], s2[1]);
+                    *reinterpret_cast<float4*>(st + 4) = make_float4(s1[2], s2[2], s1[3], s2[3]);
+                }
+            }
+        }
+    }
 }
 
-template <int KT, int STRIDE, int UPS, int WM, int WN>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI>
 int launch(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN>;
-    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -335,15 +410,15 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <int KT, int STRIDE, int UPS>
+template <int KT, int STRIDE, int UPS, int EPI = 0>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
-    if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1>(a, s);
+    if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI>(a, s);
     if constexpr (STRIDE == 1) {
-        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2>(a, s);
-        return launch<KT, STRIDE, UPS, 1, 2>(a, s);
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 2, EPI>(a, s);
     } else {
-        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1>(a, s);
-        return launch<KT, STRIDE, UPS, 1, 1>(a, s);
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1, EPI>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 1, EPI>(a, s);
     }
 }
 
@@ -391,6 +466,7 @@ extern "C" int tq_conv1d_fwd(const TqConvDesc* d, const float* x0, const float* 
     if (pdrop >= 1.f) return TQ_ERR_ARG;
     a.drop_thresh = (uint32_t)((double)pdrop * 4294967296.0);
     a.drop_scale = 1.0f / (1.0f - pdrop);
+    a.fx0 = a.fx1 = a.fgs = a.fgh = nullptr; a.y1 = nullptr; a.OC0 = d->C_out; a.bflags = 0;
 
     if (d->stride == 2) return dispatch_tile<3, 2, 0>(a, stream);
     if (d->upsample) {
@@ -403,6 +479,44 @@ extern "C" int tq_conv1d_fwd(const TqConvDesc* d, const float* x0, const float* 
         case 3: return dispatch_tile<3, 1, 0>(a, stream);
         case 5: return dispatch_tile<5, 1, 0>(a, stream);
         default: return TQ_ERR_SHAPE;
+    }
+}
+
+// Data gradient of a stride-1 "same" convolution (the transposed, tap-flipped weights are packed with mode 1):
+//   acc[b,t,ci] = sum_{k,co} W[co,ci,K-1-k] * dy[b, t + k - pad, co]
+// followed by the chain rule through the forward conv's prologue (see the EPI == 1 epilogue above).
+extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const void* wpk_t, const float* x0,
+                                  const float* x1, const float* gscale, const float* gshift, float* dx0, float* dx1,
+                                  float* gstats, hipStream_t stream) {
+    if (!d || !dy || !wpk_t || !dx0) return TQ_ERR_ARG;
+    if (d->C_dy <= 0 || d->C_dy % 32 || d->C_dx0 <= 0 || d->C_dx0 % 32 || d->C_dx1 < 0 || d->C_dx1 % 32) return TQ_ERR_SHAPE;
+    if (d->C_dx1 > 0 && !dx1) return TQ_ERR_ARG;
+    const int need_x = d->flags & (TQ_BWD_GN | TQ_BWD_SILU | TQ_BWD_STATS);
+    if (need_x && (!x0 || (d->C_dx1 > 0 && !x1))) return TQ_ERR_ARG;
+    if ((d->flags & TQ_BWD_GN) && (!gscale || !gshift)) return TQ_ERR_ARG;
+    if ((d->flags & TQ_BWD_STATS) && !gstats) return TQ_ERR_ARG;
+    if (d->B <= 0 || d->T <= 0 || (d->ktaps != 1 && d->ktaps != 3 && d->ktaps != 5)) return TQ_ERR_SHAPE;
+    ConvArgs a;
+    a.x0 = dy; a.x1 = nullptr; a.gscale = nullptr; a.gshift = nullptr;
+    a.wpk = reinterpret_cast<const uint4*>(wpk_t);
+    a.bias = nullptr; a.emb = nullptr; a.res = nullptr; a.y = dx0; a.stats = gstats;
+    a.B = d->B; a.T_in = d->T; a.T_out = d->T; a.C0 = d->C_dy; a.C1 = 0; a.C_out = d->C_dx0 + d->C_dx1;
+    a.emb_stride = 0; a.flags = 0;
+    const int tile = tq_conv_tile_co(a.C_out);
+    a.ncob_pad = ((a.C_out + tile - 1) / tile) * tile / 16;
+    a.nslots = (d->T + STAT_SLOT - 1) / STAT_SLOT;
+    a.drop_site = d->dropout_site; a.drop_seed = d->dropout_seed;
+    float pdrop = d->dropout_p;
+    a.bflags = d->flags;
+    if (!(d->flags & TQ_BWD_DROPOUT) || pdrop <= 0.f) { a.bflags &= ~TQ_BWD_DROPOUT; pdrop = 0.f; }
+    if (pdrop >= 1.f) return TQ_ERR_ARG;
+    a.drop_thresh = (uint32_t)((double)pdrop * 4294967296.0);
+    a.drop_scale = 1.0f / (1.0f - pdrop);
+    a.fx0 = x0; a.fx1 = x1; a.fgs = gscale; a.fgh = gshift; a.y1 = dx1; a.OC0 = d->C_dx0;
+    switch (d->ktaps) {
+        case 1: return dispatch_tile<1, 1, 0, 1>(a, stream);
+        case 3: return dispatch_tile<3, 1, 0, 1>(a, stream);
+        default: return dispatch_tile<5, 1, 0, 1>(a, stream);
     }
 }
 

@@ -213,7 +213,7 @@ class LightningEDM(LightningModule):
         return bufs
 
     @th.no_grad()
-    def sample_deterministically(self, eps, sigmas, cond_sample=None, cond=None):
+    def sample_deterministically(self, eps, sigmas, cond_sample=None, cond=None, use_graph=False):
         """Deterministic Heun sampler (edm.py:171-196): ``eps`` is the fp64 start state (already scaled by sigmas[0]),
         ``sigmas`` the fp32 schedule ending in 0.  NFE = 2*len(sigmas) - 3 when the last sigma is the appended 0."""
         if cond_sample is not None:

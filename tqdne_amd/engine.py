@@ -66,6 +66,23 @@ class ConvSite:
         self.version = -1
 
 
+class Probe:
+    """HIP-event timings of one op of the plan (events are recorded on the stream the kernel is launched on)."""
+
+    def __init__(self, idx, name, flops):
+        self.idx, self.name, self.flops, self.events = idx, name, flops, []
+
+    def reset(self):
+        self.events = []
+
+    def result(self):
+        if not self.events:
+            return None, self.flops, self.name, 0
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        return sum(ms) / len(ms), self.flops, self.name, len(ms)
+
+
 class UNetEngine:
     def __init__(self, model, B: int, T: int, device: torch.device):
         self.lib = _lib.load()
@@ -77,6 +94,7 @@ class UNetEngine:
         self.conv_sites: List[ConvSite] = []
         self.dropout_descs: List[TqConvDesc] = []
         self.acts: List[Act] = []
+        self._probe = None
         self._build()
         self._w_version = None
 
@@ -105,7 +123,7 @@ class UNetEngine:
         s1 = srcs[1] if len(srcs) > 1 else None
         self.ops.append((self.lib.tq_gn_finalize, (
             _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
-            _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize"))
+            _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize", 0))
         return gscale, gshift, mean_rstd
 
     def _conv(self, srcs: Sequence[Act], site: ConvSite, *, gn=None, silu=False, emb_ptr=None, res: Optional[Act] = None,
@@ -148,7 +166,7 @@ class UNetEngine:
         self.ops.append((self.lib.tq_conv1d_fwd, (
             C.byref(d), _p(s0.buf), _p(s1.buf) if s1 else None, _p(gn[0]) if gn else None, _p(gn[1]) if gn else None,
             _p(site.packed), _p(site.bias), emb_ptr, _p(res.buf) if res else None, _p(out.buf), _p(out.stats)),
-            "conv:" + site.name))
+            "conv:" + site.name, 2 * site.C_in * site.C_out * site.K * T_out * self.B))
         return out
 
     # ------------------------------------------------------------------ graph construction
@@ -230,10 +248,18 @@ class UNetEngine:
         qkv = self._conv([x], self._site(name + ".qkv", ab.qkv), gn=g, silu=False, stats=False)
         att = self._act(ab.channels, x.T, False)
         D = ab.channels // ab.num_heads
-        if D not in (32, 64):
-            raise NotImplementedError(f"attention head dim {D} (kernels exist for 32 and 64)")
-        self.ops.append((self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), self.B, x.T, ab.num_heads, D), "attention"))
+        if D not in (32, 64, 128):
+            raise NotImplementedError(f"attention head dim {D} (kernels exist for 32, 64 and 128)")
+        self.ops.append((self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), self.B, x.T, ab.num_heads, D), "attention",
+                         4 * ab.channels * x.T * x.T * self.B))
         return self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
+
+    # ------------------------------------------------------------------ measurement
+    def install_probe(self, name_prefix: str = "conv:"):
+        """Bracket the heaviest launch (by algorithmic FLOP) with HIP events on the launch stream, every eager forward."""
+        idx = max((i for i, op in enumerate(self.ops) if op[2].startswith(name_prefix)), key=lambda i: self.ops[i][3])
+        self._probe = Probe(idx, self.ops[idx][2], self.ops[idx][3])
+        return self._probe
 
     # ------------------------------------------------------------------ weights
     def _weights_version(self):
@@ -298,10 +324,24 @@ class UNetEngine:
         check(lib.tq_stem_conv_fwd(_p(x), _p(in_scale), _p(stem.weight), _p(stem.bias), _p(self.stem_out.buf),
                                    _p(self.stem_out.stats), B, m.in_channels, T, stem.out_channels, stem.kernel_size[0],
                                    stream), "stem conv")
-        for fn, args, what in self.ops:
-            rc = fn(*args, stream)
-            if rc:
-                check(rc, what)
+        probe = self._probe
+        if probe is None or torch.cuda.is_current_stream_capturing():
+            for fn, args, what, _ in self.ops:
+                rc = fn(*args, stream)
+                if rc:
+                    check(rc, what)
+        else:
+            for i, (fn, args, what, _) in enumerate(self.ops):
+                if i == probe.idx:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = fn(*args, stream)
+                    e1.record()
+                    probe.events.append((e0, e1))
+                else:
+                    rc = fn(*args, stream)
+                if rc:
+                    check(rc, what)
         head = m.out[2]
         check(lib.tq_head_conv_fwd(_p(self.final.buf), _p(self.head_gn[0]), _p(self.head_gn[1]), _p(head.weight),
                                    _p(head.bias), _p(c_out), _p(c_skip), _p(skip_src), _p(self.out_nct), B, T,

@@ -117,3 +117,135 @@ def linear(x, w, b=None):
     out = torch.empty(B, N, device=x.device)
     check(lib.tq_linear_fwd(_p(x), _p(w.contiguous()), _p(b), _p(out), B, E, N, _stream(x.device)), "linear")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- backward wrappers
+from ._lib import TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_STATS, TqConvBwdDesc
+
+
+def conv1d_bwd_data(dy, weight, *, x0=None, x1=None, gscale=None, gshift=None, silu=False, stats=False, split=None,
+                    accumulate_into=None, dropout_p=0.0, dropout_seed=0, dropout_site=0):
+    """dy (B,T,C_out); weight (C_out, C_in, K) torch layout.  Returns (g0, g1|None, gstats|None)."""
+    lib = _lib.load()
+    B, T, C_dy = dy.shape
+    C_out, C_in, K = weight.shape
+    assert C_dy == C_out
+    C0 = C_in if split is None else split
+    C1 = C_in - C0
+    if accumulate_into is not None:
+        g0, g1 = accumulate_into
+    else:
+        g0 = torch.empty(B, T, C0, device=dy.device)
+        g1 = torch.empty(B, T, C1, device=dy.device) if C1 else None
+    st = torch.empty(B, nslots(T), C_in, 2, device=dy.device) if stats else None
+    d = TqConvBwdDesc()
+    d.B, d.T, d.C_dy, d.C_dx0, d.C_dx1, d.ktaps = B, T, C_dy, C0, C1, K
+    f = 0
+    if gscale is not None:
+        f |= TQ_BWD_GN
+    if silu:
+        f |= TQ_BWD_SILU
+    if stats:
+        f |= TQ_BWD_STATS
+    if accumulate_into is not None:
+        f |= TQ_BWD_ACCUM
+    if dropout_p > 0:
+        f |= TQ_BWD_DROPOUT
+    d.flags = f
+    d.dropout_site, d.dropout_p, d.dropout_seed = dropout_site, dropout_p, dropout_seed
+    wp = pack_conv_weight(weight, 1)
+    check(lib.tq_conv1d_bwd_data(C.byref(d), _p(dy), _p(wp), _p(x0), _p(x1), _p(gscale), _p(gshift), _p(g0), _p(g1), _p(st),
+                                 _stream(dy.device)), "conv1d_bwd_data")
+    return g0, g1, st
+
+
+def conv1d_bwd_weight(dy, x0, wshape, *, x1=None, gscale=None, gshift=None, silu=False, stride=1, upsample=False,
+                      dropout_p=0.0, dropout_seed=0, dropout_site=0):
+    lib = _lib.load()
+    B, T_in, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[2]
+    C_out, C_in, K = wshape
+    T_out = dy.shape[1]
+    d = TqConvDesc()
+    d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T_in, T_out, C0, C1, C_out
+    d.ktaps, d.stride, d.pad, d.upsample = K, stride, K // 2, int(upsample)
+    f = 0
+    if gscale is not None:
+        f |= TQ_CONV_GN
+    if silu:
+        f |= TQ_CONV_SILU
+    if dropout_p > 0:
+        f |= TQ_CONV_DROPOUT
+    d.flags = f
+    d.dropout_site, d.dropout_p, d.dropout_seed = dropout_site, dropout_p, dropout_seed
+    ws = torch.empty(lib.tq_conv1d_bwd_weight_workspace(C.byref(d)), dtype=torch.uint8, device=dy.device)
+    dw = torch.empty(C_out, C_in, K, device=dy.device)
+    check(lib.tq_conv1d_bwd_weight(C.byref(d), _p(dy), _p(x0), _p(x1), _p(gscale), _p(gshift), _p(dw), _p(ws), ws.numel(),
+                                   _stream(dy.device)), "conv1d_bwd_weight")
+    return dw
+
+
+def gn_bwd_finalize(gstats, mean_rstd, gamma, T):
+    lib = _lib.load()
+    B, _, Cn, _ = gstats.shape
+    dev = gamma.device
+    a, b, c = (torch.empty(B, Cn, device=dev) for _ in range(3))
+    dg, db = torch.zeros(Cn, device=dev), torch.zeros(Cn, device=dev)
+    check(lib.tq_gn_bwd_finalize(_p(gstats), _p(mean_rstd), _p(gamma), B, Cn, T, _p(a), _p(b), _p(c), _p(dg), _p(db),
+                                 _stream(dev)), "gn_bwd_finalize")
+    return a, b, c, dg, db
+
+
+def gn_bwd_apply(g, x, coefs, c_total, c_offset=0, r=None, accumulate_into=None):
+    lib = _lib.load()
+    B, T, Cs = g.shape
+    dx = accumulate_into if accumulate_into is not None else torch.empty_like(g)
+    check(lib.tq_gn_bwd_apply(_p(g), _p(x), _p(r), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]), _p(dx), B, T, Cs, c_total, c_offset,
+                              int(accumulate_into is not None), _stream(g.device)), "gn_bwd_apply")
+    return dx
+
+
+def colsum(dy, per_sample=True, total=True, bscale=None):
+    lib = _lib.load()
+    B, T, Cn = dy.shape
+    obc = torch.zeros(B, Cn, device=dy.device) if per_sample else None
+    oc = torch.zeros(Cn, device=dy.device) if total else None
+    check(lib.tq_colsum(_p(dy), B, T, Cn, _p(obc), Cn, _p(oc), _p(bscale), _stream(dy.device)), "colsum")
+    return obc, oc
+
+
+def zero_stuff(dy, T_in):
+    lib = _lib.load()
+    B, T_out, Cn = dy.shape
+    out = torch.empty(B, T_in, Cn, device=dy.device)
+    check(lib.tq_zero_stuff(_p(dy), _p(out), B, T_out, T_in, Cn, _stream(dy.device)), "zero_stuff")
+    return out
+
+
+def pair_sum(d_up, accumulate_into=None):
+    lib = _lib.load()
+    B, T2, Cn = d_up.shape
+    dx = accumulate_into if accumulate_into is not None else torch.empty(B, T2 // 2, Cn, device=d_up.device)
+    check(lib.tq_pair_sum(_p(d_up), _p(dx), B, T2 // 2, Cn, int(accumulate_into is not None), _stream(d_up.device)), "pair_sum")
+    return dx
+
+
+def stem_conv_bwd_weight(dy, x_nct, wshape, in_scale=None):
+    lib = _lib.load()
+    B, Cin, T = x_nct.shape
+    Cout, _, K = wshape
+    dw = torch.zeros(Cout, Cin, K, device=dy.device)
+    check(lib.tq_stem_conv_bwd_weight(_p(dy), _p(x_nct), _p(in_scale), _p(dw), B, Cin, T, Cout, K, _stream(dy.device)), "stem wgrad")
+    return dw
+
+
+def head_conv_bwd(dpred_nct, x, weight, gscale=None, gshift=None, c_out=None, stats=True):
+    lib = _lib.load()
+    B, T, Cin = x.shape
+    Cout, _, K = weight.shape
+    g = torch.empty_like(x)
+    st = torch.empty(B, nslots(T), Cin, 2, device=x.device) if stats else None
+    dw, db = torch.zeros_like(weight), torch.zeros(Cout, device=x.device)
+    check(lib.tq_head_conv_bwd(_p(dpred_nct), _p(c_out), _p(x), _p(gscale), _p(gshift), _p(weight.contiguous()), _p(g), _p(st),
+                               _p(dw), _p(db), B, T, Cin, Cout, K, _stream(x.device)), "head bwd")
+    return g, st, dw, db
