@@ -88,35 +88,72 @@ def conv_flops_per_sample(unet, T):
     return total
 
 
-def cpu_baseline(cfg, sd, B, T, nsample_steps, seed):
-    """Time the CPU oracle (oracle/ = our PyTorch-CPU restatement, "port") on a bounded sample of the same workload:
-    one full train step (fwd + bwd + Adam) and one 18-step sample at batch B on the host cores."""
+def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads):
+    """Runs in a child process: time the CPU oracle (oracle/ = our PyTorch-CPU restatement, a "port") on a bounded
+    sample of the same workload: one full train step (fwd + bwd + Adam) and one 18-step sample at batch B."""
+    import torch
     from oracle import edm as OE
+    from tqdne_amd import UNetModel, paper_1d_unet_config, tiny_1d_unet_config
 
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    torch.set_num_threads(nthreads)
+    cfg = paper_1d_unet_config() if cfg_name == "paper" else tiny_1d_unet_config()
+    torch.manual_seed(0)
+    sd = perturbed_state(UNetModel(**cfg), 17)
     g = torch.Generator().manual_seed(seed)
     sig = 0.5 * torch.randn(B, 3, T, generator=g)
     cond = torch.randn(B, 5, generator=g) if cfg.get("cond_features") else None
     params = {("unet." + k): v.clone().requires_grad_(v.is_floating_point() and k != "time_embed.W") for k, v in sd.items()}
     opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=1e-4)
     p = OE.EDMParams()
-    masks = None  # dropout masks cost nothing measurable on the CPU; eval-mode arithmetic is identical otherwise
+    net = OE.make_net(params, cfg)
     t0 = time.perf_counter()
     opt.zero_grad()
-    net = OE.make_net(params, cfg, dropout_masks=masks)
     loss = OE.loss_step(p, net, sig, torch.randn(B, generator=g), torch.randn(B, 3, T, generator=g), cond=cond)
     loss.backward()
     opt.step()
     t_train = time.perf_counter() - t0
+    print(json.dumps(dict(stage="train", t_train=t_train)), flush=True)
     t0 = time.perf_counter()
     with torch.no_grad():
         OE.sample_deterministic(p, net, torch.randn(B, 3, T, generator=g, dtype=torch.float64), nsample_steps, cond=cond)
     t_sample = time.perf_counter() - t0
-    return dict(value=B / (t_train + t_sample), unit="waveforms/s", cores=ncores, kind="port",
-                sample=f"paper UNet, B={B}, 3x{T}: 1 train step ({t_train:.2f} s) + 1 x {nsample_steps}-step sample "
-                       f"({t_sample:.2f} s), torch {torch.__version__} CPU, {ncores} threads",
-                train_s=t_train, sample_s=t_sample)
+    print(json.dumps(dict(stage="done", t_train=t_train, t_sample=t_sample)), flush=True)
+
+
+def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=240):
+    """Launch the worker with a hard timeout (a slow or oversubscribed host must not stall the bench)."""
+    import subprocess
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        ncores = os.cpu_count() or 1
+    nthreads = max(1, min(ncores, 64))
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
+            f"bench._cpu_baseline_worker({cfg_name!r}, {B}, {T}, {nsample_steps}, {seed}, {nthreads})")
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(nthreads))
+    t_train = t_sample = None
+    try:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=timeout_s, env=env, cwd=ROOT)
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    for l in lines:
+        t_train = l.get("t_train", t_train)
+        t_sample = l.get("t_sample", t_sample)
+    res = dict(value=None, unit="waveforms/s", cores=nthreads, kind="port", train_s=t_train, sample_s=t_sample,
+               sample=f"{cfg_name} UNet, B={B}, 3x{T}: 1 train step + 1 x {nsample_steps}-step sample, torch {torch.__version__} CPU, "
+                      f"{nthreads} threads ({ncores} cores visible)")
+    if t_train is not None and t_sample is not None:
+        res["value"] = B / (t_train + t_sample)
+    else:
+        res["sample"] += f" -- did not finish within {timeout_s} s"
+    return res
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
 
 
 def main():
@@ -196,9 +233,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    log("model on device, plan built; warmup ...")
     for _ in range(args.warmup):
         one_step()
     sync()
+    log("warmup done; timing", args.steps, "steps")
     probe.reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -210,6 +249,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = 1e3 * dt / args.steps
+    log(f"timed region done: {ms_per_step:.1f} ms/step")
     value = world * B / (dt / args.steps)
 
     # separate timings of the two halves (reported, not the headline)
@@ -257,8 +297,8 @@ def main():
         if args.no_train or args.no_sample:
             out["metric"] += " [DEBUG: partial workload, not the headline metric]"
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, {k: v.cpu() for k, v in edm.unet.state_dict().items()}, args.cpu_batch, T,
-                                               args.sample_steps, 99)
+            log("timing the CPU oracle (bounded sample, subprocess) ...")
+            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, T, args.sample_steps, 99)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -231,3 +231,25 @@ def test_dropout_forward_backward_consistency():
     assert rel_err(ncw(g0), xm.grad * mask) < TOL
     dw = ops.conv1d_bwd_weight(cl(dy), cl(x), w.shape, gscale=ones, gshift=zeros, **kw)
     assert rel_err(dw.cpu(), wr.grad) < TOL
+
+
+@pytest.mark.parametrize("H,D,T", [(4, 64, 512), (2, 32, 62), (1, 128, 200), (2, 64, 127)])
+def test_attention_backward(H, D, T):
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(H * D + T)
+    B = 2
+    qkv = (torch.randn(B, 3 * H * D, T, generator=g) * 1.2).requires_grad_(True)
+    dout = torch.randn(B, H * D, T, generator=g)
+    q, k, v = qkv.chunk(3, dim=1)
+    sc = 1 / math.sqrt(math.sqrt(D))
+    w = torch.einsum("bct,bcs->bts", (q * sc).reshape(B * H, D, T), (k * sc).reshape(B * H, D, T))
+    w = torch.softmax(w.float(), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", w, v.reshape(B * H, D, T)).reshape(B, -1, T)
+    ref.backward(dout)
+    x = cl(qkv.detach())
+    out, lse = ops.attention(x, H, return_lse=True)
+    assert rel_err(ncw(out), ref) < TOL
+    dqkv = ops.attention_bwd(x, out, cl(dout), lse, H)
+    got = ncw(dqkv)
+    for name, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, 2 * H * D)), ("dv", slice(2 * H * D, 3 * H * D))):
+        assert rel_err(got[:, sl], qkv.grad[:, sl]) < TOL, name

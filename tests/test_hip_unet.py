@@ -137,3 +137,62 @@ def test_consistency_vs_golden():
     e1, e2 = rel_err(y1.cpu(), d["one_step"]), rel_err(y2.cpu(), d["refined"])
     print(f"consistency 1-step {e1:.2e}, refined {e2:.2e}")
     assert e1 < TOL and e2 < TOL
+
+
+def test_edm_step_gradients_vs_golden():
+    """loss.backward() through the hand-written HIP backward vs the reference's autograd gradients (golden)."""
+    edm, d = _edm_pair()
+    edm.train()  # dropout is 0.0 in the micro config, so train mode is deterministic
+    loss = edm.step_with_noise(torch.from_numpy(d["signal"]).to(dev()), torch.from_numpy(d["step:eps"]).to(dev()),
+                               torch.from_numpy(d["step:noise"]).to(dev()), cond=torch.from_numpy(d["cond"]).to(dev()))
+    assert rel_err(loss.detach().cpu(), d["step:loss"]) < TOL
+    loss.backward()
+    worst = 0.0
+    n = 0
+    for k in d:
+        if k.startswith("step:grad:"):
+            name = k[len("step:grad:"):]
+            g = edm.get_parameter(name).grad
+            assert g is not None, name
+            e = rel_err(g.cpu(), d[k])
+            print(f"grad {name}: {e:.2e}")
+            worst = max(worst, e)
+            n += 1
+    assert n >= 15 and worst < TOL
+
+
+@pytest.mark.parametrize("which", ["tiny", "paper"])
+def test_full_size_gradients_vs_oracle(which):
+    """every parameter gradient of the EDM loss at 3 x 4096 (B=2) vs torch autograd through the CPU oracle"""
+    from oracle import edm as OE
+    from tqdne_amd import LightningEDM, paper_1d_unet_config, tiny_1d_unet_config
+    cfg = dict(paper_1d_unet_config() if which == "paper" else tiny_1d_unet_config(), dropout=0.0)
+    torch.manual_seed(0)
+    edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
+    sd = perturbed_state(edm.unet, 23)
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev()).train()
+    g = torch.Generator().manual_seed(77)
+    B, T = 2, 4096
+    sig = 0.5 * torch.randn(B, 3, T, generator=g)
+    cond = torch.randn(B, 5, generator=g) if cfg["cond_features"] else None
+    eps, noise = torch.randn(B, generator=g), torch.randn(B, 3, T, generator=g)
+    loss = edm.step_with_noise(sig.to(dev()), eps.to(dev()), noise.to(dev()), cond=cond.to(dev()) if cond is not None else None)
+    loss.backward()
+    params = {("unet." + k): v.clone().requires_grad_(k != "time_embed.W") for k, v in sd.items()}
+    lo = OE.loss_step(OE.EDMParams(), OE.make_net(params, cfg), sig, eps, noise, cond=cond)
+    lo.backward()
+    assert rel_err(loss.detach().cpu(), lo.detach()) < TOL
+    worst, wname = 0.0, ""
+    # gradients that are exactly zero in exact arithmetic (a bias feeding a GroupNorm whose groups have one channel,
+    # C=32) are pure rounding noise on both sides: errors are measured against max(|ref|, 1e-3 * largest gradient)
+    gmax = max(float(v.grad.abs().max()) for v in params.values() if v.grad is not None)
+    for name, p in edm.unet.named_parameters():
+        ref = params["unet." + name].grad
+        if not p.requires_grad:
+            continue
+        e = float((p.grad.cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-3 * gmax))
+        if e > worst:
+            worst, wname = e, name
+    print(f"{which}: loss {float(loss):.6f}; worst gradient rel err {worst:.2e} at {wname}")
+    assert worst < TOL

@@ -19,8 +19,8 @@ constexpr int QT = 64;   // queries per workgroup
 constexpr int KTILE = 64;  // keys per tile
 
 template <int D>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T,
-                                                           int H, float scale) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           float* __restrict__ lse, int T, int H, float scale) {
     constexpr int KS = D / 32;       // k-steps over the head dimension
     constexpr int CB = D / 16;       // output column blocks
     constexpr int KROW = D * 2 + 16;   // bytes per key row of the K image (padded)
@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         const int q = q0 + 4 * (lane >> 4) + r;
         if (q < T) {
             const float inv = 1.0f / l_run[r];
+            if (lse && (lane & 15) == 0) lse[((size_t)b * H + h) * T + q] = m_run[r] + __logf(l_run[r]);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
                 out[((size_t)b * T + q) * (H * D) + h * D + cb * 16 + (lane & 15)] = o[cb][r] * inv;
@@ -204,24 +205,374 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 }
 
 template <int D>
-int launch_attn(const float* qkv, float* out, int B, int T, int H, hipStream_t stream) {
+int launch_attn(const float* qkv, float* out, float* lse, int B, int T, int H, hipStream_t stream) {
     constexpr int KROW = D * 2 + 16, VROW = KTILE * 2 + 16, PROW = KTILE * 2 + 16;
     const size_t sh = 2 * KTILE * KROW + 2 * D * VROW + 4 * 2 * 16 * PROW;
     if (sh > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int nqt = (T + QT - 1) / QT;
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));  // blocks.py:173 (python double, then fp32)
-    hipLaunchKernelGGL(attention_kernel<D>, dim3(B * H * nqt), dim3(256), sh, stream, qkv, out, T, H, scale);
+    hipLaunchKernelGGL(attention_kernel<D>, dim3(B * H * nqt), dim3(256), sh, stream, qkv, out, lse, T, H, scale);
     TQ_CHECK_LAUNCH();
     return 0;
 }
 }  // namespace
 
-extern "C" int tq_attention_fwd(const float* qkv, float* out, int B, int T, int H, int D, hipStream_t stream) {
+extern "C" int tq_attention_fwd(const float* qkv, float* out, float* lse, int B, int T, int H, int D, hipStream_t stream) {
     if (!qkv || !out) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || H <= 0) return TQ_ERR_SHAPE;
-    if (D == 64) return launch_attn<64>(qkv, out, B, T, H, stream);
-    if (D == 32) return launch_attn<32>(qkv, out, B, T, H, stream);
-    if (D == 128) return launch_attn<128>(qkv, out, B, T, H, stream);
+    if (D == 64) return launch_attn<64>(qkv, out, lse, B, T, H, stream);
+    if (D == 32) return launch_attn<32>(qkv, out, lse, B, T, H, stream);
+    if (D == 128) return launch_attn<128>(qkv, out, lse, B, T, H, stream);
+    return TQ_ERR_SHAPE;
+}
+
+// =================================================================================================
+// Attention backward (flash-style recompute).  Per (b, head), with Qs = scale*Q, Ks = scale*K:
+//   S = Qs Ks^T,  P = exp(S - lse),  O = P V,   delta_i = sum_d dO[i,d] O[i,d]
+//   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - delta),  dQ = scale * dS Ks,  dK = scale * dS^T Qs
+// Pass A keeps 64 queries stationary and streams key tiles (dQ); pass B keeps 64 keys stationary and streams
+// query tiles (dK, dV).  No atomics; P is recomputed in each pass.  Operands whose MFMA k index is the LDS row
+// (key / query) are fetched with ds_read_b64_tr_b16 from the same row-major images the other products read.
+// =================================================================================================
+namespace {
+
+typedef short s16x4b __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
+    s16x4b v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4b*)(p));
+    union { s16x4b s; uint2 u; } c;
+    c.s = v;
+    return c.u;
+}
+
+__global__ void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, float* __restrict__ delta, int T,
+                                  int H, int D, size_t n) {
+    // one wave per (b, t, h) row would be wasteful for D <= 128: one thread per row, 16-byte loads
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int h = (int)(i % H);
+    const size_t bt = i / H;
+    const int t = (int)(bt % T);
+    const size_t b = bt / T;
+    const float4* po = reinterpret_cast<const float4*>(o + bt * (size_t)(H * D) + h * D);
+    const float4* pd = reinterpret_cast<const float4*>(d_o + bt * (size_t)(H * D) + h * D);
+    float a = 0.f;
+    for (int j = 0; j < D / 4; ++j) {
+        const float4 x = po[j], y = pd[j];
+        a += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    delta[(b * H + h) * T + t] = a;
+}
+
+// stage a [64 rows][D] fp32 tile (rows of `src` with row stride `rs`, optional scale) as bf16 hi/lo row-major images
+template <int D>
+__device__ __forceinline__ void stage_rows(const float* src, size_t rs, int row0, int T, float scale, unsigned char* hi,
+                                           unsigned char* lo, int ROWB) {
+    for (int i = threadIdx.x; i < 64 * (D / 4); i += 256) {
+        const int r = i / (D / 4), c4 = i % (D / 4);
+        float4 v = make_float4(0, 0, 0, 0);
+        if (row0 + r < T) v = *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * rs + 4 * c4);
+        const float u[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+        bf16x4 hv, lv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { __bf16 hh, ll; split_bf16(u[j], hh, ll); hv[j] = hh; lv[j] = ll; }
+        *reinterpret_cast<bf16x4*>(hi + r * ROWB + c4 * 8) = hv;
+        *reinterpret_cast<bf16x4*>(lo + r * ROWB + c4 * 8) = lv;
+    }
+}
+
+// A-operand fragments (row = l&15 of a 16-row block starting at row0, k = channel) straight from global memory
+template <int D>
+__device__ __forceinline__ void load_row_frags(const float* src, size_t rs, int row, bool ok, float scale, Frag (&fh)[D / 32],
+                                               Frag (&fl)[D / 32]) {
+    const int lane = threadIdx.x & 63;
+    const float* p = src + (size_t)(ok ? row : 0) * rs + 8 * (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) {
+        float4 a = make_float4(0, 0, 0, 0), c = a;
+        if (ok) { a = *reinterpret_cast<const float4*>(p + ks * 32); c = *reinterpret_cast<const float4*>(p + ks * 32 + 4); }
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __bf16 hh, ll; split_bf16(v[j] * scale, hh, ll); fh[ks].v[j] = hh; fl[ks].v[j] = ll; }
+    }
+}
+
+// write a 16 x 64 accumulator tile set (4 column blocks) as bf16 hi/lo [row][col] image for use as an A operand
+__device__ __forceinline__ void acc_to_image(const f32x4 (&s)[4], unsigned char* hi, unsigned char* lo, int ROWB) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __bf16 hh, ll;
+            split_bf16(s[cb][r], hh, ll);
+            const int off = (4 * (lane >> 4) + r) * ROWB + (cb * 16 + (lane & 15)) * 2;
+            *reinterpret_cast<__bf16*>(hi + off) = hh;
+            *reinterpret_cast<__bf16*>(lo + off) = ll;
+        }
+}
+
+// ---- pass A: dQ ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  float* __restrict__ dqkv, int T, int H, float scale) {
+    constexpr int KS = D / 32, CB = D / 16;
+    constexpr int ROWB = D * 2 + 16;
+    constexpr int PROW = 64 * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* k_hi = lds;
+    unsigned char* k_lo = k_hi + 64 * ROWB;
+    unsigned char* v_hi = k_lo + 64 * ROWB;
+    unsigned char* v_lo = v_hi + 64 * ROWB;
+    unsigned char* p_base = v_lo + 64 * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nqt = (T + 63) / 64;
+    int bid = blockIdx.x;
+    const int qt = bid % nqt; bid /= nqt;
+    const int h = bid % H;
+    const int b = bid / H;
+    const int C3 = 3 * H * D, C1 = H * D;
+    const float* base = qkv + (size_t)b * T * C3;
+    const int q0 = qt * 64 + wave * 16;
+    unsigned char* p_hi = p_base + wave * 2 * 16 * PROW;
+    unsigned char* p_lo = p_hi + 16 * PROW;
+
+    Frag qh[KS], ql[KS], gh[KS], gl[KS];
+    {
+        const int q = q0 + (lane & 15);
+        load_row_frags<D>(base + h * D, C3, q, q < T, scale, qh, ql);
+        load_row_frags<D>(d_o + (size_t)b * T * C1 + h * D, C1, q, q < T, 1.0f, gh, gl);
+    }
+    float lrow[4], drow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 4 * (lane >> 4) + r;
+        lrow[r] = (q < T) ? lse[((size_t)b * H + h) * T + q] : 0.f;
+        drow[r] = (q < T) ? delta[((size_t)b * H + h) * T + q] : 0.f;
+    }
+    f32x4 dq[CB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (T + 63) / 64;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int s0 = kt * 64;
+        __syncthreads();
+        stage_rows<D>(base + (H + h) * D, C3, s0, T, scale, k_hi, k_lo, ROWB);
+        stage_rows<D>(base + (2 * H + h) * D, C3, s0, T, 1.0f, v_hi, v_lo, ROWB);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            s[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int key = cb * 16 + (lane & 15);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag bh, bl;
+                const int off = key * ROWB + (ks * 4 + (lane >> 4)) * 16;
+                bh.u = *reinterpret_cast<const uint4*>(k_hi + off);
+                bl.u = *reinterpret_cast<const uint4*>(k_lo + off);
+                s[cb] = mfma_x3(qh[ks].v, ql[ks].v, bh.v, bl.v, s[cb]);
+                bh.u = *reinterpret_cast<const uint4*>(v_hi + off);
+                bl.u = *reinterpret_cast<const uint4*>(v_lo + off);
+                dp[cb] = mfma_x3(gh[ks].v, gl[ks].v, bh.v, bl.v, dp[cb]);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const bool valid = (s0 + cb * 16 + (lane & 15)) < T;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = valid ? __expf(s[cb][r] - lrow[r]) : 0.f;
+                s[cb][r] = pv * (dp[cb][r] - drow[r]);  // dS
+            }
+        }
+        acc_to_image(s, p_hi, p_lo, PROW);
+        __syncthreads();
+        // dQ += dS Ks : A = dS image (row = query), B[k = key][col = d] via transposed reads of the K image
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag ah, al;
+            const int poff = (lane & 15) * PROW + (ks * 4 + (lane >> 4)) * 16;
+            ah.u = *reinterpret_cast<const uint4*>(p_hi + poff);
+            al.u = *reinterpret_cast<const uint4*>(p_lo + poff);
+            const int krow = ks * 32 + 8 * (lane >> 4) + ((lane >> 2) & 3);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                Frag bh, bl;
+                const int off = krow * ROWB + (cb * 16 + 4 * (lane & 3)) * 2;
+                bh.h[0] = tr_read(k_hi + off); bh.h[1] = tr_read(k_hi + off + 4 * ROWB);
+                bl.h[0] = tr_read(k_lo + off); bl.h[1] = tr_read(k_lo + off + 4 * ROWB);
+                dq[cb] = mfma_x3(ah.v, al.v, bh.v, bl.v, dq[cb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 4 * (lane >> 4) + r;
+        if (q < T) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                dqkv[((size_t)b * T + q) * C3 + h * D + cb * 16 + (lane & 15)] = dq[cb][r] * scale;
+        }
+    }
+}
+
+// ---- pass B: dK, dV --------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   float* __restrict__ dqkv, int T, int H, float scale) {
+    constexpr int KS = D / 32, CB = D / 16;
+    constexpr int ROWB = D * 2 + 16;
+    constexpr int PROW = 64 * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* q_hi = lds;
+    unsigned char* q_lo = q_hi + 64 * ROWB;
+    unsigned char* g_hi = q_lo + 64 * ROWB;
+    unsigned char* g_lo = g_hi + 64 * ROWB;
+    float* lq = reinterpret_cast<float*>(g_lo + 64 * ROWB);  // [64] lse of the query tile
+    float* dq_ = lq + 64;                                     // [64] delta of the query tile
+    unsigned char* p_base = reinterpret_cast<unsigned char*>(dq_ + 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nkt = (T + 63) / 64;
+    int bid = blockIdx.x;
+    const int kt = bid % nkt; bid /= nkt;
+    const int h = bid % H;
+    const int b = bid / H;
+    const int C3 = 3 * H * D, C1 = H * D;
+    const float* base = qkv + (size_t)b * T * C3;
+    const int k0 = kt * 64 + wave * 16;
+    unsigned char* p_hi = p_base + wave * 4 * 16 * PROW;   // P^T image
+    unsigned char* p_lo = p_hi + 16 * PROW;
+    unsigned char* s_hi = p_lo + 16 * PROW;                // dS^T image
+    unsigned char* s_lo = s_hi + 16 * PROW;
+
+    Frag kh[KS], kl[KS], vh[KS], vl[KS];
+    {
+        const int key = k0 + (lane & 15);
+        load_row_frags<D>(base + (H + h) * D, C3, key, key < T, scale, kh, kl);
+        load_row_frags<D>(base + (2 * H + h) * D, C3, key, key < T, 1.0f, vh, vl);
+    }
+    f32x4 dk[CB], dv[CB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nqt = (T + 63) / 64;
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int q0 = qt * 64;
+        __syncthreads();
+        stage_rows<D>(base + h * D, C3, q0, T, scale, q_hi, q_lo, ROWB);
+        stage_rows<D>(d_o + (size_t)b * T * C1 + h * D, C1, q0, T, 1.0f, g_hi, g_lo, ROWB);
+        if (tid < 64) {
+            const bool ok = (q0 + tid) < T;
+            lq[tid] = ok ? lse[((size_t)b * H + h) * T + q0 + tid] : 0.f;
+            dq_[tid] = ok ? delta[((size_t)b * H + h) * T + q0 + tid] : 0.f;
+        }
+        __syncthreads();
+        // S^T = Ks Qs^T,  dP^T = V dO^T   (16 keys x 64 queries)
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            s[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int qq = cb * 16 + (lane & 15);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag bh, bl;
+                const int off = qq * ROWB + (ks * 4 + (lane >> 4)) * 16;
+                bh.u = *reinterpret_cast<const uint4*>(q_hi + off);
+                bl.u = *reinterpret_cast<const uint4*>(q_lo + off);
+                s[cb] = mfma_x3(kh[ks].v, kl[ks].v, bh.v, bl.v, s[cb]);
+                bh.u = *reinterpret_cast<const uint4*>(g_hi + off);
+                bl.u = *reinterpret_cast<const uint4*>(g_lo + off);
+                dp[cb] = mfma_x3(vh[ks].v, vl[ks].v, bh.v, bl.v, dp[cb]);
+            }
+        }
+        f32x4 ds[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int qq = cb * 16 + (lane & 15);
+            const bool valid = (q0 + qq) < T;
+            const float lv = lq[qq], dl = dq_[qq];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = valid ? __expf(s[cb][r] - lv) : 0.f;
+                s[cb][r] = pv;
+                ds[cb][r] = pv * (dp[cb][r] - dl);
+            }
+        }
+        acc_to_image(s, p_hi, p_lo, PROW);
+        acc_to_image(ds, s_hi, s_lo, PROW);
+        __syncthreads();
+        // dV += P^T dO,  dK += dS^T Qs : B[k = query][col = d] via transposed reads of the dO / Q images
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag ph, pl, sh_, sl_;
+            const int poff = (lane & 15) * PROW + (ks * 4 + (lane >> 4)) * 16;
+            ph.u = *reinterpret_cast<const uint4*>(p_hi + poff);
+            pl.u = *reinterpret_cast<const uint4*>(p_lo + poff);
+            sh_.u = *reinterpret_cast<const uint4*>(s_hi + poff);
+            sl_.u = *reinterpret_cast<const uint4*>(s_lo + poff);
+            const int qrow = ks * 32 + 8 * (lane >> 4) + ((lane >> 2) & 3);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                Frag bh, bl;
+                const int off = qrow * ROWB + (cb * 16 + 4 * (lane & 3)) * 2;
+                bh.h[0] = tr_read(g_hi + off); bh.h[1] = tr_read(g_hi + off + 4 * ROWB);
+                bl.h[0] = tr_read(g_lo + off); bl.h[1] = tr_read(g_lo + off + 4 * ROWB);
+                dv[cb] = mfma_x3(ph.v, pl.v, bh.v, bl.v, dv[cb]);
+                bh.h[0] = tr_read(q_hi + off); bh.h[1] = tr_read(q_hi + off + 4 * ROWB);
+                bl.h[0] = tr_read(q_lo + off); bl.h[1] = tr_read(q_lo + off + 4 * ROWB);
+                dk[cb] = mfma_x3(sh_.v, sl_.v, bh.v, bl.v, dk[cb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 4 * (lane >> 4) + r;
+        if (key < T) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const size_t o = ((size_t)b * T + key) * C3 + cb * 16 + (lane & 15);
+                dqkv[o + (H + h) * D] = dk[cb][r] * scale;
+                dqkv[o + (2 * H + h) * D] = dv[cb][r];
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_attn_bwd(const float* qkv, const float* out, const float* d_o, const float* lse, float* delta, float* dqkv, int B,
+                    int T, int H, hipStream_t stream) {
+    constexpr int ROWB = D * 2 + 16, PROW = 64 * 2 + 16;
+    const size_t n = (size_t)B * T * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, d_o, delta, T, H, D, n);
+    TQ_CHECK_LAUNCH();
+    const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
+    const int nt = (T + 63) / 64;
+    const size_t shA = 4 * 64 * ROWB + 4 * 2 * 16 * PROW;
+    const size_t shB = 4 * 64 * ROWB + 128 * sizeof(float) + 4 * 4 * 16 * PROW;
+    if (shA > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
+    if (shB > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
+    hipLaunchKernelGGL(attention_bwd_dq_kernel<D>, dim3(B * H * nt), dim3(256), shA, stream, qkv, d_o, lse, delta, dqkv, T, H, scale);
+    TQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel<D>, dim3(B * H * nt), dim3(256), shB, stream, qkv, d_o, lse, delta, dqkv, T, H, scale);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" int tq_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
+                                float* dqkv, int B, int T, int H, int D, hipStream_t stream) {
+    if (!qkv || !out || !dout || !lse || !delta || !dqkv) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || H <= 0) return TQ_ERR_SHAPE;
+    if (D == 64) return launch_attn_bwd<64>(qkv, out, dout, lse, delta, dqkv, B, T, H, stream);
+    if (D == 32) return launch_attn_bwd<32>(qkv, out, dout, lse, delta, dqkv, B, T, H, stream);
+    if (D == 128) return launch_attn_bwd<128>(qkv, out, dout, lse, delta, dqkv, B, T, H, stream);
     return TQ_ERR_SHAPE;
 }

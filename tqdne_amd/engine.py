@@ -21,6 +21,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
+from .engine_bwd import BackwardPlan
 from ._lib import (TQ_CONV_DROPOUT, TQ_CONV_EMB, TQ_CONV_GN, TQ_CONV_RES, TQ_CONV_SILU, TQ_CONV_STATS, STAT_SLOT,
                    TqConvDesc, check)
 
@@ -46,16 +47,28 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 class Act:
     """A channels-last activation (B, T, C) and, optionally, its per-channel partial statistics."""
 
-    __slots__ = ("buf", "stats", "C", "T")
+    __slots__ = ("buf", "stats", "C", "T", "grad", "gw")
 
     def __init__(self, buf, stats, C, T):
         self.buf, self.stats, self.C, self.T = buf, stats, C, T
+        self.grad = None   # gradient buffer (training plans only)
+        self.gw = False    # backward-plan construction: has some op already written the gradient?
+
+
+class ConvRec:
+    """Everything the backward of one fused conv launch needs (the forward descriptor is reused for the weight gradient)."""
+
+    __slots__ = ("site", "desc", "srcs", "gn", "out", "stride", "upsample", "silu", "dropout")
+
+    def __init__(self, site, desc, srcs, gn, out, stride, upsample, silu, dropout):
+        self.site, self.desc, self.srcs, self.gn, self.out = site, desc, srcs, gn, out
+        self.stride, self.upsample, self.silu, self.dropout = stride, upsample, silu, dropout
 
 
 class ConvSite:
     """One convolution's weights: torch parameter + packed bf16 hi/lo MFMA fragments."""
 
-    __slots__ = ("weight", "bias", "packed", "C_out", "C_in", "K", "version", "name")
+    __slots__ = ("weight", "bias", "packed", "packed_t", "C_out", "C_in", "K", "version", "name")
 
     def __init__(self, name, weight, bias, device, lib):
         self.name = name
@@ -63,6 +76,7 @@ class ConvSite:
         self.C_out, self.C_in, self.K = weight.shape
         nbytes = lib.tq_conv_weight_pack_bytes(self.C_out, self.C_in, self.K, 0)
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.packed_t = None  # transposed / tap-flipped fragments for the data gradient (training only)
         self.version = -1
 
 
@@ -95,6 +109,11 @@ class UNetEngine:
         self.dropout_descs: List[TqConvDesc] = []
         self.acts: List[Act] = []
         self._probe = None
+        self.tape = []
+        self.last_rec = None
+        self._bwd = None
+        self.dgrad_sites = []
+        self._wt_version = None
         self._build()
         self._w_version = None
 
@@ -167,6 +186,7 @@ class UNetEngine:
             C.byref(d), _p(s0.buf), _p(s1.buf) if s1 else None, _p(gn[0]) if gn else None, _p(gn[1]) if gn else None,
             _p(site.packed), _p(site.bias), emb_ptr, _p(res.buf) if res else None, _p(out.buf), _p(out.stats)),
             "conv:" + site.name, 2 * site.C_in * site.C_out * site.K * T_out * self.B))
+        self.last_rec = ConvRec(site, d, list(srcs), gn, out, stride, upsample, silu, dropout_site is not None)
         return out
 
     # ------------------------------------------------------------------ graph construction
@@ -208,9 +228,13 @@ class UNetEngine:
                 elif kind == "attn":
                     h = self._attention(h[0] if isinstance(h, tuple) else h, layer, pfx)
                 elif kind == "down":
+                    x_in = h
                     h = self._conv([h], self._site(pfx + ".op", layer.op), stride=2)
+                    self.tape.append(("down", dict(x=x_in, out=h, rec=self.last_rec)))
                 elif kind == "up":
+                    x_in = h
                     h = self._conv([h], self._site(pfx + ".conv", layer.conv), upsample=True)
+                    self.tape.append(("up", dict(x=x_in, out=h, rec=self.last_rec)))
                 else:
                     raise RuntimeError(f"unexpected layer {type(layer)} in {name}")
             return h
@@ -233,26 +257,37 @@ class UNetEngine:
         emb_ptr = self.emb_all.data_ptr() + 4 * self.emb_offsets[id(rb)] if hasattr(rb, "emb_layers") else None
         g1 = self._gn(srcs, rb.in_layers[0])
         h1 = self._conv(srcs, self._site(name + ".in_layers.2", rb.in_layers[2]), gn=g1, silu=True, emb_ptr=emb_ptr)
+        rec1 = self.last_rec
         g2 = self._gn([h1], rb.out_layers[0])
+        rec_sk = None
         if isinstance(rb.skip_connection, torch.nn.Identity):
             assert len(srcs) == 1
             res = srcs[0]
         else:
             res = self._conv(srcs, self._site(name + ".skip_connection", rb.skip_connection), stats=False)
+            rec_sk = self.last_rec
         self._site_counter += 1
-        return self._conv([h1], self._site(name + ".out_layers.3", rb.out_layers[3]), gn=g2, silu=True, res=res,
-                          dropout_site=self._site_counter)
+        out = self._conv([h1], self._site(name + ".out_layers.3", rb.out_layers[3]), gn=g2, silu=True, res=res,
+                         dropout_site=self._site_counter)
+        self.tape.append(("res", dict(rb=rb, srcs=srcs, g1=g1, g2=g2, h1=h1, out=out, rec1=rec1, rec2=self.last_rec,
+                                      rec_sk=rec_sk)))
+        return out
 
     def _attention(self, x: Act, ab, name: str) -> Act:
         g = self._gn([x], ab.norm)
         qkv = self._conv([x], self._site(name + ".qkv", ab.qkv), gn=g, silu=False, stats=False)
+        rec_qkv = self.last_rec
         att = self._act(ab.channels, x.T, False)
+        lse = self._empty(self.B, ab.num_heads, x.T)
         D = ab.channels // ab.num_heads
         if D not in (32, 64, 128):
             raise NotImplementedError(f"attention head dim {D} (kernels exist for 32, 64 and 128)")
-        self.ops.append((self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), self.B, x.T, ab.num_heads, D), "attention",
+        self.ops.append((self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), _p(lse), self.B, x.T, ab.num_heads, D), "attention",
                          4 * ab.channels * x.T * x.T * self.B))
-        return self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
+        out = self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
+        self.tape.append(("attn", dict(ab=ab, x=x, g=g, qkv=qkv, att=att, lse=lse, out=out, rec_qkv=rec_qkv,
+                                       rec_proj=self.last_rec, D=D)))
+        return out
 
     # ------------------------------------------------------------------ measurement
     def install_probe(self, name_prefix: str = "conv:"):
@@ -287,6 +322,16 @@ class UNetEngine:
                     self.emb_w[o:o + rb.out_channels].copy_(rb.emb_layers[1].weight)
                     self.emb_b[o:o + rb.out_channels].copy_(rb.emb_layers[1].bias)
         self._w_version = v
+
+    def repack_transposed(self, stream: int):
+        """Transposed / tap-flipped fragments for the data-gradient launches (training only)."""
+        v = sum(s.weight._version for s in self.dgrad_sites)
+        if v == self._wt_version:
+            return
+        for s in self.dgrad_sites:
+            check(self.lib.tq_pack_conv_weight(s.weight.data_ptr(), s.C_out, s.C_in, s.K, 1, s.packed_t.data_ptr(), stream),
+                  "pack^T " + s.name)
+        self._wt_version = v
 
     # ------------------------------------------------------------------ run
     def forward(self, x, timesteps, cond=None, *, in_scale=None, c_out=None, c_skip=None, skip_src=None,
@@ -342,8 +387,18 @@ class UNetEngine:
                     rc = fn(*args, stream)
                 if rc:
                     check(rc, what)
+        self._last = dict(x=x, in_scale=in_scale, c_out=c_out, timesteps=timesteps, cond=cond, train=train,
+                          dropout_p=p, dropout_seed=dropout_seed)
         head = m.out[2]
         check(lib.tq_head_conv_fwd(_p(self.final.buf), _p(self.head_gn[0]), _p(self.head_gn[1]), _p(head.weight),
                                    _p(head.bias), _p(c_out), _p(c_skip), _p(skip_src), _p(self.out_nct), B, T,
                                    self.final.C, m.out_channels, head.kernel_size[0], stream), "head conv")
         return self.out_nct
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dpred: torch.Tensor, gloss: torch.Tensor, c_out=None, in_scale=None):
+        """Gradients of every UNet parameter for d loss / d pred = gloss * dpred, for the last train-mode forward.
+        Returns a list aligned with ``model.parameters()`` (None for frozen parameters)."""
+        if self._bwd is None:
+            self._bwd = BackwardPlan(self)
+        return self._bwd.run(dpred, gloss)

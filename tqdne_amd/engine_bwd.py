@@ -1,0 +1,350 @@
+"""Backward plan of a UNetEngine: the reverse sweep over the forward tape, pre-bound to the HIP gradient kernels.
+
+Per block (reverse of the fusion map in engine.py):
+  ResBlock        wgrad(conv2) | dgrad(conv2)[x dropout x SiLU', GN sums] | gn_bwd_finalize | gn_bwd_apply -> d h1
+                  colsum(d h1) -> time-embedding + bias grads | wgrad(conv1) | dgrad(conv1)[x SiLU', GN sums, split over the
+                  concat sources] | gn_bwd_finalize | skip path (identity: residual term; 1x1: wgrad + dgrad) | gn_bwd_apply
+  AttentionBlock  wgrad/dgrad(proj) | attention_bwd (dq pass, dk/dv pass) | wgrad(qkv) | dgrad(qkv)[GN sums] |
+                  gn_bwd_finalize | gn_bwd_apply (+ residual)
+  Downsample      wgrad(stride 2) | zero_stuff + stride-1 dgrad      Upsample   wgrad(upsampled gather) | dgrad + pair_sum
+  head / stem     dedicated small kernels
+The tiny (B x 256) embedding-MLP backward is a handful of plain library GEMMs (torch.mm -> hipBLASLt).
+Tensors consumed twice (the UNet skip stack) get their gradient written by the first consumer met in the reverse
+sweep and accumulated by the second (accumulate flags are resolved when the plan is built).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List
+
+import torch
+
+from ._lib import (TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_STATS, STAT_SLOT, TqConvBwdDesc, check)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _nslots(T):
+    return (T + STAT_SLOT - 1) // STAT_SLOT
+
+
+class BackwardPlan:
+    def __init__(self, eng):
+        self.e = eng
+        self.lib = eng.lib
+        self.B, self.dev = eng.B, eng.dev
+        self.m = eng.m
+        self._keep = []
+        self.ops: List = []
+        self.bwd_dropout_descs: List[TqConvBwdDesc] = []
+        self._scratch: Dict = {}
+        self._layout_gradients()
+        self._build()
+
+    # ------------------------------------------------------------------ memory
+    def _empty(self, *shape):
+        t = torch.empty(*shape, dtype=torch.float32, device=self.dev)
+        self._keep.append(t)
+        return t
+
+    def scratch(self, tag, *shape):
+        key = (tag,) + tuple(shape)
+        t = self._scratch.get(key)
+        if t is None:
+            t = self._empty(self.B, *shape)
+            self._scratch[key] = t
+        return t
+
+    def grad(self, act):
+        if act.grad is None:
+            act.grad = self._empty(self.B, act.T, act.C)
+        return act.grad
+
+    def _layout_gradients(self):
+        """One flat fp32 buffer: [emb_layers weights (contiguous, block order) | emb_layers biases | d emb_all | the rest]."""
+        e, m = self.e, self.m
+        named = list(m.named_parameters())
+        self.param_order = [p for _, p in named]
+        first = []
+        for rb in e.res_blocks:
+            if hasattr(rb, "emb_layers"):
+                first.append(rb.emb_layers[1].weight)
+        for rb in e.res_blocks:
+            if hasattr(rb, "emb_layers"):
+                first.append(rb.emb_layers[1].bias)
+        ids = {id(p) for p in first}
+        rest = [p for _, p in named if id(p) not in ids]
+        total, offs = 0, {}
+        for p in first:
+            offs[id(p)] = total
+            total += p.numel()
+        self.off_demb = total
+        total += self.B * e.emb_total
+        for p in rest:
+            total = (total + 63) // 64 * 64
+            offs[id(p)] = total
+            total += p.numel()
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.gview = {pid: self.flat[o:o + p.numel()].view_as(p) for (pid, o), p in
+                      zip([(id(p), offs[id(p)]) for p in first + rest], first + rest)}
+        self.demb_all = self.flat[self.off_demb:self.off_demb + self.B * e.emb_total].view(self.B, e.emb_total)
+        self.g_emb_w = self.flat[0:e.emb_total * e.E].view(e.emb_total, e.E)
+        self.g_emb_b = self.flat[e.emb_total * e.E:e.emb_total * e.E + e.emb_total]
+        self.offs = offs
+
+    def g(self, param):
+        return self.gview[id(param)]
+
+    # ------------------------------------------------------------------ emitters
+    def _wgrad(self, rec, dy):
+        lib, site = self.lib, rec.site
+        need = lib.tq_conv1d_bwd_weight_workspace(C.byref(rec.desc))
+        self.ws_bytes = max(getattr(self, "ws_bytes", 0), need)
+        self._wgrad_ops.append(len(self.ops))
+        s0 = rec.srcs[0]
+        s1 = rec.srcs[1] if len(rec.srcs) > 1 else None
+        self.ops.append([lib.tq_conv1d_bwd_weight, [C.byref(rec.desc), _p(dy), _p(s0.buf), _p(s1.buf) if s1 else None,
+                                                    _p(rec.gn[0]) if rec.gn else None, _p(rec.gn[1]) if rec.gn else None,
+                                                    _p(self.g(site.weight)), None, 0], "wgrad:" + site.name])
+        if site.bias is not None:
+            self.ops.append([lib.tq_colsum, [_p(dy), self.B, rec.out.T, site.C_out, None, 0, _p(self.g(site.bias)), None],
+                             "colsum:" + site.name])
+
+    def _dgrad(self, rec, dy, T, dsts, accumulate, chain=True, stats=True):
+        """dy (B,T,C_out of the forward conv) -> gradient wrt the forward conv's (activated) inputs.
+        chain=True applies the forward prologue's derivative and emits GN sums; returns the gstats buffer (or None)."""
+        lib, site = self.lib, rec.site
+        if site.packed_t is None:
+            site.packed_t = torch.empty(lib.tq_conv_weight_pack_bytes(site.C_out, site.C_in, site.K, 1), dtype=torch.uint8,
+                                        device=self.dev)
+            self.e.dgrad_sites.append(site)
+        d = TqConvBwdDesc()
+        d.B, d.T, d.C_dy = self.B, T, site.C_out
+        d.C_dx0 = dsts[0].shape[2]
+        d.C_dx1 = dsts[1].shape[2] if len(dsts) > 1 else 0
+        assert d.C_dx0 + d.C_dx1 == site.C_in
+        d.ktaps = site.K
+        f = TQ_BWD_ACCUM if accumulate else 0
+        gst = None
+        s0 = rec.srcs[0]
+        s1 = rec.srcs[1] if len(rec.srcs) > 1 else None
+        if chain:
+            if rec.gn is not None:
+                f |= TQ_BWD_GN
+                if stats:
+                    f |= TQ_BWD_STATS
+                    gst = self._empty(self.B, _nslots(T), site.C_in, 2)
+            if rec.silu:
+                f |= TQ_BWD_SILU
+            if rec.dropout:
+                self.bwd_dropout_descs.append((d, rec.desc))
+        d.flags = f
+        d.dropout_site = rec.desc.dropout_site
+        self._keep.append(d)
+        self.ops.append([lib.tq_conv1d_bwd_data, [C.byref(d), _p(dy), _p(site.packed_t), _p(s0.buf) if chain else None,
+                                                  _p(s1.buf) if (chain and s1) else None,
+                                                  _p(rec.gn[0]) if (chain and rec.gn) else None,
+                                                  _p(rec.gn[1]) if (chain and rec.gn) else None, _p(dsts[0]),
+                                                  _p(dsts[1]) if len(dsts) > 1 else None, _p(gst)], "dgrad:" + site.name])
+        return gst
+
+    def _gn_bwd(self, gst, gn, norm, T, Ctot):
+        """finalise -> coefficient arrays; accumulates dgamma/dbeta."""
+        ca, cb, cc = self._empty(self.B, Ctot), self._empty(self.B, Ctot), self._empty(self.B, Ctot)
+        self.ops.append([self.lib.tq_gn_bwd_finalize, [_p(gst), _p(gn[2]), _p(norm.weight), self.B, Ctot, T, _p(ca), _p(cb), _p(cc),
+                                                       _p(self.g(norm.weight)), _p(self.g(norm.bias))], "gn_bwd_finalize"])
+        return ca, cb, cc
+
+    def _gn_apply(self, G, act, coef, Ctot, coff, r=None):
+        dx = self.grad(act)
+        self.ops.append([self.lib.tq_gn_bwd_apply, [_p(G), _p(act.buf), _p(r), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dx), self.B,
+                                                    act.T, act.C, Ctot, coff, int(act.gw)], "gn_bwd_apply"])
+        act.gw = True
+
+    # ------------------------------------------------------------------ plan
+    def _build(self):
+        e, m, lib, B = self.e, self.m, self.lib, self.B
+        self._wgrad_ops = []
+        if not hasattr(e, "dgrad_sites"):
+            e.dgrad_sites = []
+        for a in e.acts:
+            a.gw = False
+        # ---- head
+        final = e.final
+        head = m.out[2]
+        Gh = self.scratch("G", final.T, final.C)
+        gst = self._empty(B, _nslots(final.T), final.C, 2)
+        self.head_op = [lib.tq_head_conv_bwd, [None, None, _p(final.buf), _p(e.head_gn[0]), _p(e.head_gn[1]), _p(head.weight), _p(Gh),
+                                               _p(gst), _p(self.g(head.weight)), _p(self.g(head.bias)), B, final.T, final.C,
+                                               m.out_channels, head.kernel_size[0]], "head bwd"]
+        coef = self._gn_bwd(gst, e.head_gn, m.out[0], final.T, final.C)
+        self._gn_apply(Gh, final, coef, final.C, 0)
+        # ---- blocks, reversed
+        for kind, t in reversed(e.tape):
+            getattr(self, "_bwd_" + kind)(t)
+        # ---- stem (dynamic: x, in_scale)
+        stem = m.input_blocks[0][0]
+        so = e.stem_out
+        assert so.gw
+        self.stem_op = [lib.tq_stem_conv_bwd_weight, [_p(so.grad), None, None, _p(self.g(stem.weight)), B, m.in_channels, so.T,
+                                                      stem.out_channels, stem.kernel_size[0]], "stem wgrad"]
+        self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None], "colsum:stem"])
+        # shared workspace of the weight-gradient slabs
+        self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=self.dev)
+        for i in self._wgrad_ops:
+            self.ops[i][1][7] = self.ws.data_ptr()
+            self.ops[i][1][8] = self.ws.numel()
+
+    def _bwd_res(self, t):
+        rb, srcs, h1, out = t["rb"], t["srcs"], t["h1"], t["out"]
+        rec1, rec2, rec_sk = t["rec1"], t["rec2"], t["rec_sk"]
+        B, T, Co = self.B, out.T, out.C
+        assert out.gw, "gradient of a block output must be complete before its backward"
+        dout = out.grad
+        # conv2 (out_layers.3): weight grad, then data grad chained through dropout / SiLU / GN2
+        self._wgrad(rec2, dout)
+        G2 = self.scratch("G", T, Co)
+        gst2 = self._dgrad(rec2, dout, T, [G2], accumulate=False)
+        coef2 = self._gn_bwd(gst2, t["g2"], rb.out_layers[0], T, Co)
+        h1.gw = False
+        self._gn_apply(G2, h1, coef2, Co, 0)  # d h1  (= gradient of conv1's output and of the broadcast embedding)
+        dh1 = h1.grad
+        if hasattr(rb, "emb_layers"):
+            off = self.e.emb_offsets[id(rb)]
+            self.ops.append([self.lib.tq_colsum, [_p(dh1), B, T, Co, self.demb_all.data_ptr() + 4 * off, self.e.emb_total, None, None],
+                             "colsum:emb"])
+        # conv1 (in_layers.2)
+        self._wgrad(rec1, dh1)
+        Ctot = sum(s.C for s in srcs)
+        G1 = [self.scratch("G1_%d" % i, T, s.C) for i, s in enumerate(srcs)]
+        gst1 = self._dgrad(rec1, dh1, T, G1, accumulate=False)
+        coef1 = self._gn_bwd(gst1, t["g1"], rb.in_layers[0], T, Ctot)
+        # skip path + GN1 path into the block inputs
+        if rec_sk is None:
+            self._gn_apply(G1[0], srcs[0], coef1, Ctot, 0, r=dout)
+        else:
+            self._wgrad(rec_sk, dout)
+            acc = srcs[0].gw
+            assert all(s.gw == acc for s in srcs)
+            self._dgrad(rec_sk, dout, T, [self.grad(s) for s in srcs], accumulate=acc, chain=False)
+            for s in srcs:
+                s.gw = True
+            coff = 0
+            for Gs, s in zip(G1, srcs):
+                self._gn_apply(Gs, s, coef1, Ctot, coff)
+                coff += s.C
+
+    def _bwd_attn(self, t):
+        ab, x, qkv, att, out = t["ab"], t["x"], t["qkv"], t["att"], t["out"]
+        B, T, Cc = self.B, x.T, x.C
+        assert out.gw
+        dout = out.grad
+        self._wgrad(t["rec_proj"], dout)
+        datt = self.grad(att)
+        self._dgrad(t["rec_proj"], dout, T, [datt], accumulate=False, chain=False)
+        dqkv = self.grad(qkv)
+        delta = self._empty(B, ab.num_heads, T)
+        self.ops.append([self.lib.tq_attention_bwd, [_p(qkv.buf), _p(att.buf), _p(datt), _p(t["lse"]), _p(delta), _p(dqkv), B, T,
+                                                     ab.num_heads, t["D"]], "attention bwd"])
+        self._wgrad(t["rec_qkv"], dqkv)
+        G = self.scratch("G", T, Cc)
+        gst = self._dgrad(t["rec_qkv"], dqkv, T, [G], accumulate=False)
+        coef = self._gn_bwd(gst, t["g"], ab.norm, T, Cc)
+        self._gn_apply(G, x, coef, Cc, 0, r=dout)
+
+    def _bwd_down(self, t):
+        x, out, rec = t["x"], t["out"], t["rec"]
+        assert out.gw
+        dout = out.grad
+        self._wgrad(rec, dout)
+        dyz = self.scratch("dyz", x.T, out.C)
+        self.ops.append([self.lib.tq_zero_stuff, [_p(dout), _p(dyz), self.B, out.T, x.T, out.C], "zero_stuff"])
+        self._dgrad(rec, dyz, x.T, [self.grad(x)], accumulate=x.gw, chain=False)
+        x.gw = True
+
+    def _bwd_up(self, t):
+        x, out, rec = t["x"], t["out"], t["rec"]
+        assert out.gw
+        dout = out.grad
+        self._wgrad(rec, dout)
+        dup = self.scratch("dup", out.T, x.C)
+        self._dgrad(rec, dout, out.T, [dup], accumulate=False, chain=False)
+        self.ops.append([self.lib.tq_pair_sum, [_p(dup), _p(self.grad(x)), self.B, x.T, x.C, int(x.gw)], "pair_sum"])
+        x.gw = True
+
+    # ------------------------------------------------------------------ run
+    def run(self, dpred: torch.Tensor, gloss: torch.Tensor):
+        e, m, lib = self.e, self.m, self.lib
+        last = e._last
+        if not last.get("train", False) and m.dropout:
+            pass  # eval-mode forward: gradients are those of the eval network (dropout inactive), still well defined
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        e.repack_transposed(stream)
+        self.flat.zero_()
+        p, seed = float(last["dropout_p"]), int(last["dropout_seed"])
+        for d, fd in self.bwd_dropout_descs:
+            if p > 0.0:
+                d.flags |= TQ_BWD_DROPOUT
+                d.dropout_p, d.dropout_seed = p, seed
+            else:
+                d.flags &= ~TQ_BWD_DROPOUT
+        c_out = last["c_out"]
+        gl = gloss.to(torch.float32).reshape(())
+        cs = (c_out * gl) if c_out is not None else gl.expand(self.B).contiguous()
+        self._keep_run = (cs, dpred)
+        fn, args, what = self.head_op
+        args[0], args[1] = dpred.data_ptr(), cs.data_ptr()
+        check(fn(*args, stream), what)
+        for fn, args, what in self.ops:
+            rc = fn(*args, stream)
+            if rc:
+                check(rc, what)
+        fn, args, what = self.stem_op
+        args[1], args[2] = last["x"].data_ptr(), _p(last["in_scale"])
+        check(fn(*args, stream), what)
+        self._embedding_backward(last)
+        out = self.flat.clone()
+        res = []
+        for p_ in self.param_order:
+            if not p_.requires_grad:
+                res.append(None)
+            else:
+                o = self.offs[id(p_)]
+                res.append(out[o:o + p_.numel()].view_as(p_))
+        return res
+
+    def _embedding_backward(self, last):
+        """Backward of Fourier -> time MLP (+ cond MLP) -> per-block Linear(SiLU(emb)) (unet.py:91-97, 210-227, 383-388).
+        (B x 4mc) matrices: plain library GEMMs."""
+        e, m = self.e, self.m
+
+        def dsilu(u):
+            s = torch.sigmoid(u)
+            return s * (1 + u * (1 - s))
+
+        demb_all = self.demb_all
+        torch.mm(demb_all.t(), e.silu_emb, out=self.g_emb_w)
+        torch.sum(demb_all, dim=0, out=self.g_emb_b)
+        d_emb = torch.mm(demb_all, e.emb_w) * dsilu(e.emb)
+        tm = m.time_mlp
+        h0 = e.emb_hidden[:, 0]
+        torch.mm(d_emb.t(), torch.nn.functional.silu(h0), out=self.g(tm[2].weight))
+        torch.sum(d_emb, dim=0, out=self.g(tm[2].bias))
+        dh0 = torch.mm(d_emb, tm[2].weight) * dsilu(h0)
+        t = last["timesteps"]
+        arg = t[:, None] * m.time_embed.W[None, :] * 2 * torch.pi
+        four = torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
+        torch.mm(dh0.t(), four, out=self.g(tm[0].weight))
+        torch.sum(dh0, dim=0, out=self.g(tm[0].bias))
+        if m.cond_features is not None:
+            cm = m.cond_mlp
+            c0 = e.emb_hidden[:, 1]
+            torch.mm(d_emb.t(), torch.nn.functional.silu(c0), out=self.g(cm[2].weight))
+            torch.sum(d_emb, dim=0, out=self.g(cm[2].bias))
+            dc0 = torch.mm(d_emb, cm[2].weight) * dsilu(c0)
+            torch.mm(dc0.t(), last["cond"], out=self.g(cm[0].weight))
+            torch.sum(dc0, dim=0, out=self.g(cm[0].bias))

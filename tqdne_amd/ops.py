@@ -101,13 +101,25 @@ def head_conv(x, weight, bias, gscale=None, gshift=None, c_out=None, c_skip=None
     return y
 
 
-def attention(qkv, heads):
+def attention(qkv, heads, return_lse=False):
     lib = _lib.load()
     B, T, C3 = qkv.shape
     D = C3 // (3 * heads)
     out = torch.empty(B, T, heads * D, device=qkv.device)
-    check(lib.tq_attention_fwd(_p(qkv), _p(out), B, T, heads, D, _stream(qkv.device)), "attention")
-    return out
+    lse = torch.empty(B, heads, T, device=qkv.device) if return_lse else None
+    check(lib.tq_attention_fwd(_p(qkv), _p(out), _p(lse), B, T, heads, D, _stream(qkv.device)), "attention")
+    return (out, lse) if return_lse else out
+
+
+def attention_bwd(qkv, out, dout, lse, heads):
+    lib = _lib.load()
+    B, T, C3 = qkv.shape
+    D = C3 // (3 * heads)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, heads, T, device=qkv.device)
+    check(lib.tq_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, heads, D, _stream(qkv.device)),
+          "attention bwd")
+    return dqkv
 
 
 def linear(x, w, b=None):
