@@ -29,19 +29,21 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=(), out_name=None) -> str:
     """Compile every HIP source for gfx950 and link the C-ABI shared library."""
-    if not force and not needs_build():
+    global_out = LIBPATH if out_name is None else os.path.join(LIBDIR, out_name)
+    if out_name is None and not force and not needs_build():
         return LIBPATH
     os.makedirs(LIBDIR, exist_ok=True)
+    tag = "" if out_name is None else "." + out_name.replace(".so", "")
     objs = []
     procs = []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             continue
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-c", path, "-o", obj]
+        obj = os.path.join(LIBDIR, src.replace(".hip", tag + ".o"))
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", *extra_flags, "-c", path, "-o", obj]
         if verbose:
             print("[tqdne_amd build]", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -52,13 +54,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
         if verbose and out.strip():
             print(out)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIBPATH] + objs
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", global_out] + objs
     if verbose:
         print("[tqdne_amd build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
-    return LIBPATH
+    return global_out
 
 
 if __name__ == "__main__":

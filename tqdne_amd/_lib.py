@@ -76,7 +76,8 @@ _OPTIONAL = {}
 
 
 def lib_path() -> str:
-    return _build.LIBPATH
+    # TQDNE_HIP_LIB: developer override used by tools/ to A/B kernel variants; the default is the in-tree build
+    return os.environ.get("TQDNE_HIP_LIB", _build.LIBPATH)
 
 
 def load():

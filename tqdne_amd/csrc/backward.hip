@@ -235,16 +235,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
                 }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int KT, int C_out,
-                                    int C_in) {
+// dw[i*KT + k] = sum_s slab[s][k][i];  block (64, 4): x -> i (coalesced), y -> split partition, grid.y -> tap
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
+                                                           int KT, int C_out, int C_in) {
+    __shared__ float red[4][64];
     const size_t n = (size_t)C_out * C_in;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (int k = 0; k < KT; ++k) {
-        float a = 0.f;
-        for (int s = 0; s < nsplit; ++s) a += slab[((size_t)s * KT + k) * n + i];
-        dw[i * KT + k] = a;
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.y;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+        int s = threadIdx.y;
+        for (; s + 4 < nsplit; s += 8) {
+            a0 += slab[((size_t)s * KT + k) * n + i];
+            a1 += slab[((size_t)(s + 4) * KT + k) * n + i];
+        }
+        if (s < nsplit) a0 += slab[((size_t)s * KT + k) * n + i];
     }
+    red[threadIdx.y][threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.y == 0 && i < n) dw[i * KT + k] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_ttiles, int& nsplit, int& ups) {
@@ -312,7 +321,7 @@ extern "C" int tq_conv1d_bwd_weight(const TqConvDesc* d, const float* dy, const 
     }
     if (rc) return rc;
     const size_t n = (size_t)d->C_out * (d->C_in0 + d->C_in1);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.slab, dw, a.nsplit,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64), d->ktaps), dim3(64, 4), 0, stream, a.slab, dw, a.nsplit,
                        d->ktaps, d->C_out, d->C_in0 + d->C_in1);
     TQ_CHECK_LAUNCH();
     return 0;

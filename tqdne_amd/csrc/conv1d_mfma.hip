@@ -18,7 +18,7 @@
 //     registers: waves of a workgroup are split along co, so no wave re-reads another wave's weights.
 //   * B operand (activations) is staged through LDS once per 32-channel chunk: 16-byte coalesced fp32
 //     loads of channels-last rows, GN/SiLU/dropout/split in registers, 8-byte LDS stores into an
-//     XOR-swizzled [row][8 x 8B] image that both ds_write_b64 and the two ds_read_b64 per fragment hit
+//     XOR-swizzled [row][4 x 16B] image that the ds_write_b64 stores and the ds_read_b128 fragment reads hit
 //     conflict-free for any tap shift.  The K taps are row shifts of the same LDS image (no im2col).
 //   * double-buffered LDS, global loads for chunk c+1 issued before the MFMAs of chunk c.
 //   * epilogue: accumulator lane = 4 consecutive co at one t -> one 16-byte store per 16x16 tile.
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     // ---- staging bookkeeping: thread owns 4 consecutive channels (m) of rows i = (tid + it*NTHR) >> 3
     const int m = tid & 7;
-    const int pslot = ((m & 1) << 2) | (m >> 1);  // logical 8-byte slot: half*4 + kq
+    const int wslot = m >> 1, whalf = m & 1;  // 16-byte slot (k quarter) and 8-byte half owned by this thread
     float4 raw[C::PRE];
     float4 g_a, g_s;
 
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             split_bf16(u[j], hh, ll);
             h[j] = hh; l[j] = ll;
         }
-        const int off = i * 64 + ((pslot ^ (2 * ((i >> 2) & 3))) << 3);
+        const int off = i * 64 + ((wslot ^ (((i >> 2) & 1) << 1)) << 4) + (whalf << 3);
         *reinterpret_cast<bf16x4*>(hi_plane + off) = h;
         *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
     };
@@ -211,7 +211,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     const size_t wstep = (size_t)p.ncob_pad * 2 * 64;  // uint4 per (chunk, tap)
 
     auto load_w = [&](int step, Frag (&ah)[2], Frag (&al)[2]) __attribute__((always_inline)) {
+#ifdef TQ_ABL_NOW
+        const uint4* wp = wbase + (size_t)(step & 1) * wstep;  // ablation: weights stay L1-resident
+#else
         const uint4* wp = wbase + (size_t)step * wstep;
+#endif
 #pragma unroll
         for (int cbk = 0; cbk < 2; ++cbk) {
             ah[cbk].u = wp[(cbk * 2 + 0) * 64];
@@ -222,18 +226,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     auto mma_tap = [&](int k, const unsigned char* hi_plane, const unsigned char* lo_plane, const Frag (&ah)[2],
                        const Frag (&al)[2]) __attribute__((always_inline)) {
+        // LDS image: row = 64 B = 4 slots of 16 B (one k-quarter each), slot' = kq ^ (2 * ((row >> 2) & 1)): conflict-free for
+        // ds_read_b128 at every row offset (tap shift) and for the 8-byte staging stores.  Row of t-block tb is rowk + 16*tb,
+        // which leaves the swizzle term unchanged: one address per tap, t-blocks are immediate offsets.
+        const int rowk = (STRIDE == 1) ? (tl_lane + k) : ((k & 1) * (C::NT + 1) + tl_lane + (k >> 1));
+        const int b0 = rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
-            const int tl = tl_lane + tb * 16;
-            const int row = (STRIDE == 1) ? (tl + k) : ((k & 1) * (C::NT + 1) + tl + (k >> 1));
-            const int sw = 2 * ((row >> 2) & 3);
-            const int o0 = row * 64 + ((kq ^ sw) << 3);
-            const int o1 = row * 64 + (((4 + kq) ^ sw) << 3);
+#ifdef TQ_ABL_NOLDS
+            constexpr int toff = 0;
+            (void)tb;
+#else
+            const int toff = tb * 16 * 64;
+#endif
             Frag bh, bl;
-            bh.h[0] = *reinterpret_cast<const uint2*>(hi_plane + o0);
-            bh.h[1] = *reinterpret_cast<const uint2*>(hi_plane + o1);
-            bl.h[0] = *reinterpret_cast<const uint2*>(lo_plane + o0);
-            bl.h[1] = *reinterpret_cast<const uint2*>(lo_plane + o1);
+            bh.u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);
+            bl.u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
                 acc[cbk][tb] = mfma_x3(ah[cbk].v, al[cbk].v, bh.v, bl.v, acc[cbk][tb]);
@@ -270,9 +278,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const bool more = (c + 1) < nchunks;
+#ifdef TQ_ABL_NOSTAGE
+        if (wave_active) compute(c, c & 1);  // ablation: no staging after the first chunk
+#else
         if (more) stage_load(c + 1);
         if (wave_active) compute(c, c & 1);
         if (more) stage_write(c + 1, (c + 1) & 1);
+#endif
         __syncthreads();
     }
 

@@ -25,19 +25,34 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     const int b = blockIdx.x;
     double* csum = sh;
     double* gstat = sh + 2 * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    // thread = (channel, slot part): PARTS threads share one channel's slots so the dependent-load chain is short
+    const int PARTS = (C <= 64) ? 4 : ((C <= 128) ? 2 : 1);
+    for (int idx = threadIdx.x; idx < C * PARTS; idx += blockDim.x) {
+        const int c = idx / PARTS, part = idx % PARTS;
         const float* st;
         int cs, cc;
         if (c < C0) { st = st0; cs = C0; cc = c; } else { st = st1; cs = C1; cc = c - C0; }
         const float* pp = st + ((size_t)b * nslots * cs + cc) * 2;
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
         double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < nslots; ++s) {
+        int s = part;
+        for (; s + PARTS < nslots; s += 2 * PARTS) {
             const float2 v = *reinterpret_cast<const float2*>(pp + (size_t)s * cs * 2);
-            s1 += (double)v.x;
-            s2 += (double)v.y;
+            const float2 v2 = *reinterpret_cast<const float2*>(pp + (size_t)(s + PARTS) * cs * 2);
+            s1 += (double)v.x + (double)v2.x;
+            s2 += (double)v.y + (double)v2.y;
         }
-        csum[2 * c] = s1;
-        csum[2 * c + 1] = s2;
+        for (; s < nslots; s += PARTS) {
+            const float2 v = *reinterpret_cast<const float2*>(pp + (size_t)s * cs * 2);
+            s1 += (double)v.x; s2 += (double)v.y;
+        }
+        (void)s1a; (void)s2a; (void)s1b; (void)s2b;
+        if (PARTS == 1) { csum[2 * c] = s1; csum[2 * c + 1] = s2; }
+        else {
+            // combine the parts of one channel (adjacent lanes)
+            for (int o = 1; o < PARTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if (part == 0) { csum[2 * c] = s1; csum[2 * c + 1] = s2; }
+        }
     }
     __syncthreads();
     const int G = C / GN_GROUPS;
@@ -284,14 +299,28 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
 namespace {
 __device__ __forceinline__ void gemv_rows(const float* __restrict__ w, const float* __restrict__ bias,
                                           const float* in_sh, int n_in, int n_out, float* out_sh, bool accumulate) {
+    // wave-per-output dot products, 8 outputs in flight per wave so the L2 latency of the weight rows overlaps
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = wave; o < n_out; o += 4) {
-        float a = 0.f;
-        for (int i = lane; i < n_in; i += 64) a = fmaf(w[(size_t)o * n_in + i], in_sh[i], a);
-        a = wave_sum(a);
+    constexpr int U = 8;
+    for (int o0 = wave * U; o0 < n_out; o0 += 4 * U) {
+        float a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = 0.f;
+        for (int i = lane; i < n_in; i += 64) {
+            const float xv = in_sh[i];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (o0 + u < n_out) a[u] = fmaf(w[(size_t)(o0 + u) * n_in + i], xv, a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = wave_sum(a[u]);
         if (lane == 0) {
-            a += bias[o];
-            out_sh[o] = accumulate ? out_sh[o] + a : a;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (o0 + u < n_out) {
+                    const float v = a[u] + bias[o0 + u];
+                    out_sh[o0 + u] = accumulate ? out_sh[o0 + u] + v : v;
+                }
         }
     }
 }
