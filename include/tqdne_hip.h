@@ -157,8 +157,10 @@ int tq_linear_fwd(const float* x, const float* w, const float* bias, float* out,
 /* ---- attention -------------------------------------------------------------------------------------------- */
 /* QKVAttention (blocks.py:156-190), qkv (B, T, 3*H*D) channels-last with channel order [q heads | k heads | v heads],
  * q and k each scaled by D^-1/4, softmax over keys in fp32, out (B, T, H*D).  D in {32, 64, 128}. */
-int tq_attention_fwd(const float* qkv, float* out, float* lse /* (B,H,T) log-sum-exp per query, NULL at inference */, int B,
-                     int T, int H, int D, hipStream_t stream);
+size_t tq_attention_workspace_bytes(int B, int T, int H, int D);
+int tq_attention_fwd(const float* qkv, float* out, float* lse /* (B,H,T) log-sum-exp per query, NULL at inference */,
+                     void* workspace /* tq_attention_workspace_bytes(); NULL selects the workspace-free kernel */, int B, int T,
+                     int H, int D, hipStream_t stream);
 /* backward of the above (recomputes P from qkv and lse): dqkv (B, T, 3*H*D) from dout (B, T, H*D);
  * delta (B,H,T) is scratch.  Two passes: queries-stationary for dq, keys-stationary for dk/dv (no atomics). */
 int tq_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv, int B,

@@ -126,12 +126,14 @@ def test_attention(H, D, T):
     B = 2
     qkv = torch.randn(B, 3 * H * D, T, generator=g) * 1.5
     out = ops.attention(cl(qkv), H)
+    out1 = ops.attention(cl(qkv), H, workspace=False)
     q, k, v = qkv.chunk(3, dim=1)
     sc = 1 / math.sqrt(math.sqrt(D))
     w = torch.einsum("bct,bcs->bts", (q * sc).reshape(B * H, D, T), (k * sc).reshape(B * H, D, T))
     w = torch.softmax(w.float(), dim=-1)
     ref = torch.einsum("bts,bcs->bct", w, v.reshape(B * H, D, T)).reshape(B, -1, T)
     assert rel_err(ncw(out), ref) < TOL
+    assert rel_err(ncw(out1), ref) < TOL
 
 
 def test_attention_peaked_softmax():
@@ -141,12 +143,12 @@ def test_attention_peaked_softmax():
     B, H, D, T = 1, 1, 64, 256
     qkv = torch.randn(B, 3 * D, T, generator=g)
     qkv[0, D:2 * D, 200] = qkv[0, :D, 5] * 6.0  # key 200 aligned with query 5 (in a later tile)
-    out = ops.attention(cl(qkv), H)
     q, k, v = qkv.chunk(3, dim=1)
     sc = 1 / math.sqrt(math.sqrt(D))
     w = torch.softmax(torch.einsum("bct,bcs->bts", q * sc, k * sc), dim=-1)
     ref = torch.einsum("bts,bcs->bct", w, v)
-    assert rel_err(ncw(out), ref) < TOL
+    for ws in (True, False):
+        assert rel_err(ncw(ops.attention(cl(qkv), H, workspace=ws)), ref) < TOL
 
 
 @pytest.mark.parametrize("cin,cout,T", [(3, 64, 4096), (3, 32, 250), (6, 64, 4064), (16, 64, 512)])

@@ -50,7 +50,8 @@ _PROTOS = {
     "tq_gn_finalize": (I, [VP, I, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
     "tq_embed_fwd": (I, [VP] * 14 + [I, I, I, VP]),
     "tq_linear_fwd": (I, [VP] * 4 + [I, I, I, VP]),
-    "tq_attention_fwd": (I, [VP, VP, VP, I, I, I, I, VP]),
+    "tq_attention_fwd": (I, [VP, VP, VP, VP, I, I, I, I, VP]),
+    "tq_attention_workspace_bytes": (SZ, [I, I, I, I]),
     "tq_attention_bwd": (I, [VP] * 6 + [I, I, I, I, VP]),
     "tq_edm_scalars": (I, [VP, I, F, VP, VP, VP, VP, VP, I, VP]),
     "tq_cm_scalars": (I, [VP, I, F, F, VP, VP, I, VP]),

@@ -218,9 +218,287 @@ int launch_attn(const float* qkv, float* out, float* lse, int B, int T, int H, h
 }
 }  // namespace
 
-extern "C" int tq_attention_fwd(const float* qkv, float* out, float* lse, int B, int T, int H, int D, hipStream_t stream) {
+// -------------------------------------------------------------------------------------------------
+// Forward, second generation (used when the caller supplies a workspace):
+//   * K (scaled) and V are split into bf16 hi/lo ONCE by a prep pass ([b][h][plane][Tp][D]); the main kernel's staging
+//     is then a pure 16-byte copy (the first-generation kernel re-did the split in each of the T/64 query tiles);
+//   * 128 queries per workgroup (32 per wave), so each staged key tile feeds twice the MFMA work;
+//   * scores are computed transposed, S^T = K Q^T: the accumulator lane then holds 4 consecutive keys of ONE query,
+//     which is exactly an A-operand fragment of the P V product once the k-slots of a 32-key step are permuted as
+//     key(g, j) = 16*(j>>2) + 4*g + (j&3).  V is read with ds_read_b64_tr_b16 from its row-major image with the same
+//     permutation, so P never goes through LDS and V is never transposed;
+//   * softmax reductions: 15 in-lane max/adds + 2 cross-lane steps (lanes l, l^16, l^32) per query.
+// LDS rows are padded by 32 bytes: conflict-free for the b128 K reads and the transposed V reads (all D).
+// -------------------------------------------------------------------------------------------------
+namespace {
+typedef short s16x4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 tr_read_f(const unsigned char* p) {
+    s16x4f v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4f*)(p));
+    union { s16x4f s; uint2 u; } c;
+    c.s = v;
+    return c.u;
+}
+
+// kv[b][h][plane][t][d] (bf16), planes: 0 K hi, 1 K lo, 2 V hi, 3 V lo; rows t >= T are zero
+__global__ void attn_prep_kernel(const float* __restrict__ qkv, unsigned char* __restrict__ kv, int T, int Tp, int H, int D,
+                                 float scale, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d4n = D >> 2;
+    const int c4 = (int)(i % d4n);
+    size_t r = i / d4n;
+    const int t = (int)(r % Tp); r /= Tp;
+    const int h = (int)(r % H);
+    const size_t b = r / H;
+    float4 kx = make_float4(0, 0, 0, 0), vx = kx;
+    if (t < T) {
+        const float* row = qkv + ((size_t)b * T + t) * (3 * H * D);
+        kx = *reinterpret_cast<const float4*>(row + (H + h) * D + 4 * c4);
+        vx = *reinterpret_cast<const float4*>(row + (2 * H + h) * D + 4 * c4);
+    }
+    const float ku[4] = {kx.x * scale, kx.y * scale, kx.z * scale, kx.w * scale};
+    const float vu[4] = {vx.x, vx.y, vx.z, vx.w};
+    bf16x4 kh, kl, vh, vl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __bf16 a, c;
+        split_bf16(ku[j], a, c); kh[j] = a; kl[j] = c;
+        split_bf16(vu[j], a, c); vh[j] = a; vl[j] = c;
+    }
+    const size_t plane = (size_t)Tp * D * 2;  // bytes
+    unsigned char* base = kv + (((size_t)b * H + h) * 4) * plane + ((size_t)t * D + 4 * c4) * 2;
+    *reinterpret_cast<bf16x4*>(base) = kh;
+    *reinterpret_cast<bf16x4*>(base + plane) = kl;
+    *reinterpret_cast<bf16x4*>(base + 2 * plane) = vh;
+    *reinterpret_cast<bf16x4*>(base + 3 * plane) = vl;
+}
+
+// staging vector i = tid + it*256 -> (plane, row, 16-byte column) of one 64-key tile of the pre-split K/V planes
+template <int D, int NIT>
+__device__ __forceinline__ void att_load(uint4 (&stg)[NIT], const unsigned char* kvb, size_t gplane, int kt, int tid) {
+    constexpr int V16 = D / 8;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256;
+        const int pl = i / (64 * V16), rem = i % (64 * V16);
+        const int row = rem / V16, c16 = rem % V16;
+        stg[it] = *reinterpret_cast<const uint4*>(kvb + pl * gplane + ((size_t)(kt * 64 + row) * D) * 2 + c16 * 16);
+    }
+}
+template <int D, int NIT>
+__device__ __forceinline__ void att_write(const uint4 (&stg)[NIT], unsigned char* buf, int, int tid) {
+    constexpr int V16 = D / 8;
+    constexpr int ROWB = 2 * D + 32;
+    constexpr int PLANE = 64 * ROWB;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256;
+        const int pl = i / (64 * V16), rem = i % (64 * V16);
+        const int row = rem / V16, c16 = rem % V16;
+        *reinterpret_cast<uint4*>(buf + pl * PLANE + row * ROWB + c16 * 16) = stg[it];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv,
+                                                                float* __restrict__ out, float* __restrict__ lse, int T, int Tp,
+                                                                int H, float scale) {
+    constexpr int KS = D / 32, CB = D / 16, QB = 2;
+    constexpr int ROWB = 2 * D + 32;
+    constexpr int PLANE = 64 * ROWB;
+    constexpr int BUFB = 4 * PLANE;          // one LDS buffer: K hi, K lo, V hi, V lo
+    constexpr int V16 = D / 8;               // 16-byte vectors per row
+    constexpr int NIT = (4 * 64 * V16) / 256;  // staging vectors per thread per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int nqt = (T + 127) / 128;
+    int bid = blockIdx.x;
+    const int qt = bid % nqt; bid /= nqt;
+    const int h = bid % H;
+    const int b = bid / H;
+    const int C3 = 3 * H * D;
+    const int q0w = qt * 128 + wave * 32;
+
+    // Q as the B operand of S^T = K Q^T: lane (col = query li, k = 8*g + j)
+    Frag qh[QB][KS], ql[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0w + qb * 16 + li;
+        const bool ok = q < T;
+        const float* qp = qkv + ((size_t)b * T + (ok ? q : 0)) * C3 + h * D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float4 a = make_float4(0, 0, 0, 0), c = a;
+            if (ok) { a = *reinterpret_cast<const float4*>(qp + ks * 32); c = *reinterpret_cast<const float4*>(qp + ks * 32 + 4); }
+            const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { __bf16 hh, ll; split_bf16(v[j] * scale, hh, ll); qh[qb][ks].v[j] = hh; ql[qb][ks].v[j] = ll; }
+        }
+    }
+    f32x4 o[QB][CB];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) o[qb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const size_t gplane = (size_t)Tp * D * 2;
+    const unsigned char* kvb = kv + (((size_t)b * H + h) * 4) * gplane;
+    const int nkt = (T + 63) / 64;
+    {
+        uint4 stg[NIT];
+        att_load<D, NIT>(stg, kvb, gplane, 0, tid);
+        att_write<D, NIT>(stg, lds, 0, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int s0 = kt * 64;
+        const bool more = (kt + 1) < nkt;
+        const unsigned char* k_hi = lds + BUFB * (kt & 1);
+        const unsigned char* k_lo = k_hi + PLANE;
+        const unsigned char* v_hi = k_hi + 2 * PLANE;
+        const unsigned char* v_lo = k_hi + 3 * PLANE;
+        uint4 stg[NIT];
+        att_load<D, NIT>(stg, kvb, gplane, more ? kt + 1 : kt, tid);  // in flight under this tile's MFMAs, written to the other buffer afterwards
+        // ---- S^T tiles: st[kb][qb], lane holds keys kb*16 + 4g + r of query qb*16 + li
+        f32x4 st[4][QB];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) st[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag ah, al;
+                const int off = (kb * 16 + li) * ROWB + (ks * 4 + g) * 16;
+                ah.u = *reinterpret_cast<const uint4*>(k_hi + off);
+                al.u = *reinterpret_cast<const uint4*>(k_lo + off);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) st[kb][qb] = mfma_x3(ah.v, al.v, qh[qb][ks].v, ql[qb][ks].v, st[kb][qb]);
+            }
+        }
+        // ---- online softmax per query (lane column), keys spread over kb, r (in-lane) and g (lanes li + 16 g)
+        float alpha[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (s0 + kb * 16 + 4 * g + r >= T) st[kb][qb][r] = -INFINITY;
+                    mx = fmaxf(mx, st[kb][qb][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qb], mx);
+            alpha[qb] = (m_run[qb] == -INFINITY) ? 0.f : __expf(m_run[qb] - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = (st[kb][qb][r] == -INFINITY) ? 0.f : __expf(st[kb][qb][r] - m_new);
+                    st[kb][qb][r] = pv;
+                    rs += pv;
+                }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            l_run[qb] = l_run[qb] * alpha[qb] + rs;
+            m_run[qb] = m_new;
+        }
+        // ---- rescale O (rows = queries 4g + r of the block: fetch their alpha from the lane that owns that query)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ar = __shfl(alpha[qb], 4 * g + r);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) o[qb][cb][r] *= ar;
+            }
+        // ---- O += P V, k-slot (g, j) of a 32-key step <-> key 16*(j>>2) + 4g + (j&3)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            Frag ph[QB], pl[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 hh, ll;
+                    split_bf16(st[2 * ks2 + (j >> 2)][qb][j & 3], hh, ll);
+                    ph[qb].v[j] = hh; pl[qb].v[j] = ll;
+                }
+            const int vrow = ks2 * 32 + 4 * g + ((lane >> 2) & 3);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                Frag bh, bl;
+                const int off = vrow * ROWB + (cb * 16 + 4 * (lane & 3)) * 2;
+                bh.h[0] = tr_read_f(v_hi + off); bh.h[1] = tr_read_f(v_hi + off + 16 * ROWB);
+                bl.h[0] = tr_read_f(v_lo + off); bl.h[1] = tr_read_f(v_lo + off + 16 * ROWB);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) o[qb][cb] = mfma_x3(ph[qb].v, pl[qb].v, bh.v, bl.v, o[qb][cb]);
+            }
+        }
+        att_write<D, NIT>(stg, lds + BUFB * ((kt + 1) & 1), 0, tid);  // (the last iteration re-stages its own tile: harmless)
+        __syncthreads();
+    }
+    // ---- normalise, store
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float inv_own = 1.0f / l_run[qb];
+        if (lse && g == 0) {
+            const int q = q0w + qb * 16 + li;
+            if (q < T) lse[((size_t)b * H + h) * T + q] = m_run[qb] + __logf(l_run[qb]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = __shfl(inv_own, 4 * g + r);
+            const int q = q0w + qb * 16 + 4 * g + r;
+            if (q < T) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) out[((size_t)b * T + q) * (H * D) + h * D + cb * 16 + li] = o[qb][cb][r] * inv;
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int T, int H, hipStream_t stream) {
+    const int Tp = (T + 63) / 64 * 64;
+    const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
+    const size_t n = (size_t)B * H * Tp * (D / 4);
+    hipLaunchKernelGGL(attn_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, qkv,
+                       reinterpret_cast<unsigned char*>(ws), T, Tp, H, D, scale, n);
+    TQ_CHECK_LAUNCH();
+    constexpr int ROWB = 2 * D + 32;
+    const size_t sh = 2 * 4 * 64 * ROWB;
+    if (sh > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd2_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    const int nqt = (T + 127) / 128;
+    hipLaunchKernelGGL(attention_fwd2_kernel<D>, dim3(B * H * nqt), dim3(256), sh, stream, qkv,
+                       reinterpret_cast<const unsigned char*>(ws), out, lse, T, Tp, H, scale);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t tq_attention_workspace_bytes(int B, int T, int H, int D) {
+    const size_t Tp = (size_t)(T + 63) / 64 * 64;
+    return (size_t)B * H * 4 * Tp * D * 2;
+}
+
+extern "C" int tq_attention_fwd(const float* qkv, float* out, float* lse, void* workspace, int B, int T, int H, int D,
+                                hipStream_t stream) {
     if (!qkv || !out) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || H <= 0) return TQ_ERR_SHAPE;
+    if (workspace) {
+        if (D == 64) return launch_attn2<64>(qkv, out, lse, workspace, B, T, H, stream);
+        if (D == 32) return launch_attn2<32>(qkv, out, lse, workspace, B, T, H, stream);
+        if (D != 128) return TQ_ERR_SHAPE;  // D = 128 (tiny config's middle block) stays on the first-generation kernel
+    }
     if (D == 64) return launch_attn<64>(qkv, out, lse, B, T, H, stream);
     if (D == 32) return launch_attn<32>(qkv, out, lse, B, T, H, stream);
     if (D == 128) return launch_attn<128>(qkv, out, lse, B, T, H, stream);

@@ -282,12 +282,23 @@ class UNetEngine:
         D = ab.channels // ab.num_heads
         if D not in (32, 64, 128):
             raise NotImplementedError(f"attention head dim {D} (kernels exist for 32, 64 and 128)")
-        self.ops.append((self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), _p(lse), self.B, x.T, ab.num_heads, D), "attention",
+        ws = self._attn_workspace(self.lib.tq_attention_workspace_bytes(self.B, x.T, ab.num_heads, D))
+        self.ops.append((self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), _p(lse), _p(ws), self.B, x.T, ab.num_heads, D), "attention",
                          4 * ab.channels * x.T * x.T * self.B))
         out = self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
         self.tape.append(("attn", dict(ab=ab, x=x, g=g, qkv=qkv, att=att, lse=lse, out=out, rec_qkv=rec_qkv,
                                        rec_proj=self.last_rec, D=D)))
         return out
+
+    def _attn_workspace(self, nbytes: int):
+        """pre-split K/V scratch, shared by all attention blocks of the plan (they run back to back on one stream)"""
+        ws = getattr(self, "_attn_ws", None)
+        if ws is None or ws.numel() < nbytes:
+            assert ws is None, "attention blocks of one plan share a shape"
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            self._keep.append(ws)
+            self._attn_ws = ws
+        return ws
 
     # ------------------------------------------------------------------ measurement
     def install_probe(self, name_prefix: str = "conv:"):

@@ -101,13 +101,14 @@ def head_conv(x, weight, bias, gscale=None, gshift=None, c_out=None, c_skip=None
     return y
 
 
-def attention(qkv, heads, return_lse=False):
+def attention(qkv, heads, return_lse=False, workspace=True):
     lib = _lib.load()
     B, T, C3 = qkv.shape
     D = C3 // (3 * heads)
     out = torch.empty(B, T, heads * D, device=qkv.device)
     lse = torch.empty(B, heads, T, device=qkv.device) if return_lse else None
-    check(lib.tq_attention_fwd(_p(qkv), _p(out), _p(lse), B, T, heads, D, _stream(qkv.device)), "attention")
+    ws = torch.empty(lib.tq_attention_workspace_bytes(B, T, heads, D), dtype=torch.uint8, device=qkv.device) if workspace else None
+    check(lib.tq_attention_fwd(_p(qkv), _p(out), _p(lse), _p(ws), B, T, heads, D, _stream(qkv.device)), "attention")
     return (out, lse) if return_lse else out
 
 
