@@ -120,15 +120,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         return src + (size_t)b * p.T_in * cs + coff + 4 * m;
     };
 
+    // branch-free: out-of-range rows load a clamped (valid) row and are zeroed in write_one -- an exec-masked load would put
+    // control flow in front of the MFMA phase and make hipcc drain every outstanding load there (s_waitcnt vmcnt(0))
     auto load_one = [&](const float* base, int cs, int it) -> float4 __attribute__((always_inline)) {
         const int i = (tid + it * C::NTHR) >> 3;
-        const int pos = src_pos(i);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < C::ROWS && pos >= 0 && pos < T_src) {
-            const int srow = UPS ? (pos >> 1) : pos;
-            v = *reinterpret_cast<const float4*>(base + (size_t)srow * cs);
-        }
-        return v;
+        int pos = src_pos(i);
+        pos = pos < 0 ? 0 : (pos >= T_src ? T_src - 1 : pos);
+        const int srow = UPS ? (pos >> 1) : pos;
+        return *reinterpret_cast<const float4*>(base + (size_t)srow * cs);
     };
 
     auto write_one = [&](int chunk, int buf, int it, const float4& rv) __attribute__((always_inline)) {
@@ -138,8 +137,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         const int i = (tid + it * C::NTHR) >> 3;
         if (i >= C::ROWS) return;
         const int pos = src_pos(i);
-        float u[4] = {rv.x, rv.y, rv.z, rv.w};
         const bool inside = (pos >= 0 && pos < T_src);
+        float u[4] = {inside ? rv.x : 0.f, inside ? rv.y : 0.f, inside ? rv.z : 0.f, inside ? rv.w : 0.f};
         if (inside) {
             if (p.flags & TQ_CONV_GN) {
                 u[0] = g_a.x * u[0] + g_s.x; u[1] = g_a.y * u[1] + g_s.y;
@@ -174,10 +173,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         const float* base = chunk_base(chunk, cs);
 #pragma unroll
         for (int it = 0; it < C::PRE; ++it) raw[it] = load_one(base, cs, it);
-        if (p.flags & TQ_CONV_GN) {
+        {   // folded GroupNorm coefficients of this thread's 4 channels (loaded unconditionally: no branch; unused without GN)
             const int cb = chunk << 5;
-            g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
-            g_s = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cb + 4 * m);
+            const bool gn = (p.flags & TQ_CONV_GN) != 0;
+            const float* ga = gn ? p.gscale + (size_t)b * Cin + cb + 4 * m : base;
+            const float* gs = gn ? p.gshift + (size_t)b * Cin + cb + 4 * m : base;
+            g_a = *reinterpret_cast<const float4*>(ga);
+            g_s = *reinterpret_cast<const float4*>(gs);
         }
     };
 
@@ -210,11 +212,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * 2) * 64 + lane;
     const size_t wstep = (size_t)p.ncob_pad * 2 * 64;  // uint4 per (chunk, tap)
 
+    // ---- MFMA phase of one chunk.  Written as straight-line code (no branches inside: hipcc's waitcnt insertion falls back to
+    // s_waitcnt vmcnt(0) / lgkmcnt(0) at every control-flow join, which serialises each prefetch with its consumer) and pinned
+    // with sched_barrier so that (1) the weight fragments of tap k+2 are requested before the MFMAs of tap k+1 and (2) the
+    // LDS reads of t-block tb+1 are in flight under the MFMAs of t-block tb.
+    const int last_step = nchunks * KT - 1;
     auto load_w = [&](int step, Frag (&ah)[2], Frag (&al)[2]) __attribute__((always_inline)) {
+        const int st = step < last_step ? step : last_step;  // clamped: the final refills re-read the last fragments
 #ifdef TQ_ABL_NOW
-        const uint4* wp = wbase + (size_t)(step & 1) * wstep;  // ablation: weights stay L1-resident
+        const uint4* wp = wbase + (size_t)(st & 1) * wstep;  // ablation: weights stay L1-resident
 #else
-        const uint4* wp = wbase + (size_t)step * wstep;
+        const uint4* wp = wbase + (size_t)st * wstep;
 #endif
 #pragma unroll
         for (int cbk = 0; cbk < 2; ++cbk) {
@@ -222,7 +230,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             al[cbk].u = wp[(cbk * 2 + 1) * 64];
         }
     };
-    const int nsteps = nchunks * KT;
+
+    auto read_b = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int b0, int tb, Frag& bh, Frag& bl)
+        __attribute__((always_inline)) {
+#ifdef TQ_ABL_NOLDS
+        const int toff = 0;
+        (void)tb;
+#else
+        const int toff = tb * 16 * 64;
+#endif
+        bh.u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);
+        bl.u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);
+    };
 
     auto mma_tap = [&](int k, const unsigned char* hi_plane, const unsigned char* lo_plane, const Frag (&ah)[2],
                        const Frag (&al)[2]) __attribute__((always_inline)) {
@@ -231,62 +250,56 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         // which leaves the swizzle term unchanged: one address per tap, t-blocks are immediate offsets.
         const int rowk = (STRIDE == 1) ? (tl_lane + k) : ((k & 1) * (C::NT + 1) + tl_lane + (k >> 1));
         const int b0 = rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
+        Frag bh[2], bl[2];
+        read_b(hi_plane, lo_plane, b0, 0, bh[0], bl[0]);
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
-#ifdef TQ_ABL_NOLDS
-            constexpr int toff = 0;
-            (void)tb;
-#else
-            const int toff = tb * 16 * 64;
-#endif
-            Frag bh, bl;
-            bh.u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);
-            bl.u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);
+            if (tb + 1 < 8) read_b(hi_plane, lo_plane, b0, tb + 1, bh[(tb + 1) & 1], bl[(tb + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
-                acc[cbk][tb] = mfma_x3(ah[cbk].v, al[cbk].v, bh.v, bl.v, acc[cbk][tb]);
+                acc[cbk][tb] = mfma_x3(ah[cbk].v, al[cbk].v, bh[tb & 1].v, bl[tb & 1].v, acc[cbk][tb]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // weight fragments for step s = chunk*KT + tap are prefetched one step ahead (register double buffer)
+    // Weight fragments live in two register buffers (taps alternate a, b, a, ...); after tap k its buffer is refilled with
+    // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
+    // b = tap 1 already in flight.
     Frag wa_h[2], wa_l[2], wb_h[2], wb_l[2];
     auto compute = [&](int chunk, int buf) __attribute__((always_inline)) {
         const unsigned char* hi_plane = lds + buf * C::BUF;
         const unsigned char* lo_plane = hi_plane + C::PLANE;
         const int s0 = chunk * KT;
-        if (KT == 1) {
-            load_w(s0, wa_h, wa_l);
-            mma_tap(0, hi_plane, lo_plane, wa_h, wa_l);
-        } else {
-            // KT odd: taps 0..KT-2 in pairs (a,b), last tap alone on buffer a
-            load_w(s0, wa_h, wa_l);
-#pragma unroll 1
-            for (int k = 0; k + 1 < KT; k += 2) {
-                load_w(s0 + k + 1, wb_h, wb_l);
-                mma_tap(k, hi_plane, lo_plane, wa_h, wa_l);
-                load_w(s0 + k + 2, wa_h, wa_l);
-                mma_tap(k + 1, hi_plane, lo_plane, wb_h, wb_l);
-            }
-            mma_tap(KT - 1, hi_plane, lo_plane, wa_h, wa_l);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            if (k & 1) mma_tap(k, hi_plane, lo_plane, wb_h, wb_l);
+            else       mma_tap(k, hi_plane, lo_plane, wa_h, wa_l);
+            const int nxt = (KT == 1) ? (s0 + 1) : ((k + 2 < KT) ? (s0 + k + 2) : ((k & 1) ? (s0 + KT + 1) : (s0 + KT)));
+            if (k & 1) load_w(nxt, wb_h, wb_l); else load_w(nxt, wa_h, wa_l);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    (void)nsteps;
 
     // ---- main loop over 32-channel chunks
     stage_load(0);
+    if (wave_active) {
+        load_w(0, wa_h, wa_l);
+        if (KT > 1) load_w(1, wb_h, wb_l);
+    }
     stage_write(0, 0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = (c + 1) < nchunks;
-#ifdef TQ_ABL_NOSTAGE
-        if (wave_active) compute(c, c & 1);  // ablation: no staging after the first chunk
-#else
-        if (more) stage_load(c + 1);
+    for (int c = 0; c + 1 < nchunks; ++c) {
+#ifndef TQ_ABL_NOSTAGE
+        stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
+#endif
         if (wave_active) compute(c, c & 1);
-        if (more) stage_write(c + 1, (c + 1) & 1);
+#ifndef TQ_ABL_NOSTAGE
+        stage_write(c + 1, (c + 1) & 1);
 #endif
         __syncthreads();
     }
+    if (wave_active) compute(nchunks - 1, (nchunks - 1) & 1);
 
     // ---- epilogue
     if (!wave_active) return;
@@ -424,6 +437,11 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 
 template <int KT, int STRIDE, int UPS, int EPI = 0>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
+    // pointwise convs are staging-bound (one tap of MFMA work per staged chunk): an 8-wave workgroup covering 256 output
+    // channels stages each input tile once instead of twice (measured -32 % on 512->256, neutral for k = 5)
+    if constexpr (KT == 1 && STRIDE == 1 && UPS == 0) {
+        if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI>(a, s);
+    }
     if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI>(a, s);
     if constexpr (STRIDE == 1) {
         if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI>(a, s);

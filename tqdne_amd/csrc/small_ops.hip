@@ -299,18 +299,31 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
 namespace {
 __device__ __forceinline__ void gemv_rows(const float* __restrict__ w, const float* __restrict__ bias,
                                           const float* in_sh, int n_in, int n_out, float* out_sh, bool accumulate) {
-    // wave-per-output dot products, 8 outputs in flight per wave so the L2 latency of the weight rows overlaps
+    // wave-per-output dot products, 8 outputs in flight per wave; 16-byte weight loads when the row length allows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int U = 8;
+    const bool vec = (n_in & 3) == 0;
     for (int o0 = wave * U; o0 < n_out; o0 += 4 * U) {
         float a[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) a[u] = 0.f;
-        for (int i = lane; i < n_in; i += 64) {
-            const float xv = in_sh[i];
+        if (vec) {
+            for (int i = 4 * lane; i < n_in; i += 256) {
+                const float4 xv = *reinterpret_cast<const float4*>(in_sh + i);
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (o0 + u < n_out) a[u] = fmaf(w[(size_t)(o0 + u) * n_in + i], xv, a[u]);
+                for (int u = 0; u < U; ++u)
+                    if (o0 + u < n_out) {
+                        const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(o0 + u) * n_in + i);
+                        a[u] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+                    }
+            }
+        } else {
+            for (int i = lane; i < n_in; i += 64) {
+                const float xv = in_sh[i];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (o0 + u < n_out) a[u] = fmaf(w[(size_t)(o0 + u) * n_in + i], xv, a[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) a[u] = wave_sum(a[u]);
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ t,
                                                     const float* __restrict__ cb2, float* __restrict__ emb,
                                                     float* __restrict__ silu_emb, float* __restrict__ hidden, int mc,
                                                     int ncond) {
-    extern __shared__ float shm[];
+    extern __shared__ __attribute__((aligned(16))) float shm[];
     const int E = 4 * mc;
     float* four = shm;        // [mc]
     float* h = four + mc;     // [E]
