@@ -105,7 +105,7 @@ int tq_conv1d_bwd_weight(const TqConvDesc* desc, const float* dy, const float* x
 int tq_stem_conv_fwd(const float* x_nct, const float* in_scale, const float* w, const float* bias, float* y,
                      float* stats_partial, int B, int C_in, int T, int C_out, int ktaps, hipStream_t stream);
 
-/* Last conv: GroupNorm32+SiLU (folded scale/shift) -> conv k "same" to C_out<=4 -> (B, C_out, T) output,
+/* Last conv: GroupNorm32+SiLU (folded scale/shift) -> conv k "same" to C_out<=16 -> (B, C_out, T) output,
  * then out = c_out[b] * conv + c_skip[b] * skip_src[b, co, t]  (EDM / consistency preconditioning, edm.py:111-113,
  * consistency_model.py:78); c_out/c_skip/skip_src NULL = plain conv output.  unet.py:355-357,398. */
 int tq_head_conv_fwd(const float* x, const float* gscale, const float* gshift, const float* w, const float* bias,

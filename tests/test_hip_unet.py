@@ -196,3 +196,57 @@ def test_full_size_gradients_vs_oracle(which):
             worst, wname = e, name
     print(f"{which}: loss {float(loss):.6f}; worst gradient rel err {worst:.2e} at {wname}")
     assert worst < TOL
+
+
+def test_autoencoder_vs_golden():
+    from tqdne_amd import LightningAutoencoder
+    sd, d = load_golden("micro_ae.npz")
+    ae = LightningAutoencoder(cfg_of(d, "enc_cfg"), cfg_of(d, "dec_cfg"), {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0})
+    ae.load_state_dict(sd)
+    ae = ae.to(dev()).eval()
+    with torch.no_grad():
+        z, mean, log_std = ae._encode(torch.from_numpy(d["x"]).to(dev()), unit_noise=torch.from_numpy(d["eps"]).to(dev()))
+        xr = ae.decode(z)
+    errs = [rel_err(mean.cpu(), d["mean"]), rel_err(log_std.cpu(), d["log_std"]), rel_err(z.cpu(), d["z"]), rel_err(xr.cpu(), d["recon"])]
+    print("autoencoder mean/log_std/z/recon:", " ".join(f"{e:.2e}" for e in errs))
+    assert max(errs) < TOL
+
+
+def test_latent_edm_pipeline_vs_oracle():
+    """BASELINE config 3 at reduced batch: 3 x 16384 -> VAE encoder -> 16 x 4096 latent, latent UNet Heun sample, decoder."""
+    from oracle import autoencoder as OA
+    from oracle import edm as OE
+    from tqdne_amd import LightningAutoencoder, LightningEDM, get_1d_autoencoder_configs, paper_1d_unet_config
+
+    class C:
+        channels, latent_channels = 3, 16
+
+    enc_cfg, dec_cfg = get_1d_autoencoder_configs(C)
+    torch.manual_seed(0)
+    ae = LightningAutoencoder(enc_cfg, dec_cfg, {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0})
+    ae_sd = perturbed_state(ae, 5)
+    ae.load_state_dict(ae_sd)
+    ucfg = paper_1d_unet_config(in_channels=16, out_channels=16)
+    edm = LightningEDM(ucfg, {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0}, num_sampling_steps=3, autoencoder=ae)
+    u_sd = perturbed_state(edm.unet, 6)
+    edm.unet.load_state_dict(u_sd)
+    edm = edm.to(dev()).eval()
+    g = torch.Generator().manual_seed(9)
+    B, T = 1, 16384
+    x = 0.5 * torch.randn(B, 3, T, generator=g)
+    eps_enc = torch.randn(B, 16, T // 4, generator=g)
+    cond = torch.randn(B, 5, generator=g)
+    start = torch.randn(B, 16, T // 4, generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        z = ae._encode(x.to(dev()), unit_noise=eps_enc.to(dev()))[0].cpu()
+        zo = OA.encode(ae_sd, enc_cfg, x, eps_enc)[0]
+        sig = OE.sampling_sigmas(OE.EDMParams(), 3)
+        lat = edm.sample_deterministically((start * sig[0]).to(dev()), sig.to(dev()), None, cond.to(dev())).float()
+        rec = ae.decode(lat).cpu()
+        net = OE.make_net({"unet." + k: v for k, v in u_sd.items()}, ucfg)
+        lat_o = OE.sample_deterministic(OE.EDMParams(), net, start, 3, cond=cond).float()
+        rec_o = OA.decode(ae_sd, dec_cfg, lat_o)
+    e = [rel_err(z, zo), rel_err(lat.cpu(), lat_o), rel_err(rec, rec_o)]
+    print("latent pipeline encode / latent sample / decode:", " ".join(f"{v:.2e}" for v in e))
+    assert max(e) < TOL
+    assert edm.sample((B, 3, T), cond=cond.to(dev())).shape == (B, 3, T)

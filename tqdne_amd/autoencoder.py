@@ -1,0 +1,149 @@
+"""1-D VAE (latent EDM, BASELINE config 3): drop-in for the encode / decode part of ``tqdne.autoencoder`` and the
+``Encoder`` / ``Decoder`` of ``tqdne.blocks`` (reference tqdne/autoencoder.py:9-49, tqdne/blocks.py:233-436), on the same
+fused HIP kernels as the UNet (un-conditioned ResBlock = the fused convs without the embedding add).
+
+Same constructor keywords and ``state_dict`` schema (``encoder.input_layer``, ``encoder.down_blocks.{i}.*``,
+``encoder.output_layer``, ``decoder.input_layer``, ``decoder.up_blocks.{i}.*``, ``decoder.output_layer``).  Training of the
+autoencoder (``step``: KL + MSE, autoencoder.py:54-84) is a SURVEY section 8f "next" item and raises.
+"""
+
+from __future__ import annotations
+
+import torch as th
+from torch import nn
+
+from . import engine
+from .lightning_compat import LightningModule
+from .unet import AttentionParams, DownsampleParams, ResBlockParams, UpsampleParams
+
+
+def _check(dims, conv_resample):
+    if dims != 1 or not conv_resample:
+        raise NotImplementedError("tqdne_amd autoencoder implements the 1-D conv-resample path (dims=1)")
+
+
+class Encoder(nn.Module):
+    """blocks.py:263-348."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions=(8, 16, 32),
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_kernel_size=3, conv_resample=True, dims=2, num_heads=1,
+                 flash_attention=True):
+        super().__init__()
+        _check(dims, conv_resample)
+        self.in_channels, self.out_channels, self.num_heads = in_channels, out_channels, num_heads
+        k = conv_kernel_size
+        ch = int(channel_mult[0] * model_channels)
+        self.input_layer = nn.Conv1d(in_channels, ch, k, padding="same")
+        ds, blocks = 1, []
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                blocks.append(ResBlockParams(ch, None, dropout, int(mult * model_channels), k))
+                ch = int(mult * model_channels)
+                if ds in attention_resolutions:
+                    blocks.append(AttentionParams(ch, num_heads))
+            if level != len(channel_mult) - 1:
+                blocks.append(DownsampleParams(ch, ch))  # kernel 3 (blocks.py:337 passes none)
+                ds *= 2
+        self.down_blocks = nn.Sequential(*blocks)
+        self.output_layer = nn.Conv1d(ch, out_channels, k, padding="same")
+        self.time_scale = ds  # T_out = T_in / ds
+        self._engine_cache = {}
+
+    blocks_attr = "down_blocks"
+
+    def forward(self, x):
+        engine.require_device(x)
+        return _seq_engine(self, x).forward(x).clone()
+
+    def _apply(self, fn, *a, **k):
+        self._engine_cache = {}
+        return super()._apply(fn, *a, **k)
+
+
+class Decoder(nn.Module):
+    """blocks.py:351-436."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions=(8, 16, 32),
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_kernel_size=3, conv_resample=True, dims=2, num_heads=1,
+                 flash_attention=True):
+        super().__init__()
+        _check(dims, conv_resample)
+        self.in_channels, self.out_channels, self.num_heads = in_channels, out_channels, num_heads
+        k = conv_kernel_size
+        ch = int(channel_mult[-1] * model_channels)
+        self.input_layer = nn.Conv1d(in_channels, ch, k, padding="same")
+        ds, blocks = 2 ** (len(channel_mult) - 1), []
+        for level, mult in reversed(list(enumerate(channel_mult))):
+            if level != len(channel_mult) - 1:
+                blocks.append(UpsampleParams(ch, ch))  # kernel 3 (blocks.py:408 passes none)
+                ds //= 2
+            for _ in range(num_res_blocks):
+                blocks.append(ResBlockParams(ch, None, dropout, int(mult * model_channels), k))
+                ch = int(mult * model_channels)
+                if ds in attention_resolutions:
+                    blocks.append(AttentionParams(ch, num_heads))
+        self.up_blocks = nn.Sequential(*blocks)
+        self.output_layer = nn.Conv1d(ch, out_channels, k, padding="same")
+        self._engine_cache = {}
+
+    blocks_attr = "up_blocks"
+
+    def forward(self, x):
+        engine.require_device(x)
+        return _seq_engine(self, x).forward(x).clone()
+
+    def _apply(self, fn, *a, **k):
+        self._engine_cache = {}
+        return super()._apply(fn, *a, **k)
+
+
+def _seq_engine(mod, x):
+    key = (x.shape[0], x.shape[2], str(x.device))
+    eng = mod._engine_cache.get(key)
+    if eng is None:
+        eng = engine.SeqEngine(mod, x.shape[0], x.shape[2], x.device)
+        mod._engine_cache[key] = eng
+    return eng
+
+
+class LightningAutoencoder(LightningModule):
+    def __init__(self, encoder_config: dict, decoder_config: dict, optimizer_params: dict, kl_weight: float = 1e-6):
+        super().__init__()
+        self.encoder = Encoder(**encoder_config)
+        self.decoder = Decoder(**decoder_config)
+        self.optimizer_params = optimizer_params
+        self.kl_weight = kl_weight
+        self.config = encoder_config
+        self.save_hyperparameters()
+
+    def _encode(self, x, unit_noise=None):
+        """autoencoder.py:37-40.  ``unit_noise`` (optional) injects the N(0,1) draw of ``randn_like(mean)``."""
+        mean, log_std = th.chunk(self.encoder(x), 2, dim=1)
+        eps = th.randn_like(mean) if unit_noise is None else unit_noise
+        latent = mean + eps * th.exp(log_std)  # (B, latent, T/ds) elementwise: 1/100 of an encoder conv
+        return latent, mean, log_std
+
+    def encode(self, x):
+        return self._encode(x)[0]
+
+    def decode(self, x):
+        return self.decoder(x.contiguous())
+
+    def forward(self, x):
+        return self.decode(self._encode(x)[0])
+
+    def evaluate(self, batch):
+        return self(batch["signal"])
+
+    def kl_divergence(self, mean, log_std):
+        log_var = 2 * log_std
+        return 0.5 * th.sum(mean**2 + th.exp(log_var) - log_var - 1, dim=1)
+
+    def step(self, batch, stage="training"):
+        raise NotImplementedError("autoencoder training (autoencoder.py:54-84) is not part of the accelerated path yet")
+
+    def configure_optimizers(self):
+        optimizer = th.optim.AdamW(self.parameters(), lr=self.optimizer_params["learning_rate"], weight_decay=1e-4)
+        lr_scheduler = th.optim.lr_scheduler.CosineAnnealingLR(
+            optimizer, T_max=self.optimizer_params["max_steps"], eta_min=self.optimizer_params["eta_min"])
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": lr_scheduler, "interval": "step"}}

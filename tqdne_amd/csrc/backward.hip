@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 
 // Head backward.  dF = c_out[b]*dpred (B,Co,T).  Produces: G = (W^T * dF) * silu'(a*h+s) (B,T,Ci) with GN partial sums,
 // and accumulates dW, db (atomics into zeroed gradients).
-template <int KT>
+template <int KT, int MAXCO>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ c_out,
                                                        const float* __restrict__ h, const float* __restrict__ gscale,
                                                        const float* __restrict__ gshift, const float* __restrict__ w,
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     constexpr int TW = STAT_SLOT + KT - 1;
     const int LDZ = TW + 1;
     float* dfs = shm;                    // [C_out][TW]   dF with halo
-    float* zs = dfs + 4 * TW;            // [C_in][LDZ]   activated input with halo (transposed)
+    float* zs = dfs + MAXCO * TW;        // [C_in][LDZ]   activated input with halo (transposed)
     float* red = zs + C_in * LDZ;        // [nrow][C_in][2]
     const int slot = blockIdx.x % nslots, b = blockIdx.x / nslots;
     const int t0 = slot * STAT_SLOT;
@@ -686,14 +686,15 @@ extern "C" int tq_head_conv_bwd(const float* dpred_nct, const float* c_out, cons
                                 int T, int C_in, int C_out, int ktaps, hipStream_t stream) {
     if (!dpred_nct || !x || !w || !g_out || !dw || !db) return TQ_ERR_ARG;
     if ((gscale == nullptr) != (gshift == nullptr)) return TQ_ERR_ARG;
-    if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || 256 % (C_in / 4) || C_out < 1 || C_out > 4) return TQ_ERR_SHAPE;
+    if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || 256 % (C_in / 4) || C_out < 1 || C_out > 16) return TQ_ERR_SHAPE;
+    const int maxco = C_out <= 4 ? 4 : 16;
     const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
     const int nrow = 256 / (C_in / 4);
-    const size_t sh = ((size_t)4 * (STAT_SLOT + ktaps - 1) + (size_t)C_in * (STAT_SLOT + ktaps) + (size_t)nrow * C_in * 2) * sizeof(float);
+    const size_t sh = ((size_t)maxco * (STAT_SLOT + ktaps - 1) + (size_t)C_in * (STAT_SLOT + ktaps) + (size_t)nrow * C_in * 2) * sizeof(float);
     if (sh > 160 * 1024) return TQ_ERR_SHAPE;
 #define TQ_HB(K)                                                                                             \
     {                                                                                                        \
-        auto kern = head_bwd_kernel<K>;                                                                      \
+        auto kern = (maxco == 4) ? head_bwd_kernel<K, 4> : head_bwd_kernel<K, 16>;                                                                    \
         if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL(kern, dim3(B * nslots), dim3(256), sh, stream, dpred_nct, c_out, x, gscale, gshift, w, g_out, gstats, dw, db, T, C_in, C_out, nslots); \
     }

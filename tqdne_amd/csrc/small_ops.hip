@@ -199,7 +199,7 @@ extern "C" int tq_stem_conv_fwd(const float* x, const float* in_scale, const flo
 // into LDS as [ci][t] so that lanes (consecutive t) read consecutive words.
 // =================================================================================================
 namespace {
-template <int KT>
+template <int KT, int MAXCO>
 __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ gscale,
                                                         const float* __restrict__ gshift, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ c_out,
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     constexpr int TW = 128 + KT - 1;
     constexpr int LD = TW + 1;  // odd leading dimension: conflict-free transposed writes
     float* xs = shm;             // [C_in][LD]
-    float* part = xs + C_in * LD;  // [2][128][4]
+    float* part = xs + C_in * LD;  // [128][MAXCO]
     const int tile = blockIdx.x % ntiles;
     const int b = blockIdx.x / ntiles;
     const int t0 = tile * 128;
@@ -235,28 +235,30 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     const int tl = threadIdx.x & 127;
     const int half = threadIdx.x >> 7;
     const int c_lo = half * (C_in >> 1), c_hi = c_lo + (C_in >> 1);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[MAXCO];
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) acc[co] = 0.f;
     for (int ci = c_lo; ci < c_hi; ++ci) {
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             const float xv = xs[ci * LD + tl + k];
 #pragma unroll
-            for (int co = 0; co < 4; ++co)
+            for (int co = 0; co < MAXCO; ++co)
                 if (co < C_out) acc[co] = fmaf(w[((size_t)co * C_in + ci) * KT + k], xv, acc[co]);
         }
     }
     if (half == 1) {
 #pragma unroll
-        for (int co = 0; co < 4; ++co) part[tl * 4 + co] = acc[co];
+        for (int co = 0; co < MAXCO; ++co) part[tl * MAXCO + co] = acc[co];
     }
     __syncthreads();
     if (half == 0) {
         const int t = t0 + tl;
         if (t < T) {
 #pragma unroll
-            for (int co = 0; co < 4; ++co) {
+            for (int co = 0; co < MAXCO; ++co) {
                 if (co >= C_out) break;
-                float v = acc[co] + part[tl * 4 + co] + (bias ? bias[co] : 0.f);
+                float v = acc[co] + part[tl * MAXCO + co] + (bias ? bias[co] : 0.f);
                 const size_t o = ((size_t)b * C_out + co) * T + t;
                 if (c_out) v = v * c_out[b] + c_skip[b] * skip_src[o];
                 y[o] = v;
@@ -272,13 +274,14 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
     if (!x || !w || !y) return TQ_ERR_ARG;
     if ((gscale == nullptr) != (gshift == nullptr)) return TQ_ERR_ARG;
     if (c_out && (!c_skip || !skip_src)) return TQ_ERR_ARG;
-    if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || C_out < 1 || C_out > 4) return TQ_ERR_SHAPE;
+    if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || C_out < 1 || C_out > 16) return TQ_ERR_SHAPE;
     const int ntiles = (T + 127) / 128;
-    const size_t sh = ((size_t)C_in * (128 + ktaps) + 128 * 4) * sizeof(float);
+    const int maxco = C_out <= 4 ? 4 : 16;
+    const size_t sh = ((size_t)C_in * (128 + ktaps) + 128 * maxco) * sizeof(float);
     if (sh > 160 * 1024) return TQ_ERR_SHAPE;
 #define TQ_HEAD(K)                                                                                          \
     {                                                                                                       \
-        auto kern = head_conv_kernel<K>;                                                                    \
+        auto kern = (maxco == 4) ? head_conv_kernel<K, 4> : head_conv_kernel<K, 16>;                        \
         if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL(kern, dim3(B * ntiles), dim3(256), sh, stream, x, gscale, gshift, w, bias, c_out, c_skip, skip_src, y, T, C_in, C_out, ntiles); \
     }

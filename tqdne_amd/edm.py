@@ -189,8 +189,10 @@ class LightningEDM(LightningModule):
         if self.autoencoder:
             if cond_sample is not None:
                 cond_sample = self.autoencoder.encode(cond_sample)
-            dummy = th.zeros(shape, device=self.device)
-            shape = self.autoencoder.encode(dummy).shape
+            # the reference encodes a zeros tensor just to learn the latent shape (edm.py:154-157); the shape is known
+            # in closed form, so the wasted encoder pass is skipped
+            enc = self.autoencoder.encoder
+            shape = (shape[0], enc.out_channels // 2, shape[2] // enc.time_scale)
         # schedule built on the host in fp32 exactly like the reference's CPU path, then moved (pow differs by ulps on device)
         sigmas = self.edm.sampling_sigmas(self.num_sampling_steps).to(self.device)
         eps = th.randn(shape, device=self.device, dtype=dtype) * sigmas[0]

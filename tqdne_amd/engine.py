@@ -102,7 +102,7 @@ class UNetEngine:
         self.lib = _lib.load()
         self.m = model
         self.B, self.T, self.dev = B, T, device
-        self.E = 4 * model.model_channels
+        self.E = 4 * getattr(model, "model_channels", 0)
         self._keep = []          # ctypes structs / tensors referenced by raw pointers
         self.ops: List[Tuple] = []
         self.conv_sites: List[ConvSite] = []
@@ -413,3 +413,69 @@ class UNetEngine:
         if self._bwd is None:
             self._bwd = BackwardPlan(self)
         return self._bwd.run(dpred, gloss)
+
+
+class SeqEngine(UNetEngine):
+    """Plan for the VAE Encoder / Decoder (blocks.py:263-436): NCW stem conv -> sequence of un-conditioned ResBlocks /
+    attention / down / up blocks -> output conv -> NCW.  Reuses the UNet plan's op builders (no embedding, no skip stack)."""
+
+    def _build(self):
+        m, B, T = self.m, self.B, self.T
+        self.res_blocks, self.emb_offsets, self.emb_total = [], {}, 0
+        self._site_counter = 0
+        stem = m.input_layer
+        if stem.in_channels > 16:
+            raise NotImplementedError("input layer with more than 16 channels")
+        self.stem_out = self._act(stem.out_channels, T, True)
+        h = self.stem_out
+        blocks = getattr(m, m.blocks_attr)
+        for li, layer in enumerate(blocks):
+            kind = getattr(layer, "kind", None)
+            pfx = f"{m.blocks_attr}.{li}"
+            if kind == "res":
+                h = self._res_block(h, layer, pfx)
+            elif kind == "attn":
+                h = self._attention(h, layer, pfx)
+            elif kind == "down":
+                x_in = h
+                h = self._conv([h], self._site(pfx + ".op", layer.op), stride=2)
+                self.tape.append(("down", dict(x=x_in, out=h, rec=self.last_rec)))
+            elif kind == "up":
+                x_in = h
+                h = self._conv([h], self._site(pfx + ".conv", layer.conv), upsample=True)
+                self.tape.append(("up", dict(x=x_in, out=h, rec=self.last_rec)))
+            else:
+                raise RuntimeError(f"unexpected layer {type(layer)}")
+        self.final = h
+        out = m.output_layer
+        self.out_nct = self._empty(B, out.out_channels, h.T)
+        if out.out_channels <= 16:
+            self.out_mode = "head"
+        else:  # wide output (encoder: 2 x latent channels): fused conv to channels-last, then a layout flip
+            self.out_mode = "conv"
+            self.out_btc = self._conv([h], self._site("output_layer", out), stats=False)
+
+    def forward(self, x):
+        m, lib, B, T = self.m, self.lib, self.B, self.T
+        if tuple(x.shape) != (B, m.in_channels, T):
+            raise ValueError(f"plan was built for {(B, m.in_channels, T)}, got {tuple(x.shape)}")
+        x = x.contiguous()
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.repack(stream)
+        for d in self.dropout_descs:
+            d.flags &= ~TQ_CONV_DROPOUT
+        stem = m.input_layer
+        check(lib.tq_stem_conv_fwd(_p(x), None, _p(stem.weight), _p(stem.bias), _p(self.stem_out.buf), _p(self.stem_out.stats), B,
+                                   m.in_channels, T, stem.out_channels, stem.kernel_size[0], stream), "input layer")
+        for fn, args, what, _ in self.ops:
+            rc = fn(*args, stream)
+            if rc:
+                check(rc, what)
+        out = m.output_layer
+        if self.out_mode == "head":
+            check(lib.tq_head_conv_fwd(_p(self.final.buf), None, None, _p(out.weight), _p(out.bias), None, None, None,
+                                       _p(self.out_nct), B, self.final.T, self.final.C, out.out_channels, out.kernel_size[0],
+                                       stream), "output layer")
+        else:
+            self.out_nct.copy_(self.out_btc.buf.permute(0, 2, 1))  # (B,T,C) -> (B,C,T): 1/60 of the encoder's traffic
+        return self.out_nct
