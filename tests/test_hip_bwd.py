@@ -209,7 +209,7 @@ def test_stem_and_head_backward():
 
 
 def test_dropout_forward_backward_consistency():
-    """the mask regenerated in dgrad/wgrad equals the forward mask: finite-difference-free check via linearity"""
+    """the mask regenerated in dgrad/wgrad equals the forward mask"""
     from tqdne_amd import ops
     g = torch.Generator().manual_seed(4)
     d = dev()
@@ -217,18 +217,19 @@ def test_dropout_forward_backward_consistency():
     x = torch.randn(B, C, T, generator=g)
     w = torch.randn(C, C, 5, generator=g) / 18
     dy = torch.randn(B, C, T, generator=g)
-    kw = dict(dropout_p=0.25, dropout_seed=99, dropout_site=7)
+    kw = dict(silu=True, dropout_p=0.25, dropout_seed=99, dropout_site=7)
     ones, zeros = torch.ones(B, C, device=d), torch.zeros(B, C, device=d)
     eye = torch.zeros(C, C, 1); eye[torch.arange(C), torch.arange(C), 0] = 1
-    mask = ncw(ops.conv1d(torch.ones(B, T, C, device=d), eye.to(d), None, **kw)[0])  # mask/(1-p)
+    big = torch.full((B, T, C), 30.0, device=d)  # silu(30) == 30 in fp32: the identity conv returns 30 * mask / (1-p)
+    mask = ncw(ops.conv1d(big, eye.to(d), None, gscale=ones, gshift=zeros, **kw)[0]) / 30.0
     y, _ = ops.conv1d(cl(x), w.to(d), None, gscale=ones, gshift=zeros, **kw)
-    xm = (x * mask).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
     wr = w.clone().requires_grad_(True)
-    yr = F.conv1d(xm, wr, None, padding=2)
+    yr = F.conv1d(F.silu(xr) * mask, wr, None, padding=2)
     assert rel_err(ncw(y), yr) < TOL
     yr.backward(dy)
     g0, _, _ = ops.conv1d_bwd_data(cl(dy), w.to(d), x0=cl(x), gscale=ones, gshift=zeros, **kw)
-    assert rel_err(ncw(g0), xm.grad * mask) < TOL
+    assert rel_err(ncw(g0), xr.grad) < TOL
     dw = ops.conv1d_bwd_weight(cl(dy), cl(x), w.shape, gscale=ones, gshift=zeros, **kw)
     assert rel_err(dw.cpu(), wr.grad) < TOL
 

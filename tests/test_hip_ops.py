@@ -196,13 +196,16 @@ def test_dropout_mask_statistics_and_determinism():
     d = dev()
     B, C, T = 2, 64, 1024
     x = torch.ones(B, T, C, device=d)
+    ones, zeros = torch.ones(B, C, device=d), torch.zeros(B, C, device=d)
     w = torch.zeros(C, C, 1)
-    w[torch.arange(C), torch.arange(C), 0] = 1.0  # identity 1x1 conv exposes the mask
-    y1, _ = ops.conv1d(x, w.to(d), None, dropout_p=0.1, dropout_seed=42, dropout_site=3)
-    y2, _ = ops.conv1d(x, w.to(d), None, dropout_p=0.1, dropout_seed=42, dropout_site=3)
-    y3, _ = ops.conv1d(x, w.to(d), None, dropout_p=0.1, dropout_seed=43, dropout_site=3)
+    w[torch.arange(C), torch.arange(C), 0] = 1.0  # identity 1x1 conv exposes silu(1) * mask / (1-p)
+    kw = dict(gscale=ones, gshift=zeros, silu=True, dropout_p=0.1, dropout_site=3)
+    y1, _ = ops.conv1d(x, w.to(d), None, dropout_seed=42, **kw)
+    y2, _ = ops.conv1d(x, w.to(d), None, dropout_seed=42, **kw)
+    y3, _ = ops.conv1d(x, w.to(d), None, dropout_seed=43, **kw)
     assert torch.equal(y1, y2) and not torch.equal(y1, y3)
     keep = (y1 != 0).float().mean().item()
     assert abs(keep - 0.9) < 0.01
     vals = torch.unique(y1)
-    assert len(vals) == 2 and abs(vals.max().item() - 1 / 0.9) < 1e-4
+    silu1 = float(torch.nn.functional.silu(torch.tensor(1.0)))
+    assert len(vals) == 2 and abs(vals.max().item() - silu1 / 0.9) < 1e-4

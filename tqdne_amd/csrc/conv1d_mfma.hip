@@ -27,6 +27,23 @@
 
 using namespace tq;
 
+#ifdef TQ_STAMP
+// diagnostic build only: per-phase wave-cycle sums (never compiled into the shipped library)
+__device__ unsigned long long tq_stamps[8];
+extern "C" int tq_debug_read_stamps(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tq_stamps), sizeof(unsigned long long) * 8);
+    if (e != hipSuccess) return (int)e;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(tq_stamps), z, sizeof(z));
+    }
+    return (int)e;
+}
+#define TQ_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define TQ_T(x)
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -65,13 +82,16 @@ struct Cfg {
     static constexpr int NIT = (ROWS * 8 + NTHR - 1) / NTHR;
     static constexpr int PRE = NIT < 5 ? NIT : 5;  // staging iterations prefetched into registers across the MFMA phase
     static constexpr int SYNC_BATCH = 4;           // the rest is loaded+written synchronously in batches
-    static constexpr int PLANE = ROWS * 64;       // bytes per hi (or lo) plane
+    static constexpr int ITERS = (NIT <= PRE) ? NIT : PRE + ((NIT - PRE + SYNC_BATCH - 1) / SYNC_BATCH) * SYNC_BATCH;
+    static constexpr int ROWS_PAD = (ITERS * NTHR + 7) / 8;  // every staging task lands in-bounds: no predicate
+    static constexpr int PLANE = (ROWS_PAD > ROWS ? ROWS_PAD : ROWS) * 64;  // bytes per hi (or lo) plane
     static constexpr int BUF = 2 * PLANE;         // hi + lo
     static constexpr int LDS_BYTES = 2 * BUF;     // double buffered
     static constexpr int PAD = (STRIDE == 1) ? (KT / 2) : 1;
 };
 
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI>
+// ACT (compile time): prologue applied while staging -- 0 none, 1 folded GN, 2 GN + SiLU, 3 GN + SiLU + dropout
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -130,40 +150,47 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         return *reinterpret_cast<const float4*>(base + (size_t)srow * cs);
     };
 
+    // transform + split + LDS store of one staged float4: ~12 VALU per element, no branches (rows past the tile go to padding
+    // rows of the LDS image; rows outside the signal are multiplied by 0 = the conv's zero padding of the ACTIVATED input)
     auto write_one = [&](int chunk, int buf, int it, const float4& rv) __attribute__((always_inline)) {
         unsigned char* hi_plane = lds + buf * C::BUF;
         unsigned char* lo_plane = hi_plane + C::PLANE;
-        const int cb = chunk << 5;
         const int i = (tid + it * C::NTHR) >> 3;
-        if (i >= C::ROWS) return;
         const int pos = src_pos(i);
-        const bool inside = (pos >= 0 && pos < T_src);
-        float u[4] = {inside ? rv.x : 0.f, inside ? rv.y : 0.f, inside ? rv.z : 0.f, inside ? rv.w : 0.f};
-        if (inside) {
-            if (p.flags & TQ_CONV_GN) {
-                u[0] = g_a.x * u[0] + g_s.x; u[1] = g_a.y * u[1] + g_s.y;
-                u[2] = g_a.z * u[2] + g_s.z; u[3] = g_a.w * u[3] + g_s.w;
-            }
-            if (p.flags & TQ_CONV_SILU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) u[j] = silu_f(u[j]);
-            }
-            if (p.flags & TQ_CONV_DROPOUT) {
-                const uint64_t e0 = ((uint64_t)b * T_src + pos) * Cin + cb + 4 * m;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    u[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? u[j] * p.drop_scale : 0.f;
-            }
+        const float msk = (pos >= 0 && pos < T_src) ? 1.f : 0.f;
+        float u[4] = {rv.x, rv.y, rv.z, rv.w};
+        if (ACT >= 1) {
+            u[0] = fmaf(g_a.x, u[0], g_s.x); u[1] = fmaf(g_a.y, u[1], g_s.y);
+            u[2] = fmaf(g_a.z, u[2], g_s.z); u[3] = fmaf(g_a.w, u[3], g_s.w);
         }
-        bf16x4 h, l;
+        if (ACT >= 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)  // u * sigmoid(u) = u / (1 + 2^(-u*log2 e)): v_mul, v_exp, v_add, v_rcp, v_mul
+                u[j] = u[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[j] * -1.4426950408889634f));
+        }
+        if (ACT == 3) {
+            const int cb = chunk << 5;
+            const int pc = pos < 0 ? 0 : pos;
+            const uint64_t e0 = ((uint64_t)b * T_src + pc) * Cin + cb + 4 * m;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                u[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? u[j] * p.drop_scale : 0.f;
+        }
+        uint32_t hb[4];
+        float lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __bf16 hh, ll;
-            split_bf16(u[j], hh, ll);
-            h[j] = hh; l[j] = ll;
+            u[j] *= msk;
+            hb[j] = __float_as_uint(u[j]) & 0xFFFF0000u;  // hi = x truncated to bf16; lo (rounded) carries the remainder
+            lo[j] = u[j] - __uint_as_float(hb[j]);
         }
+        uint2 hv;
+        hv.x = (hb[0] >> 16) | hb[1];
+        hv.y = (hb[2] >> 16) | hb[3];
+        bf16x4 l;
+        l[0] = (__bf16)lo[0]; l[1] = (__bf16)lo[1]; l[2] = (__bf16)lo[2]; l[3] = (__bf16)lo[3];
         const int off = i * 64 + ((wslot ^ (((i >> 2) & 1) << 1)) << 4) + (whalf << 3);
-        *reinterpret_cast<bf16x4*>(hi_plane + off) = h;
+        *reinterpret_cast<uint2*>(hi_plane + off) = hv;
         *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
     };
 
@@ -173,13 +200,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         const float* base = chunk_base(chunk, cs);
 #pragma unroll
         for (int it = 0; it < C::PRE; ++it) raw[it] = load_one(base, cs, it);
-        {   // folded GroupNorm coefficients of this thread's 4 channels (loaded unconditionally: no branch; unused without GN)
+        if (ACT >= 1) {  // folded GroupNorm coefficients of this thread's 4 channels
             const int cb = chunk << 5;
-            const bool gn = (p.flags & TQ_CONV_GN) != 0;
-            const float* ga = gn ? p.gscale + (size_t)b * Cin + cb + 4 * m : base;
-            const float* gs = gn ? p.gshift + (size_t)b * Cin + cb + 4 * m : base;
-            g_a = *reinterpret_cast<const float4*>(ga);
-            g_s = *reinterpret_cast<const float4*>(gs);
+            g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
+            g_s = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cb + 4 * m);
         }
     };
 
@@ -289,17 +313,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     }
     stage_write(0, 0);
     __syncthreads();
+#ifdef TQ_STAMP
+    unsigned long long s_load = 0, s_mma = 0, s_write = 0, s_bar = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int c = 0; c + 1 < nchunks; ++c) {
+        TQ_T(tA)
 #ifndef TQ_ABL_NOSTAGE
         stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
 #endif
+        TQ_T(tB)
         if (wave_active) compute(c, c & 1);
+        TQ_T(tC)
 #ifndef TQ_ABL_NOSTAGE
         stage_write(c + 1, (c + 1) & 1);
 #endif
+        TQ_T(tD)
         __syncthreads();
+        TQ_T(tE)
+#ifdef TQ_STAMP
+        s_load += tB - tA; s_mma += tC - tB; s_write += tD - tC; s_bar += tE - tD;
+#endif
     }
     if (wave_active) compute(nchunks - 1, (nchunks - 1) & 1);
+#ifdef TQ_STAMP
+    if (lane == 0) {
+        const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+        atomicAdd(&tq_stamps[0], s_load); atomicAdd(&tq_stamps[1], s_mma); atomicAdd(&tq_stamps[2], s_write);
+        atomicAdd(&tq_stamps[3], s_bar); atomicAdd(&tq_stamps[4], t_loop - t_begin); atomicAdd(&tq_stamps[5], 1ull);
+    }
+#endif
 
     // ---- epilogue
     if (!wave_active) return;
@@ -416,10 +459,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     }
 }
 
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT>
 int launch(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN>;
-    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -435,21 +478,32 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <int KT, int STRIDE, int UPS, int EPI = 0>
+template <int KT, int STRIDE, int UPS, int EPI, int ACT>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     // pointwise convs are staging-bound (one tap of MFMA work per staged chunk): an 8-wave workgroup covering 256 output
     // channels stages each input tile once instead of twice (measured -32 % on 512->256, neutral for k = 5)
     if constexpr (KT == 1 && STRIDE == 1 && UPS == 0) {
-        if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI>(a, s);
+        if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT>(a, s);
     }
-    if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI>(a, s);
+    if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT>(a, s);
     if constexpr (STRIDE == 1) {
-        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI>(a, s);
-        return launch<KT, STRIDE, UPS, 1, 2, EPI>(a, s);
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 2, EPI, ACT>(a, s);
     } else {
-        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1, EPI>(a, s);
-        return launch<KT, STRIDE, UPS, 1, 1, EPI>(a, s);
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1, EPI, ACT>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 1, EPI, ACT>(a, s);
     }
+}
+
+// forward prologue variants; strided / upsampled convs and data gradients only exist un-activated in the networks served
+template <int KT>
+int dispatch_act(const ConvArgs& a, hipStream_t s) {
+    const bool gn = a.flags & TQ_CONV_GN, silu = a.flags & TQ_CONV_SILU, drop = a.flags & TQ_CONV_DROPOUT;
+    if ((!gn && silu) || (drop && !silu)) return TQ_ERR_ARG;  // supported prologues: none | GN | GN+SiLU | GN+SiLU+dropout
+    if (gn && silu && drop) return dispatch_tile<KT, 1, 0, 0, 3>(a, s);
+    if (gn && silu) return dispatch_tile<KT, 1, 0, 0, 2>(a, s);
+    if (gn) return dispatch_tile<KT, 1, 0, 0, 1>(a, s);
+    return dispatch_tile<KT, 1, 0, 0, 0>(a, s);
 }
 
 }  // namespace
@@ -498,16 +552,17 @@ extern "C" int tq_conv1d_fwd(const TqConvDesc* d, const float* x0, const float* 
     a.drop_scale = 1.0f / (1.0f - pdrop);
     a.fx0 = a.fx1 = a.fgs = a.fgh = nullptr; a.y1 = nullptr; a.OC0 = d->C_out; a.bflags = 0;
 
-    if (d->stride == 2) return dispatch_tile<3, 2, 0>(a, stream);
-    if (d->upsample) {
-        if (d->ktaps == 5) return dispatch_tile<5, 1, 1>(a, stream);
-        if (d->ktaps == 3) return dispatch_tile<3, 1, 1>(a, stream);
+    if (d->stride == 2 || d->upsample) {
+        if (a.flags & (TQ_CONV_GN | TQ_CONV_SILU | TQ_CONV_DROPOUT)) return TQ_ERR_SHAPE;  // resampling convs take raw inputs
+        if (d->stride == 2) return dispatch_tile<3, 2, 0, 0, 0>(a, stream);
+        if (d->ktaps == 5) return dispatch_tile<5, 1, 1, 0, 0>(a, stream);
+        if (d->ktaps == 3) return dispatch_tile<3, 1, 1, 0, 0>(a, stream);
         return TQ_ERR_SHAPE;
     }
     switch (d->ktaps) {
-        case 1: return dispatch_tile<1, 1, 0>(a, stream);
-        case 3: return dispatch_tile<3, 1, 0>(a, stream);
-        case 5: return dispatch_tile<5, 1, 0>(a, stream);
+        case 1: return dispatch_act<1>(a, stream);
+        case 3: return dispatch_act<3>(a, stream);
+        case 5: return dispatch_act<5>(a, stream);
         default: return TQ_ERR_SHAPE;
     }
 }
@@ -544,9 +599,9 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.drop_scale = 1.0f / (1.0f - pdrop);
     a.fx0 = x0; a.fx1 = x1; a.fgs = gscale; a.fgh = gshift; a.y1 = dx1; a.OC0 = d->C_dx0;
     switch (d->ktaps) {
-        case 1: return dispatch_tile<1, 1, 0, 1>(a, stream);
-        case 3: return dispatch_tile<3, 1, 0, 1>(a, stream);
-        default: return dispatch_tile<5, 1, 0, 1>(a, stream);
+        case 1: return dispatch_tile<1, 1, 0, 1, 0>(a, stream);
+        case 3: return dispatch_tile<3, 1, 0, 1, 0>(a, stream);
+        default: return dispatch_tile<5, 1, 0, 1, 0>(a, stream);
     }
 }
 
