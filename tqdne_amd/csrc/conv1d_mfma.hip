@@ -194,6 +194,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
     };
 
+    auto stage_hosted = [](int it) constexpr -> bool {
+#ifdef TQ_INTERLEAVE
+        return (KT == 5 || KT == 3) && it >= 0;
+#else
+        (void)it;
+        return false;
+#endif
+    };
     // phase 1 (before the MFMAs of the previous chunk): issue the first PRE iterations' loads
     auto stage_load = [&](int chunk) __attribute__((always_inline)) {
         int cs;
@@ -208,9 +216,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     };
 
     // phase 2 (after them): transform + LDS write; iterations beyond PRE are loaded here in small batches
-    auto stage_write = [&](int chunk, int buf) __attribute__((always_inline)) {
+    auto stage_write = [&](int chunk, int buf, bool hosted_done) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < C::PRE; ++it) write_one(chunk, buf, it, raw[it]);
+        for (int it = 0; it < C::PRE; ++it)
+            if (!(hosted_done && stage_hosted(it))) write_one(chunk, buf, it, raw[it]);
         if (C::NIT > C::PRE) {
             int cs;
             const float* base = chunk_base(chunk, cs);
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     };
 
     auto mma_tap = [&](int k, const unsigned char* hi_plane, const unsigned char* lo_plane, const Frag (&ah)[2],
-                       const Frag (&al)[2]) __attribute__((always_inline)) {
+                       const Frag (&al)[2], int nv) __attribute__((always_inline)) {
         // LDS image: row = 64 B = 4 slots of 16 B (one k-quarter each), slot' = kq ^ (2 * ((row >> 2) & 1)): conflict-free for
         // ds_read_b128 at every row offset (tap shift) and for the 8-byte staging stores.  Row of t-block tb is rowk + 16*tb,
         // which leaves the swizzle term unchanged: one address per tap, t-blocks are immediate offsets.
@@ -279,26 +288,66 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
             if (tb + 1 < 8) read_b(hi_plane, lo_plane, b0, tb + 1, bh[(tb + 1) & 1], bl[(tb + 1) & 1]);
+#ifndef TQ_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
                 acc[cbk][tb] = mfma_x3(ah[cbk].v, al[cbk].v, bh[tb & 1].v, bl[tb & 1].v, acc[cbk][tb]);
+#ifndef TQ_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#ifdef TQ_INTERLEAVE
+        // issue order inside the tap: fragment reads one t-block ahead, and after every MFMA up to `nv` VALU instructions of
+        // the staging transform hosted by this tap (they issue in the shadow of the 16-cycle MFMA instead of after the phase)
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int tb = 0; tb < 8; ++tb) {
+            if (tb + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (nv == 1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                else if (nv == 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                else if (nv >= 3) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+        }
+#else
+        (void)nv;
+#endif
     };
 
     // Weight fragments live in two register buffers (taps alternate a, b, a, ...); after tap k its buffer is refilled with
     // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
     // b = tap 1 already in flight.
     Frag wa_h[2], wa_l[2], wb_h[2], wb_l[2];
-    auto compute = [&](int chunk, int buf) __attribute__((always_inline)) {
+    // tap of the current chunk whose MFMAs host the transform of staging iteration `it` of the NEXT chunk (TQ_INTERLEAVE);
+    // the global loads of those iterations are issued right before tap 0, so the first tap(s) are left for them to land
+    auto stage_tap = [](int it) constexpr -> int {
+#ifdef TQ_INTERLEAVE
+        return KT == 5 ? (it < 2 ? 2 : (it < 4 ? 3 : 4)) : (KT == 3 ? (it < 2 ? 1 : 2) : -1);
+#else
+        (void)it;
+        return -1;
+#endif
+    };
+    auto compute = [&](int chunk, int buf, bool stage_next) __attribute__((always_inline)) {
         const unsigned char* hi_plane = lds + buf * C::BUF;
         const unsigned char* lo_plane = hi_plane + C::PLANE;
         const int s0 = chunk * KT;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            if (k & 1) mma_tap(k, hi_plane, lo_plane, wb_h, wb_l);
-            else       mma_tap(k, hi_plane, lo_plane, wa_h, wa_l);
+            int nhost = 0;
+#pragma unroll
+            for (int it = 0; it < C::PRE; ++it)
+                if (stage_tap(it) == k) {
+                    ++nhost;
+                    if (stage_next) write_one(chunk + 1, buf ^ 1, it, raw[it]);
+                }
+            const int nv = (nhost * 56 + 47) / 48;
+            if (k & 1) mma_tap(k, hi_plane, lo_plane, wb_h, wb_l, nv);
+            else       mma_tap(k, hi_plane, lo_plane, wa_h, wa_l, nv);
             const int nxt = (KT == 1) ? (s0 + 1) : ((k + 2 < KT) ? (s0 + k + 2) : ((k & 1) ? (s0 + KT + 1) : (s0 + KT)));
             if (k & 1) load_w(nxt, wb_h, wb_l); else load_w(nxt, wa_h, wa_l);
             __builtin_amdgcn_sched_barrier(0);
@@ -311,7 +360,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         load_w(0, wa_h, wa_l);
         if (KT > 1) load_w(1, wb_h, wb_l);
     }
-    stage_write(0, 0);
+    stage_write(0, 0, false);
     __syncthreads();
 #ifdef TQ_STAMP
     unsigned long long s_load = 0, s_mma = 0, s_write = 0, s_bar = 0;
@@ -323,10 +372,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
 #endif
         TQ_T(tB)
-        if (wave_active) compute(c, c & 1);
+        if (wave_active) compute(c, c & 1, true);
         TQ_T(tC)
 #ifndef TQ_ABL_NOSTAGE
-        stage_write(c + 1, (c + 1) & 1);
+        stage_write(c + 1, (c + 1) & 1, wave_active);
 #endif
         TQ_T(tD)
         __syncthreads();
@@ -335,7 +384,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         s_load += tB - tA; s_mma += tC - tB; s_write += tD - tC; s_bar += tE - tD;
 #endif
     }
-    if (wave_active) compute(nchunks - 1, (nchunks - 1) & 1);
+    if (wave_active) compute(nchunks - 1, (nchunks - 1) & 1, false);
 #ifdef TQ_STAMP
     if (lane == 0) {
         const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
