@@ -127,9 +127,10 @@ int tq_gn_bwd_finalize(const float* gstats_partial, const float* mean_rstd, cons
 int tq_gn_bwd_apply(const float* g, const float* x, const float* r, const float* coef_a, const float* coef_b,
                     const float* coef_c, float* dx, int B, int T, int C_src, int C_total, int c_offset, int accumulate,
                     hipStream_t stream);
-/* out_bc[b*bc_stride + c] += bscale[b] * sum_t dy[b,t,c];  out_c[c] += sum_{b,t} (...)   (bias / embedding gradients) */
-int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, const float* bscale,
-              hipStream_t stream);
+/* out_bc[b*bc_stride + c] += bscale[b] * sum_t dy[b,t,c];  out_c[c], out_c2[c] += sum_{b,t} (...)  (each optional; bias and
+ * embedding gradients: two biases fed by the same tensor are served by one pass) */
+int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, float* out_c2,
+              const float* bscale, hipStream_t stream);
 /* gradient plumbing of the strided / upsampled convs: out[b,u,:] = (u even) ? dy[b,u/2,:] : 0 for u < T_in;
  * dx[b,t,:] (+)= d_up[b,2t,:] + d_up[b,2t+1,:] */
 int tq_zero_stuff(const float* dy, float* out, int B, int T_out, int T_in, int C, hipStream_t stream);

@@ -250,3 +250,34 @@ def test_latent_edm_pipeline_vs_oracle():
     print("latent pipeline encode / latent sample / decode:", " ".join(f"{v:.2e}" for v in e))
     assert max(e) < TOL
     assert edm.sample((B, 3, T), cond=cond.to(dev())).shape == (B, 3, T)
+
+
+def test_trainer_step_matches_autograd_path():
+    """DataParallelTrainer's fused step (no autograd) produces the same loss / gradients as loss.backward()."""
+    from tqdne_amd import LightningEDM
+    from tqdne_amd.trainer import DataParallelTrainer
+    sd, _ = load_golden("micro_unet.npz")
+    _, d = load_golden("micro_edm.npz")
+    edm = LightningEDM(cfg_of(d), {"learning_rate": 1e-3, "max_steps": 10, "eta_min": 0.0})
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev()).train()
+    sig, cond = torch.from_numpy(d["signal"]).to(dev()), torch.from_numpy(d["cond"]).to(dev())
+    eps, noise = torch.from_numpy(d["step:eps"]).to(dev()), torch.from_numpy(d["step:noise"]).to(dev())
+    loss = edm.step_with_noise(sig, eps, noise, cond=cond)
+    loss.backward()
+    ref = {n: p.grad.clone() for n, p in edm.unet.named_parameters() if p.grad is not None}
+    for p in edm.parameters():
+        p.grad = None
+    from tqdne_amd.autograd import edm_loss_and_grads
+    loss2, flat = edm_loss_and_grads(edm, sig, eps, noise, cond)
+    assert rel_err(loss2.cpu(), loss.detach().cpu()) < 1e-6
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    for n, p in edm.unet.named_parameters():
+        if n in ref:  # (biases in front of a one-channel-per-group GroupNorm have an exactly-zero gradient: rounding noise)
+            err = float((p.grad - ref[n]).abs().max()) / max(float(ref[n].abs().max()), 1e-3 * gmax)
+            assert err < 1e-4, (n, err)
+    before = {n: p.detach().clone() for n, p in edm.unet.named_parameters()}
+    tr = DataParallelTrainer(edm, world_size=1)
+    tr.train_step({"signal": sig, "cond": cond})
+    changed = sum(int(not torch.equal(before[n], p.detach())) for n, p in edm.unet.named_parameters() if p.requires_grad)
+    assert changed > 100

@@ -65,7 +65,7 @@ _PROTOS = {
     "tq_conv1d_bwd_weight": (I, [VP] * 8 + [SZ, VP]),
     "tq_gn_bwd_finalize": (I, [VP, VP, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
     "tq_gn_bwd_apply": (I, [VP] * 7 + [I] * 6 + [VP]),
-    "tq_colsum": (I, [VP, I, I, I, VP, I, VP, VP, VP]),
+    "tq_colsum": (I, [VP, I, I, I, VP, I, VP, VP, VP, VP]),
     "tq_zero_stuff": (I, [VP, VP, I, I, I, I, VP]),
     "tq_pair_sum": (I, [VP, VP, I, I, I, I, VP]),
     "tq_stem_conv_bwd_weight": (I, [VP] * 4 + [I] * 5 + [VP]),

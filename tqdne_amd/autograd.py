@@ -58,6 +58,29 @@ class _EDMLossFn(th.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
+def edm_loss_and_grads(module, sample, eps, unit_noise, cond):
+    """Fused training step without the autograd round trip: runs the HIP forward and backward back to back and leaves the
+    gradients in the backward plan's flat buffer; ``p.grad`` of every UNet parameter is (re)bound to its view of that buffer.
+    Returns (loss, flat_gradient_buffer).  Used by DataParallelTrainer (one all-reduce over the flat buffer, no per-parameter
+    accumulation kernels)."""
+    params = list(module.unet.parameters())
+    with th.no_grad():
+        loss = _EDMLossFn.forward(_Ctx, module, sample, eps, unit_noise, cond, *params)
+        bufs = _Ctx.bufs
+        B, _, T = _Ctx.shape
+        eng = module.unet._engine(B, T, bufs["x"].device)
+        one = th.ones((), device=bufs["x"].device)
+        grads = eng.backward(bufs["dpred"], one, clone=False)
+        for p, g in zip(params, grads):
+            if g is not None and (p.grad is None or p.grad.data_ptr() != g.data_ptr()):
+                p.grad = g
+    return loss, eng._bwd.flat
+
+
+class _Ctx:
+    """stand-in for the autograd context when the loss Function's forward is driven directly"""
+
+
 def edm_loss(module, sample, eps, unit_noise, cond):
     params = [p for p in module.unet.parameters()]
     return _EDMLossFn.apply(module, sample, eps, unit_noise, cond, *params)

@@ -407,7 +407,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ g, const float* __
 
 // out_bc[b*stride + c] += sum_t dy[b,t,c];  out_c[c] += sum_{b,t} dy   (both optional; atomics into zeroed buffers)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int T, int C, float* __restrict__ out_bc,
-                                                     int bc_stride, float* __restrict__ out_c, float scale_by_b,
+                                                     int bc_stride, float* __restrict__ out_c, float* __restrict__ out_c2,
                                                      const float* __restrict__ bscale) {
     extern __shared__ float red[];
     const int nsl = (T + STAT_SLOT - 1) / STAT_SLOT;
@@ -433,8 +433,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
         s *= sc;
         if (out_bc) atomicAdd(out_bc + (size_t)b * bc_stride + c, s);
         if (out_c) atomicAdd(out_c + c, s);
+        if (out_c2) atomicAdd(out_c2 + c, s);
     }
-    (void)scale_by_b;
 }
 
 __global__ void zero_stuff_kernel(const float* __restrict__ dy, float* __restrict__ out, int T_out, int T_in, int C, size_t n4) {
@@ -496,15 +496,15 @@ extern "C" int tq_gn_bwd_apply(const float* g, const float* x, const float* r, c
     return 0;
 }
 
-extern "C" int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c,
+extern "C" int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, float* out_c2,
                          const float* bscale, hipStream_t stream) {
-    if (!dy || (!out_bc && !out_c)) return TQ_ERR_ARG;
+    if (!dy || (!out_bc && !out_c && !out_c2)) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || C < 4 || C % 4 || C > 1024) return TQ_ERR_SHAPE;
     const int nsl = (T + STAT_SLOT - 1) / STAT_SLOT;
     const int c4n = C / 4;
     const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
     const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float);
-    hipLaunchKernelGGL(colsum_kernel, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, 0.f, bscale);
+    hipLaunchKernelGGL(colsum_kernel, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, out_c2, bscale);
     TQ_CHECK_LAUNCH();
     return 0;
 }
@@ -532,33 +532,55 @@ extern "C" int tq_pair_sum(const float* d_up, float* dx, int B, int T, int C, in
 namespace {
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ in_scale, float* __restrict__ dw,
-                                                         int C_in, int T, int C_out, int KT, int nslots) {
+                                                         int C_in, int T, int C_out, int KT, int nslots, int nunits, int upw) {
     extern __shared__ float shm[];
     const int PAD = KT / 2;
     const int TW = STAT_SLOT + KT - 1;
     float* xs = shm;                 // [C_in][TW]
     float* ds = xs + C_in * TW;      // [128][C_out + 1]
     const int LD = C_out + 1;
-    const int slot = blockIdx.x % nslots, b = blockIdx.x / nslots;
-    const int t0 = slot * STAT_SLOT;
-    const float sc = in_scale ? in_scale[b] : 1.0f;
-    for (int i = threadIdx.x; i < C_in * TW; i += 256) {
-        const int c = i / TW, j = i % TW;
-        const int t = t0 - PAD + j;
-        xs[i] = (t >= 0 && t < T) ? x[((size_t)b * C_in + c) * T + t] * sc : 0.f;
-    }
-    for (int i = threadIdx.x; i < STAT_SLOT * C_out; i += 256) {
-        const int tl = i / C_out, c = i % C_out;
-        ds[tl * LD + c] = (t0 + tl < T) ? dy[((size_t)b * T + t0 + tl) * C_out + c] : 0.f;
-    }
-    __syncthreads();
     const int nout = C_out * C_in * KT;
-    for (int o = threadIdx.x; o < nout; o += 256) {
-        const int co = o % C_out, r = o / C_out;
-        const int ci = r % C_in, k = r / C_in;
-        float a = 0.f;
-        for (int tl = 0; tl < STAT_SLOT; ++tl) a = fmaf(ds[tl * LD + co], xs[ci * TW + tl + k], a);
-        atomicAdd(dw + ((size_t)co * C_in + ci) * KT + k, a);
+    constexpr int MAXO = 8;          // outputs per thread held in registers (nout <= 2048)
+    float acc[MAXO];
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) acc[q] = 0.f;
+    const int u0 = blockIdx.x * upw;
+    const int u1 = min(nunits, u0 + upw);
+    for (int u = u0; u < u1; ++u) {
+        const int slot = u % nslots, b = u / nslots;
+        const int t0 = slot * STAT_SLOT;
+        const float sc = in_scale ? in_scale[b] : 1.0f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < C_in * TW; i += 256) {
+            const int c = i / TW, j = i % TW;
+            const int t = t0 - PAD + j;
+            xs[i] = (t >= 0 && t < T) ? x[((size_t)b * C_in + c) * T + t] * sc : 0.f;
+        }
+        for (int i = threadIdx.x; i < STAT_SLOT * C_out; i += 256) {
+            const int tl = i / C_out, c = i % C_out;
+            ds[tl * LD + c] = (t0 + tl < T) ? dy[((size_t)b * T + t0 + tl) * C_out + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MAXO; ++q) {
+            const int o = threadIdx.x + q * 256;
+            if (o < nout) {
+                const int co = o % C_out, r = o / C_out;
+                const int ci = r % C_in, k = r / C_in;
+                float a = 0.f;
+                for (int tl = 0; tl < STAT_SLOT; ++tl) a = fmaf(ds[tl * LD + co], xs[ci * TW + tl + k], a);
+                acc[q] += a;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) {
+        const int o = threadIdx.x + q * 256;
+        if (o < nout) {
+            const int co = o % C_out, r = o / C_out;
+            const int ci = r % C_in, k = r / C_in;
+            atomicAdd(dw + ((size_t)co * C_in + ci) * KT + k, acc[q]);
+        }
     }
 }
 
@@ -674,9 +696,14 @@ extern "C" int tq_stem_conv_bwd_weight(const float* dy, const float* x_nct, cons
     const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
     const size_t sh = ((size_t)C_in * (STAT_SLOT + ktaps - 1) + (size_t)STAT_SLOT * (C_out + 1)) * sizeof(float);
     if (sh > 160 * 1024) return TQ_ERR_SHAPE;
+    if (C_out * C_in * ktaps > 8 * 256) return TQ_ERR_SHAPE;
     auto kern = stem_wgrad_kernel;
     if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(kern, dim3(B * nslots), dim3(256), sh, stream, dy, x_nct, in_scale, dw, C_in, T, C_out, ktaps, nslots);
+    const int nunits = B * nslots;
+    const int nwg = nunits < 512 ? nunits : 512;
+    const int upw = (nunits + nwg - 1) / nwg;
+    hipLaunchKernelGGL(kern, dim3((nunits + upw - 1) / upw), dim3(256), sh, stream, dy, x_nct, in_scale, dw, C_in, T, C_out, ktaps,
+                       nslots, nunits, upw);
     TQ_CHECK_LAUNCH();
     return 0;
 }

@@ -171,6 +171,20 @@ class LightningEDM(LightningModule):
         from .autograd import edm_loss
         return edm_loss(self, sample.contiguous(), eps.contiguous().float(), unit_noise.contiguous(), cond)
 
+    def step_and_backward(self, batch):
+        """``step`` + backward in one call, gradients left in ``p.grad`` (views of one flat buffer, returned as well)."""
+        from .autograd import edm_loss_and_grads
+        sample = batch["signal"]
+        cond = batch["cond"] if "cond" in batch else None
+        if "cond_signal" in batch:
+            raise NotImplementedError("cond_signal goes through the autograd path (step)")
+        if self.autoencoder:
+            with th.no_grad():
+                sample = self.autoencoder.encode(sample)
+        eps = th.randn(sample.shape[0], device=sample.device)
+        unit_noise = th.randn_like(sample)
+        return edm_loss_and_grads(self, sample.contiguous(), eps, unit_noise, cond)
+
     def training_step(self, batch, batch_idx):
         loss = self.step(batch, batch_idx)
         self.log("training/loss", loss.item(), sync_dist=True)

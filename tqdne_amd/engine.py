@@ -407,12 +407,12 @@ class UNetEngine:
         return self.out_nct
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dpred: torch.Tensor, gloss: torch.Tensor, c_out=None, in_scale=None):
+    def backward(self, dpred: torch.Tensor, gloss: torch.Tensor, c_out=None, in_scale=None, clone: bool = True):
         """Gradients of every UNet parameter for d loss / d pred = gloss * dpred, for the last train-mode forward.
         Returns a list aligned with ``model.parameters()`` (None for frozen parameters)."""
         if self._bwd is None:
             self._bwd = BackwardPlan(self)
-        return self._bwd.run(dpred, gloss)
+        return self._bwd.run(dpred, gloss, clone=clone)
 
 
 class SeqEngine(UNetEngine):

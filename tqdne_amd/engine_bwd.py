@@ -100,7 +100,7 @@ class BackwardPlan:
         return self.gview[id(param)]
 
     # ------------------------------------------------------------------ emitters
-    def _wgrad(self, rec, dy):
+    def _wgrad(self, rec, dy, bias_colsum=True):
         lib, site = self.lib, rec.site
         need = lib.tq_conv1d_bwd_weight_workspace(C.byref(rec.desc))
         self.ws_bytes = max(getattr(self, "ws_bytes", 0), need)
@@ -110,8 +110,8 @@ class BackwardPlan:
         self.ops.append([lib.tq_conv1d_bwd_weight, [C.byref(rec.desc), _p(dy), _p(s0.buf), _p(s1.buf) if s1 else None,
                                                     _p(rec.gn[0]) if rec.gn else None, _p(rec.gn[1]) if rec.gn else None,
                                                     _p(self.g(site.weight)), None, 0], "wgrad:" + site.name])
-        if site.bias is not None:
-            self.ops.append([lib.tq_colsum, [_p(dy), self.B, rec.out.T, site.C_out, None, 0, _p(self.g(site.bias)), None],
+        if site.bias is not None and bias_colsum:
+            self.ops.append([lib.tq_colsum, [_p(dy), self.B, rec.out.T, site.C_out, None, 0, _p(self.g(site.bias)), None, None],
                              "colsum:" + site.name])
 
     def _dgrad(self, rec, dy, T, dsts, accumulate, chain=True, stats=True):
@@ -192,7 +192,7 @@ class BackwardPlan:
         assert so.gw
         self.stem_op = [lib.tq_stem_conv_bwd_weight, [_p(so.grad), None, None, _p(self.g(stem.weight)), B, m.in_channels, so.T,
                                                       stem.out_channels, stem.kernel_size[0]], "stem wgrad"]
-        self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None], "colsum:stem"])
+        self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None, None], "colsum:stem"])
         # shared workspace of the weight-gradient slabs
         self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=self.dev)
         for i in self._wgrad_ops:
@@ -205,20 +205,25 @@ class BackwardPlan:
         B, T, Co = self.B, out.T, out.C
         assert out.gw, "gradient of a block output must be complete before its backward"
         dout = out.grad
-        # conv2 (out_layers.3): weight grad, then data grad chained through dropout / SiLU / GN2
-        self._wgrad(rec2, dout)
+        # conv2 (out_layers.3): weight grad, then data grad chained through dropout / SiLU / GN2.  The bias gradients of conv2
+        # and of the 1x1 skip conv are the same column sums of d out: one pass
+        self._wgrad(rec2, dout, bias_colsum=False)
+        self.ops.append([self.lib.tq_colsum, [_p(dout), B, T, Co, None, 0, _p(self.g(rec2.site.bias)),
+                                              _p(self.g(rec_sk.site.bias)) if rec_sk is not None else None, None], "colsum:out"])
         G2 = self.scratch("G", T, Co)
         gst2 = self._dgrad(rec2, dout, T, [G2], accumulate=False)
         coef2 = self._gn_bwd(gst2, t["g2"], rb.out_layers[0], T, Co)
         h1.gw = False
         self._gn_apply(G2, h1, coef2, Co, 0)  # d h1  (= gradient of conv1's output and of the broadcast embedding)
         dh1 = h1.grad
+        # column sums of d h1: per-sample -> gradient of the broadcast time embedding; total -> bias of conv1
+        emb_dst = None
         if hasattr(rb, "emb_layers"):
-            off = self.e.emb_offsets[id(rb)]
-            self.ops.append([self.lib.tq_colsum, [_p(dh1), B, T, Co, self.demb_all.data_ptr() + 4 * off, self.e.emb_total, None, None],
-                             "colsum:emb"])
+            emb_dst = self.demb_all.data_ptr() + 4 * self.e.emb_offsets[id(rb)]
+        self.ops.append([self.lib.tq_colsum, [_p(dh1), B, T, Co, emb_dst, self.e.emb_total, _p(self.g(rec1.site.bias)), None, None],
+                         "colsum:h1"])
         # conv1 (in_layers.2)
-        self._wgrad(rec1, dh1)
+        self._wgrad(rec1, dh1, bias_colsum=False)
         Ctot = sum(s.C for s in srcs)
         G1 = [self.scratch("G1_%d" % i, T, s.C) for i, s in enumerate(srcs)]
         gst1 = self._dgrad(rec1, dh1, T, G1, accumulate=False)
@@ -227,7 +232,7 @@ class BackwardPlan:
         if rec_sk is None:
             self._gn_apply(G1[0], srcs[0], coef1, Ctot, 0, r=dout)
         else:
-            self._wgrad(rec_sk, dout)
+            self._wgrad(rec_sk, dout, bias_colsum=False)
             acc = srcs[0].gw
             assert all(s.gw == acc for s in srcs)
             self._dgrad(rec_sk, dout, T, [self.grad(s) for s in srcs], accumulate=acc, chain=False)
@@ -277,7 +282,7 @@ class BackwardPlan:
         x.gw = True
 
     # ------------------------------------------------------------------ run
-    def run(self, dpred: torch.Tensor, gloss: torch.Tensor):
+    def run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True):
         e, m, lib = self.e, self.m, self.lib
         last = e._last
         if not last.get("train", False) and m.dropout:
@@ -307,7 +312,7 @@ class BackwardPlan:
         args[1], args[2] = last["x"].data_ptr(), _p(last["in_scale"])
         check(fn(*args, stream), what)
         self._embedding_backward(last)
-        out = self.flat.clone()
+        out = self.flat.clone() if clone else self.flat  # clone: autograd may keep the returned tensors alive
         res = []
         for p_ in self.param_order:
             if not p_.requires_grad:

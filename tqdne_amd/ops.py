@@ -223,7 +223,7 @@ def colsum(dy, per_sample=True, total=True, bscale=None):
     B, T, Cn = dy.shape
     obc = torch.zeros(B, Cn, device=dy.device) if per_sample else None
     oc = torch.zeros(Cn, device=dy.device) if total else None
-    check(lib.tq_colsum(_p(dy), B, T, Cn, _p(obc), Cn, _p(oc), _p(bscale), _stream(dy.device)), "colsum")
+    check(lib.tq_colsum(_p(dy), B, T, Cn, _p(obc), Cn, _p(oc), None, _p(bscale), _stream(dy.device)), "colsum")
     return obc, oc
 
 

@@ -42,24 +42,15 @@ class DataParallelTrainer:
         cfg = module.configure_optimizers()
         self.optimizer = cfg["optimizer"]
         self.scheduler = cfg["lr_scheduler"]["scheduler"]
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        # gradients live in one flat buffer (p.grad are views): one memset per step, few large all-reduces
-        n = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
         self.bucket_elems = max(1, bucket_bytes // 4)
         if world_size > 1:
             for p in module.parameters():  # replicas start identical (DDP's initial broadcast)
                 dist.broadcast(p.data, src=0)
 
     def train_step(self, batch):
-        self.flat_grad.zero_()
-        loss = self.module.step(batch, 0)
-        loss.backward()
-        allreduce_mean_(self.flat_grad, self.world, self.bucket_elems)
+        """loss, backward (HIP), gradient mean over ranks (one flat buffer, bucketed all-reduce), Adam, cosine LR."""
+        loss, flat = self.module.step_and_backward(batch)
+        allreduce_mean_(flat, self.world, self.bucket_elems)
         self.optimizer.step()
         self.scheduler.step()
         return loss
