@@ -281,3 +281,33 @@ def test_trainer_step_matches_autograd_path():
     tr.train_step({"signal": sig, "cond": cond})
     changed = sum(int(not torch.equal(before[n], p.detach())) for n, p in edm.unet.named_parameters() if p.requires_grad)
     assert changed > 100
+
+
+def test_edm_stochastic_sampler_vs_golden():
+    edm, d = _edm_pair(6)
+    edm.deterministic_sampling = False
+    from oracle import edm as OE
+    sig = OE.sampling_sigmas(OE.EDMParams(), 6)
+    start = torch.from_numpy(d["stoch:start"])
+    churn = [torch.from_numpy(c).to(dev()) for c in d["stoch:churn"]]
+    out = edm.sample_stochastically((start * sig[0]).to(dev()), sig.to(dev()), None, torch.from_numpy(d["cond"]).to(dev()),
+                                    churn_noises=churn).to(torch.float32)
+    e = rel_err(out.cpu(), d["stoch:out"])
+    print(f"6-step stochastic sampler: {e:.2e}")
+    assert e < TOL
+
+
+def test_batch_of_one_and_repeated_calls_are_consistent():
+    """plans are cached per (B, T): a second call with new inputs and a B=1 plan must agree with the B=2 result"""
+    from tqdne_amd import UNetModel
+    sd, d = load_golden("micro_unet.npz")
+    m = UNetModel(**cfg_of(d))
+    m.load_state_dict(sd)
+    m = m.to(dev()).eval()
+    x, t, c = (torch.from_numpy(d[f"T256:{k}"]).to(dev()) for k in ("x", "t", "cond"))
+    with torch.no_grad():
+        y2 = m(x, t, c)
+        y1 = m(x[:1].contiguous(), t[:1].contiguous(), c[:1].contiguous())
+        y2b = m(x, t, c)
+    assert torch.equal(y2, y2b)
+    assert rel_err(y1.cpu(), y2[:1].cpu()) < 1e-6

@@ -104,11 +104,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     const int n_ttiles = (p.T_out + C::NT - 1) / C::NT;
     const int n_ctiles = (p.C_out + C::MT - 1) / C::MT;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so ids i and i + 8 share an L2.  The channel tiles
+    // of one (b, t-tile) re-read the same input rows: give them ids 8 apart (same XCD) instead of adjacent (different XCDs).
     int bid = blockIdx.x;
-    const int ct = bid % n_ctiles;
-    bid /= n_ctiles;
-    const int tt = bid % n_ttiles;
-    const int b = bid / n_ttiles;
+    int ct, tile;
+    const int ntile = p.B * n_ttiles;
+    if (n_ctiles > 1 && (ntile & 7) == 0) {
+        const int grp = bid / (8 * n_ctiles), within = bid % (8 * n_ctiles);
+        ct = within >> 3;
+        tile = grp * 8 + (within & 7);
+    } else {
+        ct = bid % n_ctiles;
+        tile = bid / n_ctiles;
+    }
+    const int tt = tile % n_ttiles;
+    const int b = tile / n_ttiles;
     const int t0 = tt * C::NT;
     const int co_wave = ct * C::MT + wm * 32;
     const bool wave_active = co_wave < p.C_out;
@@ -283,17 +293,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         // which leaves the swizzle term unchanged: one address per tap, t-blocks are immediate offsets.
         const int rowk = (STRIDE == 1) ? (tl_lane + k) : ((k & 1) * (C::NT + 1) + tl_lane + (k >> 1));
         const int b0 = rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
-        Frag bh[2], bl[2];
-        read_b(hi_plane, lo_plane, b0, 0, bh[0], bl[0]);
+#ifndef TQ_LDS_DEPTH
+#define TQ_LDS_DEPTH 2
+#endif
+        // fragment reads run TQ_LDS_DEPTH t-blocks ahead of the MFMAs that consume them (6 MFMAs = 96 cycles per t-block do
+        // not cover the LDS latency under load with a single block of lookahead)
+        constexpr int DEP = TQ_LDS_DEPTH, NB = TQ_LDS_DEPTH + 1;
+        Frag bh[NB], bl[NB];
+#pragma unroll
+        for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bh[t], bl[t]);
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
-            if (tb + 1 < 8) read_b(hi_plane, lo_plane, b0, tb + 1, bh[(tb + 1) & 1], bl[(tb + 1) & 1]);
+            if (tb + DEP < 8) read_b(hi_plane, lo_plane, b0, tb + DEP, bh[(tb + DEP) % NB], bl[(tb + DEP) % NB]);
 #ifndef TQ_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
-                acc[cbk][tb] = mfma_x3(ah[cbk].v, al[cbk].v, bh[tb & 1].v, bl[tb & 1].v, acc[cbk][tb]);
+                acc[cbk][tb] = mfma_x3(ah[cbk].v, al[cbk].v, bh[tb % NB].v, bl[tb % NB].v, acc[cbk][tb]);
 #ifndef TQ_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -529,9 +546,9 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 
 template <int KT, int STRIDE, int UPS, int EPI, int ACT>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
-    // pointwise convs are staging-bound (one tap of MFMA work per staged chunk): an 8-wave workgroup covering 256 output
-    // channels stages each input tile once instead of twice (measured -32 % on 512->256, neutral for k = 5)
-    if constexpr (KT == 1 && STRIDE == 1 && UPS == 0) {
+    // 256 output channels: one 8-wave workgroup stages each input tile once instead of two 4-wave workgroups staging it
+    // twice (measured -32 % for pointwise convs, which are staging-bound, and -2...-5 % for k = 5)
+    if constexpr (STRIDE == 1 && UPS == 0) {
         if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT>(a, s);
     }
     if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT>(a, s);

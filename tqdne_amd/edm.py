@@ -261,19 +261,20 @@ class LightningEDM(LightningModule):
         return x.clone()
 
     @th.no_grad()
-    def sample_stochastically(self, eps, sigmas, cond_sample=None, cond=None):
+    def sample_stochastically(self, eps, sigmas, cond_sample=None, cond=None, churn_noises=None):
         """Stochastic (churned) sampler (edm.py:198-230).  The churn bookkeeping is a handful of fp64 elementwise torch
         ops per step around the fused HIP denoiser; sigma_hat is resolved on the host exactly as the reference does."""
-        return self._sample_generic(eps, sigmas, cond_sample, cond, stochastic=True)
+        return self._sample_generic(eps, sigmas, cond_sample, cond, stochastic=True, churn_noises=churn_noises)
 
-    def _sample_generic(self, eps, sigmas, cond_sample, cond, stochastic):
+    def _sample_generic(self, eps, sigmas, cond_sample, cond, stochastic, churn_noises=None):
         dtype = th.float64
         sample_next = eps
         for i, (sigma, sigma_next) in enumerate(zip(sigmas[:-1], sigmas[1:])):
             sample_curr = sample_next
             if stochastic:
                 sigma_hat = self.edm.sigma_hat(sigma, self.num_sampling_steps)
-                noise = th.randn_like(sample_curr) * self.edm.S_noise
+                unit = th.randn_like(sample_curr) if churn_noises is None else churn_noises[i]  # edm.py:207 draw
+                noise = unit * self.edm.S_noise
                 sample_hat = sample_curr + noise * (sigma_hat**2 - sigma**2) ** 0.5
             else:
                 sigma_hat, sample_hat = sigma, sample_curr
