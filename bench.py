@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--no-sample", action="store_true", help="debug: time the train step only (NOT the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--no-graph", action="store_true", help="disable HIP-graph replay of the UNet forward in the sampler")
+    ap.add_argument("--graph", action="store_true", help="replay the UNet forward of the sampler from a HIP graph (neutral at B=64: GPU-bound)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -213,7 +213,7 @@ def main():
     trainer = DataParallelTrainer(edm, world_size=world) if not args.no_train else None
     sigmas = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
     eps0 = start_noise * sigmas[0]
-    use_graph = not args.no_graph
+    use_graph = args.graph
 
     # HIP-event probe around the dominant kernel (the heaviest k=5 conv launch of the forward)
     eng = edm.unet._engine(B, T, dev)

@@ -311,3 +311,16 @@ def test_batch_of_one_and_repeated_calls_are_consistent():
         y2b = m(x, t, c)
     assert torch.equal(y2, y2b)
     assert rel_err(y1.cpu(), y2[:1].cpu()) < 1e-6
+
+
+def test_graph_replayed_sampler_matches_eager():
+    edm, d = _edm_pair(18)
+    from oracle import edm as OE
+    sig = OE.sampling_sigmas(OE.EDMParams(), 18).to(dev())
+    eps = (torch.from_numpy(d["sample:start"]) * sig[0].cpu()).to(dev())
+    cond = torch.from_numpy(d["cond"]).to(dev())
+    a = edm.sample_deterministically(eps, sig, None, cond, use_graph=False)
+    b = edm.sample_deterministically(eps, sig, None, cond, use_graph=True)
+    c = edm.sample_deterministically(eps, sig, None, cond, use_graph=True)  # cached graph
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert rel_err(a.float().cpu(), d["sample:out"]) < TOL

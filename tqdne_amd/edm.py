@@ -249,16 +249,44 @@ class LightningEDM(LightningModule):
         nsteps = sigmas.numel() - 1
         sp = sigmas.data_ptr()
         stream = th.cuda.current_stream(dev).cuda_stream
+        denoise = lambda sig_ptr: self._denoise_static(x32, _RawPtr(sig_ptr), 0, cond)
+        if use_graph:
+            denoise = self._graph_denoiser(bufs, x32, cond)
         for i in range(nsteps):
             s_i, s_n = sp + 4 * i, sp + 4 * (i + 1)
-            den = self._denoise_static(x32, _RawPtr(s_i), 0, cond)
+            den = denoise(s_i)
             check(lib.tq_heun_euler(_p(x), _p(den), s_i, s_n, _p(d), _p(xn), _p(x32), n, stream), "heun euler")
             if i < self.num_sampling_steps - 1:
-                den = self._denoise_static(x32, _RawPtr(s_n), 0, cond)
+                den = denoise(s_n)
                 check(lib.tq_heun_correct(_p(x), _p(xn), _p(den), _p(d), s_i, s_n, _p(x), _p(x32), n, stream), "heun correct")
             else:
                 x, xn = xn, x
         return x.clone()
+
+    def _graph_denoiser(self, bufs, x32, cond):
+        """One preconditioned UNet evaluation (~160 launches) captured once in a HIP graph and replayed per NFE; sigma is fed
+        through a static device slot.  Pays off when the forward is launch-bound (small batches); at B = 64 the host already
+        runs ahead of the GPU."""
+        g = bufs.get("graph")
+        if g is None or bufs.get("graph_cond") != (None if cond is None else cond.data_ptr()):
+            slot = th.zeros(1, device=x32.device)
+            self._denoise_static(x32, slot, 0, cond)  # warm-up outside capture (plan build, weight packing)
+            th.cuda.synchronize(x32.device)
+            graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(graph):
+                out = self._denoise_static(x32, slot, 0, cond)
+            g = (graph, slot, out)
+            bufs["graph"], bufs["graph_cond"] = g, (None if cond is None else cond.data_ptr())
+        graph, slot, out = g
+        elem = slot.element_size()
+
+        def run(sig_ptr):
+            # device-to-device copy of the 4-byte sigma into the captured slot, then replay
+            _lib_memcpy_d2d(slot.data_ptr(), sig_ptr, elem, th.cuda.current_stream(slot.device).cuda_stream)
+            graph.replay()
+            return out
+
+        return run
 
     @th.no_grad()
     def sample_stochastically(self, eps, sigmas, cond_sample=None, cond=None, churn_noises=None):
@@ -301,6 +329,32 @@ class LightningEDM(LightningModule):
             optimizer, T_max=self.optimizer_params["max_steps"], eta_min=self.optimizer_params["eta_min"]
         )
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": lr_scheduler, "interval": "step"}}
+
+
+def _lib_memcpy_d2d(dst, src, nbytes, stream):
+    """async device-to-device copy on ``stream`` (hipMemcpyAsync through the runtime torch already loaded)"""
+    import ctypes
+    rt = _hip_runtime()
+    rc = rt.hipMemcpyAsync(ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(nbytes), 3, ctypes.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpyAsync failed: {rc}")
+
+
+_HIP_RT = []
+
+
+def _hip_runtime():
+    if not _HIP_RT:
+        import ctypes
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6", "/opt/rocm/lib/libamdhip64.so"):
+            try:
+                _HIP_RT.append(ctypes.CDLL(name))
+                break
+            except OSError:
+                continue
+        if not _HIP_RT:
+            raise RuntimeError("libamdhip64.so not found")
+    return _HIP_RT[0]
 
 
 class _RawPtr:
