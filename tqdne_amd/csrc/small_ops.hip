@@ -211,6 +211,12 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     constexpr int LD = TW + 1;  // odd leading dimension: conflict-free transposed writes
     float* xs = shm;             // [C_in][LD]
     float* part = xs + C_in * LD;  // [128][MAXCO]
+    float* wl = part + 128 * MAXCO;  // [C_in][KT][MAXCO] weights, co fastest (broadcast reads)
+    for (int i = threadIdx.x; i < C_in * KT * MAXCO; i += 256) {
+        const int co = i % MAXCO, r = i / MAXCO;
+        const int k = r % KT, ci = r / KT;
+        wl[i] = (co < C_out) ? w[((size_t)co * C_in + ci) * KT + k] : 0.f;
+    }
     const int tile = blockIdx.x % ntiles;
     const int b = blockIdx.x / ntiles;
     const int t0 = tile * 128;
@@ -242,9 +248,9 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             const float xv = xs[ci * LD + tl + k];
+            const float* wr = wl + (ci * KT + k) * MAXCO;
 #pragma unroll
-            for (int co = 0; co < MAXCO; ++co)
-                if (co < C_out) acc[co] = fmaf(w[((size_t)co * C_in + ci) * KT + k], xv, acc[co]);
+            for (int co = 0; co < MAXCO; ++co) acc[co] = fmaf(wr[co], xv, acc[co]);
         }
     }
     if (half == 1) {
@@ -277,7 +283,7 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
     if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || C_out < 1 || C_out > 16) return TQ_ERR_SHAPE;
     const int ntiles = (T + 127) / 128;
     const int maxco = C_out <= 4 ? 4 : 16;
-    const size_t sh = ((size_t)C_in * (128 + ktaps) + 128 * maxco) * sizeof(float);
+    const size_t sh = ((size_t)C_in * (128 + ktaps) + 128 * maxco + (size_t)C_in * ktaps * maxco) * sizeof(float);
     if (sh > 160 * 1024) return TQ_ERR_SHAPE;
 #define TQ_HEAD(K)                                                                                          \
     {                                                                                                       \
@@ -349,13 +355,16 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ t,
                                                     const float* __restrict__ cb2, float* __restrict__ emb,
                                                     float* __restrict__ silu_emb, float* __restrict__ hidden, int mc,
                                                     int ncond) {
+    // grid (B, 4): every workgroup recomputes the cheap first layers (mc -> E and ncond -> E) and owns one quarter of the
+    // outputs of the two E x E layers, so the 2 * E * E weight reads of a sample are spread over four CUs
     extern __shared__ __attribute__((aligned(16))) float shm[];
     const int E = 4 * mc;
     float* four = shm;        // [mc]
-    float* h = four + mc;     // [E]
-    float* e = h + E;         // [E]
-    float* cs = e + E;        // [ncond]
-    const int b = blockIdx.x;
+    float* h = four + mc;     // [E]  silu(time hidden)
+    float* c = h + E;         // [E]  silu(cond hidden)
+    float* e = c + E;         // [E/4] this workgroup's outputs
+    float* cs = e + E / 4;    // [ncond]
+    const int b = blockIdx.x, q = blockIdx.y;
     const float tv = t[b];
     const int half = mc >> 1;
     for (int i = threadIdx.x; i < half; i += 256) {
@@ -367,28 +376,27 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ t,
     for (int i = threadIdx.x; i < ncond; i += 256) cs[i] = cond[(size_t)b * ncond + i];
     __syncthreads();
     gemv_rows(w0, b0, four, mc, E, h, false);
+    if (ncond > 0) gemv_rows(cw0, cb0, cs, ncond, E, c, false);
     __syncthreads();
     for (int i = threadIdx.x; i < E; i += 256) {
-        if (hidden) hidden[((size_t)b * 2 + 0) * E + i] = h[i];
-        h[i] = silu_f(h[i]);
-    }
-    __syncthreads();
-    gemv_rows(w2, b2, h, E, E, e, false);
-    __syncthreads();
-    if (ncond > 0) {
-        gemv_rows(cw0, cb0, cs, ncond, E, h, false);
-        __syncthreads();
-        for (int i = threadIdx.x; i < E; i += 256) {
-            if (hidden) hidden[((size_t)b * 2 + 1) * E + i] = h[i];
-            h[i] = silu_f(h[i]);
+        if (hidden && q == 0) {
+            hidden[((size_t)b * 2 + 0) * E + i] = h[i];
+            if (ncond > 0) hidden[((size_t)b * 2 + 1) * E + i] = c[i];
         }
-        __syncthreads();
-        gemv_rows(cw2, cb2, h, E, E, e, true);
-        __syncthreads();
+        h[i] = silu_f(h[i]);
+        if (ncond > 0) c[i] = silu_f(c[i]);
     }
-    for (int i = threadIdx.x; i < E; i += 256) {
-        emb[(size_t)b * E + i] = e[i];
-        silu_emb[(size_t)b * E + i] = silu_f(e[i]);
+    __syncthreads();
+    const int o0 = q * (E / 4);
+    gemv_rows(w2 + (size_t)o0 * E, b2 + o0, h, E, E / 4, e, false);
+    if (ncond > 0) {
+        __syncthreads();
+        gemv_rows(cw2 + (size_t)o0 * E, cb2 + o0, c, E, E / 4, e, true);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < E / 4; i += 256) {
+        emb[(size_t)b * E + o0 + i] = e[i];
+        silu_emb[(size_t)b * E + o0 + i] = silu_f(e[i]);
     }
 }
 
@@ -438,8 +446,8 @@ extern "C" int tq_embed_fwd(const float* t, const float* cond, const float* four
     if (!t || !fourier_w || !w0 || !b0 || !w2 || !b2 || !emb || !silu_emb) return TQ_ERR_ARG;
     if (ncond > 0 && (!cond || !cw0 || !cb0 || !cw2 || !cb2)) return TQ_ERR_ARG;
     if (B <= 0 || mc <= 0 || mc % 2 || ncond < 0) return TQ_ERR_SHAPE;
-    const size_t sh = (size_t)(mc + 8 * mc + ncond) * sizeof(float);
-    hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), sh, stream, t, cond, fourier_w, w0, b0, w2, b2, cw0, cb0, cw2, cb2,
+    const size_t sh = (size_t)(mc + 9 * mc + ncond + 4) * sizeof(float);
+    hipLaunchKernelGGL(embed_kernel, dim3(B, 4), dim3(256), sh, stream, t, cond, fourier_w, w0, b0, w2, b2, cw0, cb0, cw2, cb2,
                        emb, silu_emb, hidden, mc, ncond);
     TQ_CHECK_LAUNCH();
     return 0;
