@@ -278,6 +278,18 @@ def main():
                              "frac = algorithmic FLOP/s over the dense bf16 MFMA peak, so 1/3 is the ceiling of this scheme")
         if roofline["achieved"]:
             roofline["frac"] = roofline["achieved"] / roofline["peak"]
+        # HBM traffic of the same launch from PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
+        # separate rocprofv3 --pmc passes by tools/pmc_dominant.sh; bench.py cannot read PMCs itself
+        import glob
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_dominant_conv.json")))
+        if pmc and args.config == "paper" and B == 64 and T == 4096:
+            try:
+                pj = json.load(open(pmc[-1]))
+                roofline["traffic"] = pj.get("hbm_traffic_bytes_per_launch")
+                roofline["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
+                roofline["algorithmic_bytes_per_launch"] = pj.get("algorithmic_bytes_per_launch")
+            except Exception:
+                pass
         nfe = 2 * args.sample_steps - 1
         work_flop = B * flops_fwd * ((3 if trainer else 0) + (nfe if not args.no_sample else 0))
         algo_bytes = None
