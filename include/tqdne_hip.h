@@ -49,6 +49,7 @@ typedef struct TqConvDesc {
     uint32_t dropout_site;
     float dropout_p;
     uint64_t dropout_seed;
+    int32_t C_skip0, C_skip1; /* tq_conv1d_fwd_skip only: channels of the fused 1x1 skip conv's (concatenated) input; else 0 */
 } TqConvDesc;
 
 /* flags of TqConvBwdDesc.flags: which stages the FORWARD conv applied to its input */
@@ -85,6 +86,13 @@ int tq_conv_tile_co(int C_out);
 int tq_conv1d_fwd(const TqConvDesc* desc, const float* x0, const float* x1, const float* gscale, const float* gshift,
                   const void* packed_w, const float* bias, const float* emb, const float* residual, float* y,
                   float* stats_partial, hipStream_t stream);
+
+/* Same, with the ResBlock's 1x1 skip convolution fused in (unet.py:112,143): y = conv_k(f(x)) + W_skip * x_skip + biases.
+ * packed_w holds tq_pack_conv_weight(main, mode 0) immediately followed by tq_pack_conv_weight(skip 1x1, mode 0).
+ * Built for k = 5 with GN + SiLU (+ dropout) prologues. */
+int tq_conv1d_fwd_skip(const TqConvDesc* desc, const float* x0, const float* x1, const float* gscale, const float* gshift,
+                       const void* packed_w_main_then_skip, const float* bias, const float* emb, const float* skip_x0,
+                       const float* skip_x1, const float* skip_bias, float* y, float* stats_partial, hipStream_t stream);
 
 /* Data gradient of tq_conv1d_fwd (stride 1): g = (W^T * dy) chained through the forward prologue (dropout, SiLU,
  * folded GN scale); packed_w_t from tq_pack_conv_weight(mode 1).  x0/x1/gscale/gshift are the FORWARD conv's inputs.

@@ -73,6 +73,36 @@ def test_conv_fused_everything():
     assert rel_err(st.cpu(), ref_stats(ref)) < TOL
 
 
+@pytest.mark.parametrize("C,Cs0,Cs1,Co,T,p", [
+    (128, 64, 0, 128, 333, 0.0), (256, 256, 256, 256, 200, 0.0), (256, 128, 0, 256, 129, 0.0), (128, 128, 64, 128, 700, 0.0),
+    (256, 32, 0, 256, 64, 0.0), (128, 96, 32, 128, 257, 0.3),
+])
+def test_conv_fused_skip(C, Cs0, Cs1, Co, T, p):
+    """ResBlock tail in one launch: conv5(SiLU(GN(h))) + emb + 1x1 skip conv of the (concatenated, raw) block input."""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(C + Cs0 + Cs1 + T)
+    B = 2
+    h = torch.randn(B, C, T, generator=g)
+    s0 = torch.randn(B, Cs0, T, generator=g)
+    s1 = torch.randn(B, Cs1, T, generator=g) if Cs1 else None
+    a, sh = torch.randn(B, C, generator=g), torch.randn(B, C, generator=g)
+    w = torch.randn(Co, C, 5, generator=g) / math.sqrt(5 * C)
+    wsk = torch.randn(Co, Cs0 + Cs1, 1, generator=g) / math.sqrt(Cs0 + Cs1)
+    b, bsk, emb = torch.randn(Co, generator=g), torch.randn(Co, generator=g), torch.randn(B, Co, generator=g)
+    d = dev()
+    kw = dict(gscale=a.to(d), gshift=sh.to(d), silu=True, emb=emb.to(d), dropout_p=p, dropout_seed=11, dropout_site=3)
+    y, st = ops.conv1d(cl(h), w.to(d), b.to(d), skip=(cl(s0), cl(s1) if Cs1 else None, wsk.to(d), bsk.to(d)), **kw)
+    sx = torch.cat([s0, s1], 1) if Cs1 else s0
+    skip_ref = F.conv1d(sx, wsk, bsk)
+    if p == 0.0:
+        ref = F.conv1d(F.silu(h * a[:, :, None] + sh[:, :, None]), w, b, padding=2) + emb[:, :, None] + skip_ref
+    else:  # the dropout mask is the kernel's own (counter hash): compare with the two-launch form of the same seed / site
+        res = ops.conv1d(cl(sx), wsk.to(d), bsk.to(d), stats=False)[0]
+        ref = ncw(ops.conv1d(cl(h), w.to(d), b.to(d), residual=res, **kw)[0])
+    assert rel_err(ncw(y), ref) < TOL
+    assert rel_err(st.cpu(), ref_stats(ref)) < TOL
+
+
 @pytest.mark.parametrize("C,T", [(64, 256), (128, 250), (32, 131), (256, 508)])
 def test_conv_downsample(C, T):
     from tqdne_amd import ops

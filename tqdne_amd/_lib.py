@@ -28,6 +28,7 @@ class TqConvDesc(C.Structure):
         ("ktaps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("upsample", C.c_int32), ("flags", C.c_int32), ("emb_stride", C.c_int32),
         ("dropout_site", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+        ("C_skip0", C.c_int32), ("C_skip1", C.c_int32),
     ]
 
 
@@ -45,6 +46,7 @@ _PROTOS = {
     "tq_pack_conv_weight": (I, [VP, I, I, I, I, VP, VP]),
     "tq_conv_tile_co": (I, [I]),
     "tq_conv1d_fwd": (I, [C.POINTER(TqConvDesc)] + [VP] * 11),
+    "tq_conv1d_fwd_skip": (I, [C.POINTER(TqConvDesc)] + [VP] * 13),
     "tq_stem_conv_fwd": (I, [VP] * 6 + [I] * 5 + [VP]),
     "tq_head_conv_fwd": (I, [VP] * 9 + [I] * 5 + [VP]),
     "tq_gn_finalize": (I, [VP, I, VP, I, I, I, VP, VP, VP, VP, VP, VP]),

@@ -71,6 +71,11 @@ struct ConvArgs {
     float* y1;
     int OC0;     // output channels [0, OC0) -> y (row stride OC0), [OC0, C_out) -> y1 (row stride C_out - OC0)
     int bflags;  // TQ_BWD_*
+    // fused 1x1 skip convolution (FUSE): extra K chunks read un-activated from the block input, centre tap only
+    const float* sx0;
+    const float* sx1;
+    const float* sbias;
+    int sC0, sC1;
 };
 
 template <int KT, int STRIDE, int UPS, int WM, int WN>
@@ -91,7 +96,9 @@ struct Cfg {
 };
 
 // ACT (compile time): prologue applied while staging -- 0 none, 1 folded GN, 2 GN + SiLU, 3 GN + SiLU + dropout
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT>
+// FUSE: the ResBlock's 1x1 skip convolution (unet.py:112,143) is accumulated into the same MFMA accumulators as extra
+// 32-channel stages read from the block input (plain, centre tap), instead of a separate launch + residual round trip
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -125,6 +132,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     const int Cin = p.C0 + p.C1;
     const int nchunks = Cin >> 5;
+    const int nskip = FUSE ? ((p.sC0 + p.sC1) >> 5) : 0;
+    const int nstages = nchunks + nskip;  // stage s < nchunks: main chunk (KT taps); else skip chunk (centre tap)
     const int T_src = UPS ? 2 * p.T_in : p.T_in;  // extent of the (virtually upsampled) input
 
     // ---- staging bookkeeping: thread owns 4 consecutive channels (m) of rows i = (tid + it*NTHR) >> 3
@@ -141,12 +150,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         return 2 * t0 - C::PAD + 2 * idx + par;
     };
 
-    auto chunk_base = [&](int chunk, int& cs) -> const float* __attribute__((always_inline)) {
-        const int cb = chunk << 5;
-        const float* src;
-        int coff;
-        if (cb < p.C0) { src = p.x0; cs = p.C0; coff = cb; }
-        else           { src = p.x1; cs = p.C1; coff = cb - p.C0; }
+    auto chunk_base = [&](int stage, int& cs) -> const float* __attribute__((always_inline)) {
+        const bool sk = FUSE && stage >= nchunks;
+        const int cb = (sk ? stage - nchunks : stage) << 5;
+        const float* a0 = sk ? p.sx0 : p.x0;
+        const float* a1 = sk ? p.sx1 : p.x1;
+        const int c0 = sk ? p.sC0 : p.C0, c1 = sk ? p.sC1 : p.C1;
+        const bool first = cb < c0;
+        const float* src = first ? a0 : a1;
+        cs = first ? c0 : c1;
+        const int coff = first ? cb : cb - c0;
         return src + (size_t)b * p.T_in * cs + coff + 4 * m;
     };
 
@@ -169,16 +182,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         const int pos = src_pos(i);
         const float msk = (pos >= 0 && pos < T_src) ? 1.f : 0.f;
         float u[4] = {rv.x, rv.y, rv.z, rv.w};
-        if (ACT >= 1) {
+        const bool act = !(FUSE && chunk >= nchunks);  // skip stages stage the raw block input
+        if (ACT >= 1 && act) {
             u[0] = fmaf(g_a.x, u[0], g_s.x); u[1] = fmaf(g_a.y, u[1], g_s.y);
             u[2] = fmaf(g_a.z, u[2], g_s.z); u[3] = fmaf(g_a.w, u[3], g_s.w);
         }
-        if (ACT >= 2) {
+        if (ACT >= 2 && act) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)  // u * sigmoid(u) = u / (1 + 2^(-u*log2 e)): v_mul, v_exp, v_add, v_rcp, v_mul
                 u[j] = u[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[j] * -1.4426950408889634f));
         }
-        if (ACT == 3) {
+        if (ACT == 3 && act) {
             const int cb = chunk << 5;
             const int pc = pos < 0 ? 0 : pos;
             const uint64_t e0 = ((uint64_t)b * T_src + pc) * Cin + cb + 4 * m;
@@ -218,8 +232,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         const float* base = chunk_base(chunk, cs);
 #pragma unroll
         for (int it = 0; it < C::PRE; ++it) raw[it] = load_one(base, cs, it);
-        if (ACT >= 1) {  // folded GroupNorm coefficients of this thread's 4 channels
-            const int cb = chunk << 5;
+        if (ACT >= 1) {  // folded GroupNorm coefficients of this thread's 4 channels (skip stages: clamped, unused)
+            const int cb = (chunk < nchunks ? chunk : nchunks - 1) << 5;
             g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
             g_s = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cb + 4 * m);
         }
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // s_waitcnt vmcnt(0) / lgkmcnt(0) at every control-flow join, which serialises each prefetch with its consumer) and pinned
     // with sched_barrier so that (1) the weight fragments of tap k+2 are requested before the MFMAs of tap k+1 and (2) the
     // LDS reads of t-block tb+1 are in flight under the MFMAs of t-block tb.
-    const int last_step = nchunks * KT - 1;
+    const int last_step = nchunks * KT + nskip - 1;
     auto load_w = [&](int step, Frag (&ah)[2], Frag (&al)[2]) __attribute__((always_inline)) {
         const int st = step < last_step ? step : last_step;  // clamped: the final refills re-read the last fragments
 #ifdef TQ_ABL_NOW
@@ -371,11 +385,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         }
     };
 
-    // ---- main loop over 32-channel chunks
+    // skip stage j: one (centre) tap. Buffer a holds this step's weights and b the next one's (the last main chunk's
+    // wrap-around refills fetched skip steps 0 / 1 as "next chunk, taps 0 / 1"); b is shifted into a afterwards, which
+    // keeps every buffer access statically indexed (a pointer select between a and b would demote both to scratch)
+    auto compute_skip = [&](int j, int buf) __attribute__((always_inline)) {
+        const unsigned char* hi_plane = lds + buf * C::BUF;
+        const unsigned char* lo_plane = hi_plane + C::PLANE;
+        mma_tap(C::PAD, hi_plane, lo_plane, wa_h, wa_l, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { wa_h[i] = wb_h[i]; wa_l[i] = wb_l[i]; }
+        load_w(nchunks * KT + j + 2, wb_h, wb_l);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- main loop over the stages (32-channel chunks of the conv input, then of the fused skip input)
     stage_load(0);
     if (wave_active) {
         load_w(0, wa_h, wa_l);
-        if (KT > 1) load_w(1, wb_h, wb_l);
+        if (KT > 1 || nskip > 0) load_w(1, wb_h, wb_l);
     }
     stage_write(0, 0, false);
     __syncthreads();
@@ -383,16 +410,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     unsigned long long s_load = 0, s_mma = 0, s_write = 0, s_bar = 0;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-    for (int c = 0; c + 1 < nchunks; ++c) {
+    for (int c = 0; c + 1 < nstages; ++c) {
         TQ_T(tA)
 #ifndef TQ_ABL_NOSTAGE
         stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
 #endif
         TQ_T(tB)
-        if (wave_active) compute(c, c & 1, true);
+        if (wave_active) {
+            if (!FUSE || c < nchunks) compute(c, c & 1, true);
+            else compute_skip(c - nchunks, c & 1);
+        }
         TQ_T(tC)
 #ifndef TQ_ABL_NOSTAGE
-        stage_write(c + 1, (c + 1) & 1, wave_active);
+        stage_write(c + 1, (c + 1) & 1, wave_active && (!FUSE || c < nchunks));
 #endif
         TQ_T(tD)
         __syncthreads();
@@ -401,7 +431,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         s_load += tB - tA; s_mma += tC - tB; s_write += tD - tC; s_bar += tE - tD;
 #endif
     }
-    if (wave_active) compute(nchunks - 1, (nchunks - 1) & 1, false);
+    if (wave_active) {
+        if (!FUSE || nskip == 0) compute(nstages - 1, (nstages - 1) & 1, false);
+        else compute_skip(nskip - 1, (nstages - 1) & 1);
+    }
 #ifdef TQ_STAMP
     if (lane == 0) {
         const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
@@ -422,6 +455,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         if (p.bias) add = *reinterpret_cast<const float4*>(p.bias + co);
         if (emb_b) {
             const float4 e = *reinterpret_cast<const float4*>(emb_b + co);
+            add.x += e.x; add.y += e.y; add.z += e.z; add.w += e.w;
+        }
+        if (FUSE && p.sbias) {
+            const float4 e = *reinterpret_cast<const float4*>(p.sbias + co);
             add.x += e.x; add.y += e.y; add.z += e.z; add.w += e.w;
         }
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -525,10 +562,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     }
 }
 
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE>
 int launch(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN>;
-    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -544,20 +581,20 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <int KT, int STRIDE, int UPS, int EPI, int ACT>
+template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     // 256 output channels: one 8-wave workgroup stages each input tile once instead of two 4-wave workgroups staging it
     // twice (measured -32 % for pointwise convs, which are staging-bound, and -2...-5 % for k = 5)
     if constexpr (STRIDE == 1 && UPS == 0) {
-        if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT>(a, s);
+        if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE>(a, s);
     }
-    if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT>(a, s);
+    if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE>(a, s);
     if constexpr (STRIDE == 1) {
-        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT>(a, s);
-        return launch<KT, STRIDE, UPS, 1, 2, EPI, ACT>(a, s);
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT, FUSE>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 2, EPI, ACT, FUSE>(a, s);
     } else {
-        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1, EPI, ACT>(a, s);
-        return launch<KT, STRIDE, UPS, 1, 1, EPI, ACT>(a, s);
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1, EPI, ACT, FUSE>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 1, EPI, ACT, FUSE>(a, s);
     }
 }
 
@@ -566,6 +603,13 @@ template <int KT>
 int dispatch_act(const ConvArgs& a, hipStream_t s) {
     const bool gn = a.flags & TQ_CONV_GN, silu = a.flags & TQ_CONV_SILU, drop = a.flags & TQ_CONV_DROPOUT;
     if ((!gn && silu) || (drop && !silu)) return TQ_ERR_ARG;  // supported prologues: none | GN | GN+SiLU | GN+SiLU+dropout
+    if (a.sx0) {  // fused 1x1 skip conv: built for the ResBlock's second conv (k = 5, GN + SiLU [+ dropout])
+        if constexpr (KT == 5) {
+            if (gn && silu && drop) return dispatch_tile<KT, 1, 0, 0, 3, true>(a, s);
+            if (gn && silu) return dispatch_tile<KT, 1, 0, 0, 2, true>(a, s);
+        }
+        return TQ_ERR_SHAPE;
+    }
     if (gn && silu && drop) return dispatch_tile<KT, 1, 0, 0, 3>(a, s);
     if (gn && silu) return dispatch_tile<KT, 1, 0, 0, 2>(a, s);
     if (gn) return dispatch_tile<KT, 1, 0, 0, 1>(a, s);
@@ -581,9 +625,31 @@ extern "C" int tq_conv_tile_co(int C_out) {
     return 32;
 }
 
+static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale, const float* gshift,
+                           const void* wpk, const float* bias, const float* emb, const float* res, const float* skip_x0,
+                           const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream);
+
 extern "C" int tq_conv1d_fwd(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale,
                              const float* gshift, const void* wpk, const float* bias, const float* emb,
                              const float* res, float* y, float* stats, hipStream_t stream) {
+    if (d && (d->C_skip0 || d->C_skip1)) return TQ_ERR_ARG;  // fused-skip descriptors go through tq_conv1d_fwd_skip
+    return conv1d_fwd_impl(d, x0, x1, gscale, gshift, wpk, bias, emb, res, nullptr, nullptr, nullptr, y, stats, stream);
+}
+
+extern "C" int tq_conv1d_fwd_skip(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale,
+                                  const float* gshift, const void* wpk_main_then_skip, const float* bias, const float* emb,
+                                  const float* skip_x0, const float* skip_x1, const float* skip_bias, float* y, float* stats,
+                                  hipStream_t stream) {
+    if (!d || !skip_x0 || d->C_skip0 <= 0 || d->C_skip0 % 32 || d->C_skip1 < 0 || d->C_skip1 % 32) return TQ_ERR_ARG;
+    if (d->C_skip1 > 0 && !skip_x1) return TQ_ERR_ARG;
+    if (d->stride != 1 || d->upsample || (d->flags & TQ_CONV_RES)) return TQ_ERR_SHAPE;
+    return conv1d_fwd_impl(d, x0, x1, gscale, gshift, wpk_main_then_skip, bias, emb, nullptr, skip_x0, skip_x1, skip_bias, y,
+                           stats, stream);
+}
+
+static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale, const float* gshift,
+                           const void* wpk, const float* bias, const float* emb, const float* res, const float* skip_x0,
+                           const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream) {
     if (!d || !x0 || !wpk || !y) return TQ_ERR_ARG;
     if (d->C_in0 <= 0 || d->C_in0 % 32 || d->C_in1 < 0 || d->C_in1 % 32 || d->C_out <= 0 || d->C_out % 32) return TQ_ERR_SHAPE;
     if (d->C_in1 > 0 && !x1) return TQ_ERR_ARG;
@@ -617,6 +683,7 @@ extern "C" int tq_conv1d_fwd(const TqConvDesc* d, const float* x0, const float* 
     a.drop_thresh = (uint32_t)((double)pdrop * 4294967296.0);
     a.drop_scale = 1.0f / (1.0f - pdrop);
     a.fx0 = a.fx1 = a.fgs = a.fgh = nullptr; a.y1 = nullptr; a.OC0 = d->C_out; a.bflags = 0;
+    a.sx0 = skip_x0; a.sx1 = skip_x1; a.sbias = skip_bias; a.sC0 = d->C_skip0; a.sC1 = d->C_skip1;
 
     if (d->stride == 2 || d->upsample) {
         if (a.flags & (TQ_CONV_GN | TQ_CONV_SILU | TQ_CONV_DROPOUT)) return TQ_ERR_SHAPE;  // resampling convs take raw inputs
@@ -664,6 +731,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.drop_thresh = (uint32_t)((double)pdrop * 4294967296.0);
     a.drop_scale = 1.0f / (1.0f - pdrop);
     a.fx0 = x0; a.fx1 = x1; a.fgs = gscale; a.fgh = gshift; a.y1 = dx1; a.OC0 = d->C_dx0;
+    a.sx0 = a.sx1 = a.sbias = nullptr; a.sC0 = a.sC1 = 0;
     switch (d->ktaps) {
         case 1: return dispatch_tile<1, 1, 0, 1, 0>(a, stream);
         case 3: return dispatch_tile<3, 1, 0, 1, 0>(a, stream);
