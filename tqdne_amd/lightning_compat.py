@@ -47,10 +47,17 @@ except Exception:  # ImportError and friends
             self._logged[name] = value
 
         @classmethod
-        def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
-            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, ema=False, **kwargs):
+            """Lightning's classmethod of the same name (experiments/generate.py:114-120): rebuild the module from the saved
+            constructor kwargs (overridden by ``kwargs``, e.g. ``autoencoder=``) and load ``state_dict``.  ``ema=True``
+            additionally loads the EMA weights saved by the reference's EMA callback (tqdne/ema.py)."""
+            from .checkpoint import apply_ema, load_checkpoint
+
+            ckpt = load_checkpoint(checkpoint_path, map_location=map_location or "cpu")
             hp = dict(ckpt.get("hyper_parameters", {}))
             hp.update(kwargs)
             model = cls(**hp)
-            model.load_state_dict(ckpt["state_dict"], strict=True)
+            model.load_state_dict(ckpt["state_dict"], strict=strict)
+            if ema:
+                apply_ema(model, ckpt)
             return model
