@@ -198,6 +198,26 @@ int tq_heun_correct(const double* x, const double* x_next, const float* denoised
 /* x64 = unit_noise64 * sigma0; x32 = (float)x64   (edm.py:160) */
 int tq_sampler_init(const double* unit_noise, const float* sigma0, double* x, float* x32, size_t n, hipStream_t stream);
 
+/* ---- optimizer (edm.py:240-251, ema.py:24-28) ------------------------------------------------------------- */
+/* One launch for the whole model: torch.optim.Adam's update (no weight decay, no amsgrad) on every chunk of the table,
+ *   g' = g * grad_scale;  m += (1 - beta1) (g' - m);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= step_size * m / (sqrt(v) * inv_bias2_sqrt + eps)       step_size = lr / (1 - beta1^t), inv_bias2_sqrt = 1/sqrt(1 - beta2^t)
+ * followed, where ema != NULL, by the EMA callback's lerp  ema += ema_weight * (p - ema)  (ema_weight = 1 - decay).
+ * The scalars are doubles (host-side values as torch computes them: 1 - beta in double) and are rounded to fp32 once.
+ * `chunks` is a DEVICE array; a chunk is <= TQ_ADAM_CHUNK consecutive elements of one tensor, its pointers 16-byte aligned. */
+#define TQ_ADAM_CHUNK 4096
+typedef struct TqAdamChunk {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    float* ema; /* NULL: no EMA for this chunk */
+    int32_t n;
+    int32_t reserved;
+} TqAdamChunk;
+int tq_adam_ema_step(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2, double eps,
+                     double inv_bias2_sqrt, double ema_weight, double grad_scale, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

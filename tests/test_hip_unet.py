@@ -277,10 +277,17 @@ def test_trainer_step_matches_autograd_path():
             err = float((p.grad - ref[n]).abs().max()) / max(float(ref[n].abs().max()), 1e-3 * gmax)
             assert err < 1e-4, (n, err)
     before = {n: p.detach().clone() for n, p in edm.unet.named_parameters()}
-    tr = DataParallelTrainer(edm, world_size=1)
+    tr = DataParallelTrainer(edm, world_size=1, ema_decay=0.5)
+    assert tr.fused  # on a GPU the update is the one-launch Adam + EMA
     tr.train_step({"signal": sig, "cond": cond})
     changed = sum(int(not torch.equal(before[n], p.detach())) for n, p in edm.unet.named_parameters() if p.requires_grad)
     assert changed > 100
+    # first Adam step moves every weight with a gradient by lr (to rounding); the EMA is halfway between old and new
+    ema = tr.ema_state()
+    for n, p in edm.named_parameters():
+        if p.requires_grad and n.startswith("unet.") and n[5:] in ref and float(ref[n[5:]].abs().max()) > 0:
+            new = p.detach()
+            assert rel_err(ema[n], 0.5 * (before[n[5:]] + new)) < 1e-5, n
 
 
 def test_edm_stochastic_sampler_vs_golden():

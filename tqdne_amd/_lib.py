@@ -32,6 +32,14 @@ class TqConvDesc(C.Structure):
     ]
 
 
+class TqAdamChunk(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
+                ("n", C.c_int32), ("reserved", C.c_int32)]
+
+
+TQ_ADAM_CHUNK = 4096
+
+
 class TqConvBwdDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T", C.c_int32), ("C_dy", C.c_int32), ("C_dx0", C.c_int32), ("C_dx1", C.c_int32),
@@ -62,6 +70,7 @@ _PROTOS = {
     "tq_heun_euler": (I, [VP] * 7 + [SZ, VP]),
     "tq_heun_correct": (I, [VP] * 8 + [SZ, VP]),
     "tq_sampler_init": (I, [VP] * 4 + [SZ, VP]),
+    "tq_adam_ema_step": (I, [VP, I] + [C.c_double] * 7 + [VP]),
     "tq_conv1d_bwd_data": (I, [VP] * 11),
     "tq_conv1d_bwd_weight_workspace": (SZ, [VP]),
     "tq_conv1d_bwd_weight": (I, [VP] * 8 + [SZ, VP]),

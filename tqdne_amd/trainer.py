@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 
-def allreduce_mean_(flat: torch.Tensor, world_size: int, bucket_elems: int = 8 << 20):
+def allreduce_mean_(flat: torch.Tensor, world_size: int, bucket_elems: int = 8 << 20, scale: bool = True):
     """In-place mean of ``flat`` over all ranks: a few large bucketed all-reduces (RCCL over xGMI on GPUs, gloo in the
     CPU tests), launched asynchronously and waited together, then one scale.  62 MB of gradients = 2 buckets of 32 MB."""
     if world_size <= 1:
@@ -18,7 +18,8 @@ def allreduce_mean_(flat: torch.Tensor, world_size: int, bucket_elems: int = 8 <
              for i in range(0, flat.numel(), bucket_elems)]
     for w in works:
         w.wait()
-    flat.mul_(1.0 / world_size)
+    if scale:
+        flat.mul_(1.0 / world_size)
     return flat
 
 
@@ -36,12 +37,28 @@ def shard_batch(batch: dict, rank: int, world_size: int) -> dict:
 
 
 class DataParallelTrainer:
-    def __init__(self, module, world_size: int = 1, bucket_bytes: int = 32 << 20):
+    def __init__(self, module, world_size: int = 1, bucket_bytes: int = 32 << 20, ema_decay=None, fused_optimizer=None):
+        """``ema_decay``: keep the EMA weights of the reference's EMA callback (tqdne/ema.py; 0.999 in the reference's runs).
+        ``fused_optimizer``: one-launch Adam (+ EMA) instead of torch.optim.Adam; default: on GPUs."""
         self.module = module
         self.world = world_size
         cfg = module.configure_optimizers()
         self.optimizer = cfg["optimizer"]
         self.scheduler = cfg["lr_scheduler"]["scheduler"]
+        on_gpu = next(module.parameters()).device.type == "cuda"
+        self.fused = on_gpu if fused_optimizer is None else fused_optimizer
+        self.ema_decay = ema_decay
+        self._ema = None
+        if self.fused:
+            from .optim import FusedAdamEMA
+            g = self.optimizer.param_groups[0]
+            self.optimizer = FusedAdamEMA(module.named_parameters(), lr=g["lr"], betas=g["betas"], eps=g["eps"],
+                                          ema_decay=ema_decay)
+            op = module.optimizer_params
+            self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=op["max_steps"],
+                                                                        eta_min=op["eta_min"])
+        elif ema_decay is not None:
+            self._ema = {n: p.detach().clone() for n, p in module.named_parameters() if p.requires_grad}
         self.bucket_elems = max(1, bucket_bytes // 4)
         if world_size > 1:
             for p in module.parameters():  # replicas start identical (DDP's initial broadcast, SURVEY C3)
@@ -50,7 +67,24 @@ class DataParallelTrainer:
     def train_step(self, batch):
         """loss, backward (HIP), gradient mean over ranks (one flat buffer, bucketed all-reduce), Adam, cosine LR."""
         loss, flat = self.module.step_and_backward(batch)
-        allreduce_mean_(flat, self.world, self.bucket_elems)
-        self.optimizer.step()
+        if self.fused:
+            # the 1 / world_size of the gradient mean rides in the optimizer launch
+            allreduce_mean_(flat, self.world, self.bucket_elems, scale=False)
+            self.optimizer.step(grad_scale=1.0 / self.world)
+        else:
+            allreduce_mean_(flat, self.world, self.bucket_elems)
+            self.optimizer.step()
+            if self._ema is not None:
+                with torch.no_grad():
+                    named = dict(self.module.named_parameters())
+                    torch._foreach_lerp_(tuple(self._ema.values()), tuple(named[n] for n in self._ema), 1 - self.ema_decay)
         self.scheduler.step()
         return loss
+
+    def ema_state(self):
+        """name -> EMA weights, as the reference's EMA callback stores them in a checkpoint (tqdne/ema.py:50-51)."""
+        if self.fused:
+            return self.optimizer.ema_state()
+        if self._ema is None:
+            raise RuntimeError("constructed without ema_decay")
+        return self._ema
