@@ -218,6 +218,14 @@ typedef struct TqAdamChunk {
 int tq_adam_ema_step(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2, double eps,
                      double inv_bias2_sqrt, double ema_weight, double grad_scale, hipStream_t stream);
 
+/* ---- signal representation either side of the path (representation.py:41-60, MovingAverageEnvelope) ------- */
+/* x (N, C, T) fp32 NCW -> out (N, 2C, T) fp32: channels [0, C) = x / (env + eps), [C, 2C) = log(env + log_eps) - log(log_eps)/2,
+ * env = mean of |x| over [t - W/2, t + (W-1)/2] with zeros outside the signal (np.convolve(..., mode="same")); float64 inside,
+ * like numpy.  Requires window <= T (the reference's np.convolve changes length otherwise) and window <= 4096. */
+int tq_envelope_fwd(const float* x, float* out, int N, int C, int T, int window, double log_eps, double eps, hipStream_t stream);
+/* repr (N, 2C, T) -> waveform (N, C, T): scaled * (exp(log_env + log(log_eps)/2) + eps)   (representation.py:56-59) */
+int tq_envelope_inv(const float* repr, float* out, int N, int C, int T, double log_eps, double eps, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -693,3 +693,77 @@ extern "C" int tq_adam_ema_step(const TqAdamChunk* chunks, int n_chunks, double 
     TQ_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// MovingAverageEnvelope representation (representation.py:41-60).  HBM-bound (4 B in, 8 B out per sample): one workgroup per
+// 1024 positions of one (sample, channel) row; |x| of the tile + window halo is staged in LDS, each thread forms the first
+// window sum of its 4 outputs in float64 and slides it.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int ENV_TILE = 1024;
+
+__global__ __launch_bounds__(256) void envelope_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T,
+                                                           int W, double log_eps, double eps) {
+    extern __shared__ float env_lds[];
+    const int row = blockIdx.y, n = row / C, c = row % C;
+    const int t0 = blockIdx.x * ENV_TILE;
+    const int lo = W / 2, hi = (W - 1) / 2;
+    const float* xr = x + (size_t)row * T;
+    for (int i = threadIdx.x; i < ENV_TILE + W; i += 256) {
+        const int t = t0 - lo + i;
+        env_lds[i] = (t >= 0 && t < T) ? fabsf(xr[t]) : 0.f;
+    }
+    __syncthreads();
+    float* o_scaled = out + ((size_t)n * 2 * C + c) * T;
+    float* o_log = out + ((size_t)n * 2 * C + C + c) * T;
+    const int l0 = threadIdx.x * 4;  // local index of the first output; its window is env_lds[l0 .. l0 + lo + hi]
+    if (t0 + l0 >= T) return;
+    double s = 0.0;
+    for (int j = 0; j <= lo + hi; ++j) s += (double)env_lds[l0 + j];
+    const double half_log = log(log_eps) * 0.5, inv_w = 1.0 / (double)W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + l0 + k;
+        if (t >= T) break;
+        const double env = s * inv_w;
+        o_scaled[t] = (float)((double)xr[t] / (env + eps));
+        o_log[t] = (float)(log(env + log_eps) - half_log);
+        s += (double)env_lds[l0 + k + lo + hi + 1] - (double)env_lds[l0 + k];
+    }
+}
+
+__global__ __launch_bounds__(256) void envelope_inv_kernel(const float* __restrict__ r, float* __restrict__ out, int C, int T,
+                                                           double log_eps, double eps, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int t = (int)(i % T);
+    const size_t row = i / T;
+    const int c = (int)(row % C);
+    const size_t n = row / C;
+    const double scaled = r[(n * 2 * C + c) * T + t];
+    const double log_env = r[(n * 2 * C + C + c) * T + t];
+    out[i] = (float)(scaled * (exp(log_env + log(log_eps) * 0.5) + eps));
+}
+}  // namespace
+
+extern "C" int tq_envelope_fwd(const float* x, float* out, int N, int C, int T, int window, double log_eps, double eps,
+                               hipStream_t stream) {
+    if (!x || !out) return TQ_ERR_ARG;
+    if (N <= 0 || C <= 0 || T <= 0 || window <= 0 || window > T || window > 4096 || !(log_eps > 0.0)) return TQ_ERR_SHAPE;
+    const dim3 grid((T + ENV_TILE - 1) / ENV_TILE, N * C);
+    hipLaunchKernelGGL(envelope_fwd_kernel, grid, dim3(256), (ENV_TILE + window + 1) * sizeof(float), stream, x, out, C, T,
+                       window, log_eps, eps);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_envelope_inv(const float* repr, float* out, int N, int C, int T, double log_eps, double eps,
+                               hipStream_t stream) {
+    if (!repr || !out) return TQ_ERR_ARG;
+    if (N <= 0 || C <= 0 || T <= 0 || !(log_eps > 0.0)) return TQ_ERR_SHAPE;
+    const size_t total = (size_t)N * C * T;
+    hipLaunchKernelGGL(envelope_inv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, repr, out, C, T, log_eps,
+                       eps, total);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
