@@ -292,7 +292,20 @@ def main():
                 pass
         nfe = 2 * args.sample_steps - 1
         work_flop = B * flops_fwd * ((3 if trainer else 0) + (nfe if not args.no_sample else 0))
-        algo_bytes = None
+        # the north star's second fraction: fused-minimum HBM bytes of the whole step over the 8 TB/s roof.
+        # Per sample and forward every conv / attention core reads its input and writes its output once in fp32 (A), weights W
+        # once per call: forward = B*A + W, sample = NFE * forward, train = 3*B*A + 3*W + 7*W (Adam).  A from hooks over the
+        # imported reference.
+        A_W = {"paper": (174.7e6, 62.3e6), "tiny": (74.3e6, 14.2e6)}.get(args.config)
+        hbm_step = None
+        if A_W and T == 4096:
+            A_, W_ = A_W
+            algo_bytes = world * (((3 * B * A_ + 10 * W_) if trainer else 0) + ((nfe * (B * A_ + W_)) if not args.no_sample else 0))
+            gbps = algo_bytes / (dt / args.steps) / 1e9
+            hbm_step = dict(bound="hbm", achieved=gbps, peak=8000.0 * world, unit="GB/s", frac=gbps / (8000.0 * world),
+                            algorithmic_bytes_per_step=algo_bytes,
+                            note="whole step, fused-minimum byte model of SURVEY.md 8d; the step is MFMA-bound (see roofline), "
+                                 "this is the fraction the north star asks to be reported")
         out = {
             "metric": "waveforms/sec (train step + 18-step EDM sample), 3ch x 4096",
             "value": value, "unit": "waveforms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -305,6 +318,7 @@ def main():
             "parts": parts,
             "whole_step_algorithmic_tflops": work_flop / (dt / args.steps) / 1e12,
             "roofline": roofline,
+            "hbm_roofline_whole_step": hbm_step,
         }
         if args.no_train or args.no_sample:
             out["metric"] += " [DEBUG: partial workload, not the headline metric]"
