@@ -21,7 +21,7 @@ class _EDMLossFn(th.autograd.Function):
     """loss = mean(lambda(sigma) * (D(y + sigma*n; sigma) - y)^2)   (reference edm.py:126-134)."""
 
     @staticmethod
-    def forward(ctx, module, sample, eps, unit_noise, cond, *params):
+    def forward(ctx, module, sample, eps, unit_noise, cond, cond_sample, *params):
         lib = _lib.load()
         B = sample.shape[0]
         per = sample[0].numel()
@@ -39,13 +39,14 @@ class _EDMLossFn(th.autograd.Function):
         train = module.training
         _step_counter[0] += 1
         seed = (int(th.initial_seed()) * 1000003 + _step_counter[0]) & 0xFFFFFFFFFFFFFFFF
-        pred = module._denoise_static(bufs["x"], bufs["sigma"], 1, cond, train=train, dropout_seed=seed)
+        pred = module._denoise_static(bufs["x"], bufs["sigma"], 1, cond, train=train, dropout_seed=seed, cond_sample=cond_sample)
         sc = module._scalars(B, dev)
         need_grad = any(p.requires_grad for p in params)
         check(lib.tq_edm_loss(_p(pred), _p(sample), _p(sc[4]), _p(bufs["loss"]), _p(bufs["dpred"]) if need_grad else None, B,
                               per, stream), "edm loss")
         ctx.module, ctx.bufs, ctx.shape, ctx.nparams = module, bufs, tuple(sample.shape), len(params)
         ctx.cond = cond
+        ctx.concat = cond_sample is not None  # the stem then saw a pre-scaled, concatenated input
         return bufs["loss"][0].clone()
 
     @staticmethod
@@ -54,23 +55,24 @@ class _EDMLossFn(th.autograd.Function):
         B, _, T = ctx.shape
         eng = module.unet._engine(B, T, bufs["x"].device)
         sc = module._scalars(B, bufs["x"].device)
-        grads = eng.backward(bufs["dpred"], gloss, c_out=sc[1], in_scale=sc[0])
-        return (None, None, None, None, None) + tuple(grads)
+        grads = eng.backward(bufs["dpred"], gloss, c_out=sc[1], in_scale=None if ctx.concat else sc[0])
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
-def edm_loss_and_grads(module, sample, eps, unit_noise, cond):
+def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None):
     """Fused training step without the autograd round trip: runs the HIP forward and backward back to back and leaves the
     gradients in the backward plan's flat buffer; ``p.grad`` of every UNet parameter is (re)bound to its view of that buffer.
     Returns (loss, flat_gradient_buffer).  Used by DataParallelTrainer (one all-reduce over the flat buffer, no per-parameter
     accumulation kernels)."""
     params = list(module.unet.parameters())
     with th.no_grad():
-        loss = _EDMLossFn.forward(_Ctx, module, sample, eps, unit_noise, cond, *params)
+        loss = _EDMLossFn.forward(_Ctx, module, sample, eps, unit_noise, cond, cond_sample, *params)
         bufs = _Ctx.bufs
         B, _, T = _Ctx.shape
         eng = module.unet._engine(B, T, bufs["x"].device)
         one = th.ones((), device=bufs["x"].device)
-        grads = eng.backward(bufs["dpred"], one, clone=False)
+        sc = module._scalars(B, bufs["x"].device)
+        grads = eng.backward(bufs["dpred"], one, clone=False, c_out=sc[1], in_scale=None if cond_sample is not None else sc[0])
         for p, g in zip(params, grads):
             if g is not None and (p.grad is None or p.grad.data_ptr() != g.data_ptr()):
                 p.grad = g
@@ -81,9 +83,9 @@ class _Ctx:
     """stand-in for the autograd context when the loss Function's forward is driven directly"""
 
 
-def edm_loss(module, sample, eps, unit_noise, cond):
+def edm_loss(module, sample, eps, unit_noise, cond, cond_sample=None):
     params = [p for p in module.unet.parameters()]
-    return _EDMLossFn.apply(module, sample, eps, unit_noise, cond, *params)
+    return _EDMLossFn.apply(module, sample, eps, unit_noise, cond, cond_sample, *params)
 
 
 def denoise_with_grad(module, sample, sigma, cond):

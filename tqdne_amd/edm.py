@@ -111,9 +111,11 @@ class LightningEDM(LightningModule):
             self._scal[key] = s
         return s
 
-    def _denoise_static(self, sample, sigma, sigma_stride, cond, train=False, dropout_seed=0):
+    def _denoise_static(self, sample, sigma, sigma_stride, cond, train=False, dropout_seed=0, cond_sample=None):
         """Fused preconditioned forward (edm.py:105-113); returns the engine's static output buffer.
-        ``sigma``: device tensor; ``sigma_stride`` 1 (per-sample) or 0 (one value shared by the batch)."""
+        ``sigma``: device tensor; ``sigma_stride`` 1 (per-sample) or 0 (one value shared by the batch).
+        ``cond_sample``: conditioning signal concatenated on the channel axis behind the scaled sample (edm.py:108-109); the
+        pre-scale then cannot ride in the stem load (only the first channels are scaled): one elementwise + cat glue op."""
         lib = _lib.load()
         B, _, T = sample.shape
         dev = sample.device
@@ -121,6 +123,11 @@ class LightningEDM(LightningModule):
         stream = th.cuda.current_stream(dev).cuda_stream
         check(lib.tq_edm_scalars(_p(sigma), sigma_stride, float(self.edm.sigma_data), _p(sc[0]), _p(sc[1]), _p(sc[2]),
                                  _p(sc[3]), _p(sc[4]), B, stream), "edm scalars")
+        if cond_sample is not None:
+            x_in = th.cat((sample * sc[0][:, None, None], cond_sample.to(sample.dtype)), dim=1).contiguous()
+            eng = self.unet._engine(B, T, dev)
+            return eng.forward(x_in, sc[3], cond, in_scale=None, c_out=sc[1], c_skip=sc[2], skip_src=sample, train=train,
+                               dropout_seed=dropout_seed)
         eng = self.unet._engine(B, T, dev)
         return eng.forward(sample, sc[3], cond, in_scale=sc[0], c_out=sc[1], c_skip=sc[2], skip_src=sample, train=train,
                            dropout_seed=dropout_seed)
@@ -138,13 +145,10 @@ class LightningEDM(LightningModule):
                 from .autograd import denoise_with_grad
                 return denoise_with_grad(self, sample, sigma, cond)
             return self._denoise_static(sample, sigma, 1, cond).clone()
-        # conditioning signal concatenated on the channel axis (edm.py:109): the pre-scale cannot be folded into the
-        # stem (only the first channels are scaled), so the tiny glue ops run as torch elementwise kernels
-        dim = sample.dim()
-        x_in = th.cat((sample * _append_dims(self.edm.in_scaling(sigma), dim), cond_sample), dim=1)
-        out = self.unet(x_in, self.edm.noise_conditioning(sigma), cond=cond)
-        skip = _append_dims(self.edm.skip_scaling(sigma), dim) * sample
-        return out * _append_dims(self.edm.out_scaling(sigma), dim) + skip
+        if self.training and th.is_grad_enabled():
+            from .autograd import denoise_with_grad
+            return denoise_with_grad(self, sample, sigma, cond)
+        return self._denoise_static(sample, sigma, 1, cond, cond_sample=cond_sample.contiguous()).clone()
 
     # ------------------------------------------------------------------ training
     def step(self, batch, batch_idx):
@@ -162,28 +166,25 @@ class LightningEDM(LightningModule):
 
     def step_with_noise(self, sample, eps, unit_noise, cond=None, cond_sample=None):
         """``step`` with the two random draws of edm.py:126,128 supplied by the caller (tests inject CPU draws)."""
-        if cond_sample is not None:
-            sigma = self.edm.sigma(eps)
-            noise = unit_noise * _append_dims(sigma, sample.dim())
-            pred = self(sample + noise, sigma, cond_sample, cond)
-            loss = (pred - sample) ** 2
-            return th.mean(loss * _append_dims(self.edm.loss_weight(sigma), loss.dim()))
         from .autograd import edm_loss
-        return edm_loss(self, sample.contiguous(), eps.contiguous().float(), unit_noise.contiguous(), cond)
+        return edm_loss(self, sample.contiguous(), eps.contiguous().float(), unit_noise.contiguous(), cond,
+                        None if cond_sample is None else cond_sample.contiguous())
 
     def step_and_backward(self, batch):
         """``step`` + backward in one call, gradients left in ``p.grad`` (views of one flat buffer, returned as well)."""
         from .autograd import edm_loss_and_grads
         sample = batch["signal"]
         cond = batch["cond"] if "cond" in batch else None
-        if "cond_signal" in batch:
-            raise NotImplementedError("cond_signal goes through the autograd path (step)")
+        cond_sample = batch["cond_signal"] if "cond_signal" in batch else None
         if self.autoencoder:
             with th.no_grad():
                 sample = self.autoencoder.encode(sample)
+                if cond_sample is not None:
+                    cond_sample = self.autoencoder.encode(cond_sample)
         eps = th.randn(sample.shape[0], device=sample.device)
         unit_noise = th.randn_like(sample)
-        return edm_loss_and_grads(self, sample.contiguous(), eps, unit_noise, cond)
+        return edm_loss_and_grads(self, sample.contiguous(), eps, unit_noise, cond,
+                                  None if cond_sample is None else cond_sample.contiguous())
 
     def training_step(self, batch, batch_idx):
         loss = self.step(batch, batch_idx)
@@ -232,8 +233,6 @@ class LightningEDM(LightningModule):
     def sample_deterministically(self, eps, sigmas, cond_sample=None, cond=None, use_graph=False):
         """Deterministic Heun sampler (edm.py:171-196): ``eps`` is the fp64 start state (already scaled by sigmas[0]),
         ``sigmas`` the fp32 schedule ending in 0.  NFE = 2*len(sigmas) - 3 when the last sigma is the appended 0."""
-        if cond_sample is not None:
-            return self._sample_generic(eps, sigmas, cond_sample, cond, stochastic=False)
         lib = _lib.load()
         if not eps.is_cuda:
             raise RuntimeError("tqdne_amd samples on MI355X HIP kernels only; got a CPU start state")
@@ -241,6 +240,8 @@ class LightningEDM(LightningModule):
         sigmas = sigmas.to(device=dev, dtype=th.float32).contiguous()
         if cond is not None:
             cond = cond.contiguous().float()
+        if cond_sample is not None:
+            cond_sample = cond_sample.contiguous().float()
         bufs = self._sampler_buffers(eps)
         x, xn, d, x32 = bufs["x"], bufs["xn"], bufs["d"], bufs["x32"]
         x.copy_(eps)
@@ -249,9 +250,9 @@ class LightningEDM(LightningModule):
         nsteps = sigmas.numel() - 1
         sp = sigmas.data_ptr()
         stream = th.cuda.current_stream(dev).cuda_stream
-        denoise = lambda sig_ptr: self._denoise_static(x32, _RawPtr(sig_ptr), 0, cond)
+        denoise = lambda sig_ptr: self._denoise_static(x32, _RawPtr(sig_ptr), 0, cond, cond_sample=cond_sample)
         if use_graph:
-            denoise = self._graph_denoiser(bufs, x32, cond)
+            denoise = self._graph_denoiser(bufs, x32, cond, cond_sample)
         for i in range(nsteps):
             s_i, s_n = sp + 4 * i, sp + 4 * (i + 1)
             den = denoise(s_i)
@@ -263,20 +264,21 @@ class LightningEDM(LightningModule):
                 x, xn = xn, x
         return x.clone()
 
-    def _graph_denoiser(self, bufs, x32, cond):
+    def _graph_denoiser(self, bufs, x32, cond, cond_sample=None):
         """One preconditioned UNet evaluation (~160 launches) captured once in a HIP graph and replayed per NFE; sigma is fed
         through a static device slot.  Pays off when the forward is launch-bound (small batches); at B = 64 the host already
         runs ahead of the GPU."""
         g = bufs.get("graph")
-        if g is None or bufs.get("graph_cond") != (None if cond is None else cond.data_ptr()):
+        key = (None if cond is None else cond.data_ptr(), None if cond_sample is None else cond_sample.data_ptr())
+        if g is None or bufs.get("graph_cond") != key:
             slot = th.zeros(1, device=x32.device)
-            self._denoise_static(x32, slot, 0, cond)  # warm-up outside capture (plan build, weight packing)
+            self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample)  # warm-up outside capture (plan build, packing)
             th.cuda.synchronize(x32.device)
             graph = th.cuda.CUDAGraph()
             with th.cuda.graph(graph):
-                out = self._denoise_static(x32, slot, 0, cond)
+                out = self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample)
             g = (graph, slot, out)
-            bufs["graph"], bufs["graph_cond"] = g, (None if cond is None else cond.data_ptr())
+            bufs["graph"], bufs["graph_cond"] = g, key
         graph, slot, out = g
         elem = slot.element_size()
 
