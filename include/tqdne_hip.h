@@ -202,6 +202,7 @@ int tq_sampler_init(const double* unit_noise, const float* sigma0, double* x, fl
 /* One launch for the whole model: torch.optim.Adam's update (no weight decay, no amsgrad) on every chunk of the table,
  *   g' = g * grad_scale;  m += (1 - beta1) (g' - m);  v = beta2 v + (1 - beta2) g'^2;
  *   p -= step_size * m / (sqrt(v) * inv_bias2_sqrt + eps)       step_size = lr / (1 - beta1^t), inv_bias2_sqrt = 1/sqrt(1 - beta2^t)
+ * preceded by p *= decay_factor (torch.optim.AdamW's decoupled weight decay 1 - lr * wd, autoencoder.py:93-95; 1.0 = Adam) and
  * followed, where ema != NULL, by the EMA callback's lerp  ema += ema_weight * (p - ema)  (ema_weight = 1 - decay).
  * The scalars are doubles (host-side values as torch computes them: 1 - beta in double) and are rounded to fp32 once.
  * `chunks` is a DEVICE array; a chunk is <= TQ_ADAM_CHUNK consecutive elements of one tensor, its pointers 16-byte aligned. */
@@ -216,7 +217,7 @@ typedef struct TqAdamChunk {
     int32_t reserved;
 } TqAdamChunk;
 int tq_adam_ema_step(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2, double eps,
-                     double inv_bias2_sqrt, double ema_weight, double grad_scale, hipStream_t stream);
+                     double inv_bias2_sqrt, double ema_weight, double grad_scale, double decay_factor, hipStream_t stream);
 
 /* ---- signal representation either side of the path (representation.py:41-60, MovingAverageEnvelope) ------- */
 /* x (N, C, T) fp32 NCW -> out (N, 2C, T) fp32: channels [0, C) = x / (env + eps), [C, 2C) = log(env + log_eps) - log(log_eps)/2,

@@ -104,3 +104,14 @@ def encode(sd, enc_cfg, x: Tensor, unit_noise: Tensor, prefix: str = "encoder.")
 
 def decode(sd, dec_cfg, z: Tensor, prefix: str = "decoder.") -> Tensor:
     return decoder_forward(sd, dec_cfg, z, prefix)
+
+
+def step_loss(sd, enc_cfg, dec_cfg, x: Tensor, unit_noise: Tensor, kl_weight: float = 1e-6):
+    """autoencoder.py:59-66 (eval-mode dropout): loss = mean((x - D(z))^2) + kl_weight * mean(KL), with
+    KL = 0.5 * sum_c(mean^2 + exp(2 log_std) - 2 log_std - 1) (autoencoder.py:54-57).  Returns (loss, recon_loss, kl)."""
+    z, mean, log_std = encode(sd, enc_cfg, x, unit_noise)
+    recon = decode(sd, dec_cfg, z)
+    recon_loss = torch.mean((x - recon) ** 2)
+    log_var = 2 * log_std
+    kl = torch.mean(0.5 * torch.sum(mean ** 2 + torch.exp(log_var) - log_var - 1, dim=1))
+    return recon_loss + kl_weight * kl, recon_loss, kl

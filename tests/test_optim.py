@@ -73,3 +73,23 @@ def test_fused_adam_resumes_from_torch_adam_state():
         assert rel_err(ph.detach().cpu(), pr.detach()) < 1e-6
     sd = opt.state_dict()  # torch format out as well
     assert float(sd["state"][0]["step"]) == 4.0 and sd["state"][0]["exp_avg"].shape == ref[0].shape
+
+
+def test_fused_adamw_matches_torch_adamw():
+    """the autoencoder's optimizer (autoencoder.py:93-95): AdamW, weight_decay 1e-4 (here larger, to be visible)"""
+    from tqdne_amd.optim import FusedAdamEMA
+
+    dev = torch.device("cuda:0")
+    ref = [torch.nn.Parameter(t.clone()) for t in _make(2)]
+    hip = [torch.nn.Parameter(t.clone().to(dev)) for t in _make(2)]
+    opt_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.05)
+    opt = FusedAdamEMA([(f"p{i}", p) for i, p in enumerate(hip)], lr=1e-2, weight_decay=0.05)
+    g = torch.Generator().manual_seed(4)
+    for step in range(3):
+        for pr, ph in zip(ref, hip):
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad, ph.grad = gr.clone(), gr.to(dev)
+        opt_ref.step()
+        opt.step()
+    for pr, ph in zip(ref, hip):
+        assert rel_err(ph.detach().cpu(), pr.detach()) < 1e-6

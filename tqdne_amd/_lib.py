@@ -72,7 +72,7 @@ _PROTOS = {
     "tq_sampler_init": (I, [VP] * 4 + [SZ, VP]),
     "tq_envelope_fwd": (I, [VP, VP, I, I, I, I, C.c_double, C.c_double, VP]),
     "tq_envelope_inv": (I, [VP, VP, I, I, I, C.c_double, C.c_double, VP]),
-    "tq_adam_ema_step": (I, [VP, I] + [C.c_double] * 7 + [VP]),
+    "tq_adam_ema_step": (I, [VP, I] + [C.c_double] * 8 + [VP]),
     "tq_conv1d_bwd_data": (I, [VP] * 11),
     "tq_conv1d_bwd_weight_workspace": (SZ, [VP]),
     "tq_conv1d_bwd_weight": (I, [VP] * 8 + [SZ, VP]),

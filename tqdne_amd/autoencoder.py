@@ -3,8 +3,10 @@
 fused HIP kernels as the UNet (un-conditioned ResBlock = the fused convs without the embedding add).
 
 Same constructor keywords and ``state_dict`` schema (``encoder.input_layer``, ``encoder.down_blocks.{i}.*``,
-``encoder.output_layer``, ``decoder.input_layer``, ``decoder.up_blocks.{i}.*``, ``decoder.output_layer``).  Training of the
-autoencoder (``step``: KL + MSE, autoencoder.py:54-84) is a SURVEY section 8f "next" item and raises.
+``encoder.output_layer``, ``decoder.input_layer``, ``decoder.up_blocks.{i}.*``, ``decoder.output_layer``).
+
+Training (``step``: MSE + KL, autoencoder.py:59-84) runs the HIP forward and backward of both networks; the re-parameterisation
+and the two scalar losses are a few elementwise torch ops on the (B, 2 x latent, T / ds) encoder output (1/100 of a conv).
 """
 
 from __future__ import annotations
@@ -31,6 +33,7 @@ class Encoder(nn.Module):
         super().__init__()
         _check(dims, conv_resample)
         self.in_channels, self.out_channels, self.num_heads = in_channels, out_channels, num_heads
+        self.dropout = dropout
         k = conv_kernel_size
         ch = int(channel_mult[0] * model_channels)
         self.input_layer = nn.Conv1d(in_channels, ch, k, padding="same")
@@ -69,6 +72,7 @@ class Decoder(nn.Module):
         super().__init__()
         _check(dims, conv_resample)
         self.in_channels, self.out_channels, self.num_heads = in_channels, out_channels, num_heads
+        self.dropout = dropout
         k = conv_kernel_size
         ch = int(channel_mult[-1] * model_channels)
         self.input_layer = nn.Conv1d(in_channels, ch, k, padding="same")
@@ -106,6 +110,32 @@ def _seq_engine(mod, x):
     return eng
 
 
+_seed = [0]
+
+
+class _AELossFn(th.autograd.Function):
+    """loss = mean((x - D(z))^2) + kl_weight * KL(q(z|x) || N(0, I)),  z = mean + eps * exp(log_std)   (autoencoder.py:59-66).
+    The HIP backward runs eagerly inside ``forward`` (static engine buffers would not survive a second pass, e.g. the
+    ``cond_signal`` term); ``backward`` only scales the stored gradients."""
+
+    @staticmethod
+    def forward(ctx, module, x, stage, prefix, *params):
+        need = any(ctx.needs_input_grad[4:])  # (grad mode is off inside forward; this reflects the caller's)
+        rl, kl, grads = module._loss_and_grads(x, want_grads=need)
+        loss = rl + module.kl_weight * kl
+        module.log(f"{stage}/{prefix}reconstruction_loss", rl.item(), sync_dist=True)
+        module.log(f"{stage}/{prefix}kl_divergence", kl.item(), sync_dist=True)
+        module.log(f"{stage}/{prefix}loss", loss.item(), sync_dist=True)
+        ctx.grads = grads
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        if ctx.grads is None:
+            raise RuntimeError("the loss was computed without gradients")
+        return (None, None, None, None) + tuple(None if g is None else g * gloss for g in ctx.grads)
+
+
 class LightningAutoencoder(LightningModule):
     def __init__(self, encoder_config: dict, decoder_config: dict, optimizer_params: dict, kl_weight: float = 1e-6):
         super().__init__()
@@ -139,8 +169,64 @@ class LightningAutoencoder(LightningModule):
         log_var = 2 * log_std
         return 0.5 * th.sum(mean**2 + th.exp(log_var) - log_var - 1, dim=1)
 
+    # ------------------------------------------------------------------ training (autoencoder.py:59-84)
+    def _loss_and_grads(self, x, unit_noise=None, want_grads=True):
+        """recon_loss, kl, and (if wanted) the gradients of recon_loss + kl_weight * kl wrt every parameter, in
+        ``self.parameters()`` order.  Forward and backward run back to back: the engines' buffers are static."""
+        engine.require_device(x)
+        x = x.contiguous()
+        train = self.training
+        _seed[0] += 1
+        seed = (int(th.initial_seed()) * 1000003 + _seed[0]) & 0xFFFFFFFFFFFFFFFF
+        with th.no_grad():
+            e_eng = _seq_engine(self.encoder, x)
+            enc = e_eng.forward(x, train=train, dropout_seed=seed)
+            mean, log_std = th.chunk(enc, 2, dim=1)
+            eps = th.randn_like(mean) if unit_noise is None else unit_noise
+            std = th.exp(log_std)
+            z = (mean + eps * std).contiguous()
+            d_eng = _seq_engine(self.decoder, z)
+            recon = d_eng.forward(z, train=train, dropout_seed=seed ^ 0x9E3779B97F4A7C15)
+            diff = recon - x
+            recon_loss = th.mean(diff * diff)
+            kl = th.mean(0.5 * th.sum(mean * mean + std * std - 2 * log_std - 1, dim=1))
+            if not want_grads:
+                return recon_loss, kl, None
+            g_dec, dz = d_eng.backward(diff * (2.0 / diff.numel()), want_dx=True, clone=True)
+            n_kl = mean.shape[0] * mean.shape[2]  # kl is a mean over (batch, time) of a sum over channels
+            d_mean = dz + mean * (self.kl_weight / n_kl)
+            d_ls = dz * eps * std + (std * std - 1.0) * (self.kl_weight / n_kl)
+            g_enc, _ = e_eng.backward(th.cat((d_mean, d_ls), dim=1), want_dx=False, clone=True)
+        return recon_loss, kl, list(g_enc) + list(g_dec)
+
     def step(self, batch, stage="training"):
-        raise NotImplementedError("autoencoder training (autoencoder.py:54-84) is not part of the accelerated path yet")
+        x = batch["signal"]
+        loss = _AELossFn.apply(self, x, stage, "", *self.parameters())
+        if "cond_signal" not in batch:
+            return loss
+        return loss + _AELossFn.apply(self, batch["cond_signal"], stage, "cond_", *self.parameters())
+
+    def step_and_backward(self, batch):
+        """``step`` + backward without the autograd round trip: gradients are left in ``p.grad`` (DataParallelTrainer)."""
+        xs = [batch["signal"]] + ([batch["cond_signal"]] if "cond_signal" in batch else [])
+        total, grads = None, None
+        for x in xs:
+            rl, kl, g = self._loss_and_grads(x)
+            loss = rl + self.kl_weight * kl
+            total = loss if total is None else total + loss
+            grads = g if grads is None else [a if b is None else (b if a is None else a + b) for a, b in zip(grads, g)]
+        flats = []
+        for p, g in zip(self.parameters(), grads):
+            if g is not None:
+                p.grad = g
+                flats.append(g)
+        return total, flats
+
+    def training_step(self, batch, batch_idx):
+        return self.step(batch, stage="training")
+
+    def validation_step(self, batch, batch_idx):
+        return self.step(batch, stage="validation")
 
     def configure_optimizers(self):
         optimizer = th.optim.AdamW(self.parameters(), lr=self.optimizer_params["learning_rate"], weight_decay=1e-4)

@@ -644,15 +644,17 @@ extern "C" int tq_sampler_init(const double* unit_noise, const float* sigma0, do
 // ------------------------------------------------------------------------------------------------
 namespace {
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float step_size, float omb1, float b2, float omb2,
-                                      float eps, float ibc2, float gscale) {
+                                      float eps, float ibc2, float gscale, float decay) {
     g *= gscale;
+    p *= decay;  // AdamW's decoupled weight decay (1 - lr * wd); 1 for plain Adam
     m = fmaf(omb1, g - m, m);
     v = fmaf(omb2, g * g, b2 * v);
     p -= step_size * (m / (sqrtf(v) * ibc2 + eps));
 }
 
 __global__ __launch_bounds__(256) void adam_ema_kernel(const TqAdamChunk* __restrict__ chunks, float step_size, float omb1, float b2,
-                                                       float omb2, float eps, float ibc2, float ema_w, float gscale) {
+                                                       float omb2, float eps, float ibc2, float ema_w, float gscale,
+                                                       float decay) {
     const TqAdamChunk c = chunks[blockIdx.x];
     const int n4 = c.n & ~3;
     for (int i = threadIdx.x * 4; i < n4; i += 256 * 4) {
@@ -660,10 +662,10 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(const TqAdamChunk* __rest
         const float4 g = *reinterpret_cast<const float4*>(c.g + i);
         float4 m = *reinterpret_cast<const float4*>(c.m + i);
         float4 v = *reinterpret_cast<const float4*>(c.v + i);
-        adam1(p.x, g.x, m.x, v.x, step_size, omb1, b2, omb2, eps, ibc2, gscale);
-        adam1(p.y, g.y, m.y, v.y, step_size, omb1, b2, omb2, eps, ibc2, gscale);
-        adam1(p.z, g.z, m.z, v.z, step_size, omb1, b2, omb2, eps, ibc2, gscale);
-        adam1(p.w, g.w, m.w, v.w, step_size, omb1, b2, omb2, eps, ibc2, gscale);
+        adam1(p.x, g.x, m.x, v.x, step_size, omb1, b2, omb2, eps, ibc2, gscale, decay);
+        adam1(p.y, g.y, m.y, v.y, step_size, omb1, b2, omb2, eps, ibc2, gscale, decay);
+        adam1(p.z, g.z, m.z, v.z, step_size, omb1, b2, omb2, eps, ibc2, gscale, decay);
+        adam1(p.w, g.w, m.w, v.w, step_size, omb1, b2, omb2, eps, ibc2, gscale, decay);
         *reinterpret_cast<float4*>(c.p + i) = p;
         *reinterpret_cast<float4*>(c.m + i) = m;
         *reinterpret_cast<float4*>(c.v + i) = v;
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(const TqAdamChunk* __rest
     const int i = n4 + threadIdx.x;
     if (i < c.n) {
         float p = c.p[i], m = c.m[i], v = c.v[i];
-        adam1(p, c.g[i], m, v, step_size, omb1, b2, omb2, eps, ibc2, gscale);
+        adam1(p, c.g[i], m, v, step_size, omb1, b2, omb2, eps, ibc2, gscale, decay);
         c.p[i] = p; c.m[i] = m; c.v[i] = v;
         if (c.ema) c.ema[i] = fmaf(ema_w, p - c.ema[i], c.ema[i]);
     }
@@ -685,11 +687,13 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(const TqAdamChunk* __rest
 }  // namespace
 
 extern "C" int tq_adam_ema_step(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2, double eps,
-                                double inv_bias2_sqrt, double ema_weight, double grad_scale, hipStream_t stream) {
+                                double inv_bias2_sqrt, double ema_weight, double grad_scale, double decay_factor,
+                                hipStream_t stream) {
     if (!chunks || n_chunks < 0) return TQ_ERR_ARG;
     if (n_chunks == 0) return 0;
     hipLaunchKernelGGL(adam_ema_kernel, dim3(n_chunks), dim3(256), 0, stream, chunks, (float)step_size, (float)(1.0 - beta1),
-                       (float)beta2, (float)(1.0 - beta2), (float)eps, (float)inv_bias2_sqrt, (float)ema_weight, (float)grad_scale);
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, (float)inv_bias2_sqrt, (float)ema_weight, (float)grad_scale,
+                       (float)decay_factor);
     TQ_CHECK_LAUNCH();
     return 0;
 }

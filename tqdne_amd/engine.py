@@ -496,16 +496,23 @@ class SeqEngine(UNetEngine):
         else:  # wide output (encoder: 2 x latent channels): fused conv to channels-last, then a layout flip
             self.out_mode = "conv"
             self.out_btc = self._conv([h], self._site("output_layer", out), stats=False)
+            self.out_rec = self.last_rec
 
-    def forward(self, x):
+    def forward(self, x, train: bool = False, dropout_seed: int = 0):
         m, lib, B, T = self.m, self.lib, self.B, self.T
         if tuple(x.shape) != (B, m.in_channels, T):
             raise ValueError(f"plan was built for {(B, m.in_channels, T)}, got {tuple(x.shape)}")
         x = x.contiguous()
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         self.repack(stream)
+        p = float(getattr(m, "dropout", 0.0)) if train else 0.0
         for d in self.dropout_descs:
-            d.flags &= ~TQ_CONV_DROPOUT
+            if p > 0.0:
+                d.flags |= TQ_CONV_DROPOUT
+                d.dropout_p, d.dropout_seed = p, dropout_seed
+            else:
+                d.flags &= ~TQ_CONV_DROPOUT
+        self._last = dict(x=x, train=train, dropout_p=p, dropout_seed=dropout_seed)
         stem = m.input_layer
         check(lib.tq_stem_conv_fwd(_p(x), None, _p(stem.weight), _p(stem.bias), _p(self.stem_out.buf), _p(self.stem_out.stats), B,
                                    m.in_channels, T, stem.out_channels, stem.kernel_size[0], stream), "input layer")
@@ -521,3 +528,11 @@ class SeqEngine(UNetEngine):
         else:
             self.out_nct.copy_(self.out_btc.buf.permute(0, 2, 1))  # (B,T,C) -> (B,C,T): 1/60 of the encoder's traffic
         return self.out_nct
+
+    def backward(self, dout: torch.Tensor, want_dx: bool = False, clone: bool = True):
+        """Gradients of every parameter of the Encoder / Decoder for d loss / d output = ``dout`` (B, C_out, T_out), for the
+        last forward; with ``want_dx`` also d loss / d input (B, C_in, T).  Returns (list aligned with parameters(), dx|None)."""
+        from .engine_bwd import SeqBackwardPlan
+        if self._bwd is None:
+            self._bwd = SeqBackwardPlan(self)
+        return self._bwd.run_seq(dout, want_dx=want_dx, clone=clone)

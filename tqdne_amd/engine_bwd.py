@@ -353,3 +353,116 @@ class BackwardPlan:
             dc0 = torch.mm(d_emb, cm[2].weight) * dsilu(c0)
             torch.mm(dc0.t(), last["cond"], out=self.g(cm[0].weight))
             torch.sum(dc0, dim=0, out=self.g(cm[0].bias))
+
+
+class SeqBackwardPlan(BackwardPlan):
+    """Backward plan of a SeqEngine (VAE Encoder / Decoder, blocks.py:263-436; autoencoder.py:59-84): the same block
+    emitters, no embedding, a plain output conv instead of the GN-SiLU head, and optionally the gradient wrt the input
+    (the decoder's d latent feeds the encoder).  The input layer is differentiated as a generic fused conv over a
+    channels-last copy of the input padded to 32 channels (the packer zero-fills the missing weight rows / k entries)."""
+
+    def _build(self):
+        from ._lib import TqConvDesc
+        from .engine import Act, ConvRec, ConvSite
+        e, m, lib, B = self.e, self.m, self.lib, self.B
+        self._wgrad_ops = []
+        if not hasattr(e, "dgrad_sites"):
+            e.dgrad_sites = []
+        for a in e.acts:
+            a.gw = False
+        final, out = e.final, m.output_layer
+        dfin = self.grad(final)
+        if e.out_mode == "head":   # narrow output (decoder): VALU kernel straight from the NCW gradient
+            self.head_op = [lib.tq_head_conv_bwd, [None, None, _p(final.buf), None, None, _p(out.weight), _p(dfin), None,
+                                                   _p(self.g(out.weight)), _p(self.g(out.bias)), B, final.T, final.C,
+                                                   out.out_channels, out.kernel_size[0]], "output layer bwd"]
+            self.dout_btc = None
+        else:                      # wide output (encoder): generic conv gradients from a channels-last copy of d out
+            self.head_op = None
+            self.dout_btc = self._empty(B, final.T, out.out_channels)
+            self._wgrad(e.out_rec, self.dout_btc)
+            self._dgrad(e.out_rec, self.dout_btc, final.T, [dfin], accumulate=False, chain=False)
+        final.gw = True
+        for kind, t in reversed(e.tape):
+            getattr(self, "_bwd_" + kind)(t)
+        # ---- input layer: generic conv over a (B, T, 32) channels-last copy of the input
+        stem, so = m.input_layer, e.stem_out
+        assert so.gw
+        cin, K = stem.in_channels, stem.kernel_size[0]
+        self.x_btc = Act(self._empty(B, so.T, 32), None, 32, so.T)
+        self.x_btc.buf.zero_()
+        site = ConvSite("input_layer", stem.weight, stem.bias, self.dev, lib)
+        site.C_in = 32  # descriptor / packed geometry see the padded input; pack kernels guard the real (C_out, cin, K) weight
+        d = TqConvDesc()
+        d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, so.T, so.T, 32, 0, stem.out_channels
+        d.ktaps, d.stride, d.pad, d.upsample, d.flags = K, 1, K // 2, 0, 0
+        self._keep.append(d)
+        rec = ConvRec(site, d, [self.x_btc], None, so, 1, False, False, False)
+        self.dw_stem32 = self._empty(stem.out_channels, 32, K)
+        need = lib.tq_conv1d_bwd_weight_workspace(C.byref(d))
+        self.ws_bytes = max(getattr(self, "ws_bytes", 0), need)
+        self._wgrad_ops.append(len(self.ops))
+        self.ops.append([lib.tq_conv1d_bwd_weight, [C.byref(d), _p(so.grad), _p(self.x_btc.buf), None, None, None,
+                                                    _p(self.dw_stem32), None, 0], "wgrad:input_layer"])
+        self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None, None], "colsum:stem"])
+        # d input (only run on request): transposed conv into a 32-channel channels-last buffer
+        self.dx_btc = self._empty(B, so.T, 32)
+        n0 = len(self.ops)
+        site.packed_t = torch.empty(lib.tq_conv_weight_pack_bytes(stem.out_channels, cin, K, 1), dtype=torch.uint8, device=self.dev)
+        self.stem_site = site
+        bd = TqConvBwdDesc()
+        bd.B, bd.T, bd.C_dy, bd.C_dx0, bd.C_dx1, bd.ktaps, bd.flags = B, so.T, stem.out_channels, 32, 0, K, 0
+        self._keep.append(bd)
+        self.dx_op = [lib.tq_conv1d_bwd_data, [C.byref(bd), _p(so.grad), _p(site.packed_t), None, None, None, None,
+                                               _p(self.dx_btc), None, None], "dgrad:input_layer"]
+        assert len(self.ops) == n0
+        self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=self.dev)
+        for i in self._wgrad_ops:
+            self.ops[i][1][7] = self.ws.data_ptr()
+            self.ops[i][1][8] = self.ws.numel()
+
+    def run_seq(self, dout: torch.Tensor, want_dx: bool = False, clone: bool = True):
+        e, m, lib = self.e, self.m, self.lib
+        last = e._last
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        e.repack_transposed(stream)
+        stem = m.input_layer
+        cin, K = stem.in_channels, stem.kernel_size[0]
+        if want_dx:
+            check(lib.tq_pack_conv_weight(stem.weight.data_ptr(), stem.out_channels, cin, K, 1, self.stem_site.packed_t.data_ptr(),
+                                          stream), "pack^T input_layer")
+        self.flat.zero_()
+        p, seed = float(last["dropout_p"]), int(last["dropout_seed"])
+        for d, fd in self.bwd_dropout_descs:
+            if p > 0.0:
+                d.flags |= TQ_BWD_DROPOUT
+                d.dropout_p, d.dropout_seed = p, seed
+            else:
+                d.flags &= ~TQ_BWD_DROPOUT
+        dout = dout.contiguous()
+        self.x_btc.buf[:, :, :cin].copy_(last["x"].permute(0, 2, 1))
+        if self.head_op is not None:
+            fn, args, what = self.head_op
+            args[0] = dout.data_ptr()
+            check(fn(*args, stream), what)
+        else:
+            self.dout_btc.copy_(dout.permute(0, 2, 1))
+        for fn, args, what in self.ops:
+            rc = fn(*args, stream)
+            if rc:
+                check(rc, what)
+        self.g(stem.weight).copy_(self.dw_stem32[:, :cin, :])
+        dx = None
+        if want_dx:
+            fn, args, what = self.dx_op
+            check(fn(*args, stream), what)
+            dx = self.dx_btc[:, :, :cin].permute(0, 2, 1).contiguous()
+        out = self.flat.clone() if clone else self.flat
+        res = []
+        for p_ in self.param_order:
+            if not p_.requires_grad:
+                res.append(None)
+            else:
+                o = self.offs[id(p_)]
+                res.append(out[o:o + p_.numel()].view_as(p_))
+        return res, dx

@@ -22,12 +22,13 @@ from ._lib import TQ_ADAM_CHUNK, TqAdamChunk, check
 
 class FusedAdamEMA(torch.optim.Optimizer):
     def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8, ema_decay: Optional[float] = None):
+                 eps: float = 1e-8, ema_decay: Optional[float] = None, weight_decay: float = 0.0):
+        """``weight_decay`` > 0 gives torch.optim.AdamW (decoupled decay), the autoencoder's optimizer (autoencoder.py:93-95)."""
         named = [(n, p) for n, p in named_params if p.requires_grad]
         if not named:
             raise ValueError("no trainable parameters")
         self._names = [n for n, _ in named]
-        super().__init__([p for _, p in named], dict(lr=lr, betas=tuple(betas), eps=eps))
+        super().__init__([p for _, p in named], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.ema_decay = ema_decay
         self._lib = _lib.load()  # raises when the HIP library is missing: there is no fallback update
         ps = self.param_groups[0]["params"]
@@ -111,7 +112,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
         ema_w = 0.0 if self.ema_decay is None else 1.0 - self.ema_decay
         stream = torch.cuda.current_stream(self._m.device).cuda_stream
         check(self._lib.tq_adam_ema_step(self._table.data_ptr(), self._n_chunks, step_size, b1, b2, g["eps"], ibc2, ema_w,
-                                         grad_scale, stream), "adam")
+                                         grad_scale, 1.0 - g["lr"] * g["weight_decay"], stream), "adam")
         for st in self.state.values():
             st["step"] = torch.tensor(float(t))
         return loss
@@ -132,5 +133,5 @@ class FusedAdamEMA(torch.optim.Optimizer):
         for st_p in self.state.values():
             st_p["step"] = torch.tensor(float(self._step))
         for k, v in state_dict["param_groups"][0].items():
-            if k in ("lr", "betas", "eps", "initial_lr"):
+            if k in ("lr", "betas", "eps", "initial_lr", "weight_decay"):
                 self.param_groups[0][k] = v

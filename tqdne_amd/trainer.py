@@ -9,17 +9,22 @@ import torch
 import torch.distributed as dist
 
 
-def allreduce_mean_(flat: torch.Tensor, world_size: int, bucket_elems: int = 8 << 20, scale: bool = True):
+def allreduce_mean_(flat, world_size: int, bucket_elems: int = 8 << 20, scale: bool = True):
     """In-place mean of ``flat`` over all ranks: a few large bucketed all-reduces (RCCL over xGMI on GPUs, gloo in the
     CPU tests), launched asynchronously and waited together, then one scale.  62 MB of gradients = 2 buckets of 32 MB."""
     if world_size <= 1:
         return flat
-    works = [dist.all_reduce(flat[i:i + bucket_elems], op=dist.ReduceOp.SUM, async_op=True)
-             for i in range(0, flat.numel(), bucket_elems)]
+    flats = list(flat) if isinstance(flat, (list, tuple)) else [flat]  # (the autoencoder step returns per-tensor gradients)
+    works = []
+    for f in flats:
+        f1 = f.view(-1)
+        works += [dist.all_reduce(f1[i:i + bucket_elems], op=dist.ReduceOp.SUM, async_op=True)
+                  for i in range(0, f1.numel(), bucket_elems)]
     for w in works:
         w.wait()
     if scale:
-        flat.mul_(1.0 / world_size)
+        for f in flats:
+            f.mul_(1.0 / world_size)
     return flat
 
 
@@ -52,8 +57,9 @@ class DataParallelTrainer:
         if self.fused:
             from .optim import FusedAdamEMA
             g = self.optimizer.param_groups[0]
+            wd = g.get("weight_decay", 0.0) if isinstance(self.optimizer, torch.optim.AdamW) else 0.0
             self.optimizer = FusedAdamEMA(module.named_parameters(), lr=g["lr"], betas=g["betas"], eps=g["eps"],
-                                          ema_decay=ema_decay)
+                                          ema_decay=ema_decay, weight_decay=wd)
             op = module.optimizer_params
             self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=op["max_steps"],
                                                                         eta_min=op["eta_min"])
