@@ -22,6 +22,8 @@
 //     conflict-free for any tap shift.  The K taps are row shifts of the same LDS image (no im2col).
 //   * double-buffered LDS, global loads for chunk c+1 issued before the MFMAs of chunk c.
 //   * epilogue: accumulator lane = 4 consecutive co at one t -> one 16-byte store per 16x16 tile.
+#include <type_traits>
+
 #include "common.hpp"
 #include "../../include/tqdne_hip.h"
 
@@ -228,14 +230,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
     };
 
-    auto stage_hosted = [](int it) constexpr -> bool {
-#ifdef TQ_INTERLEAVE
-        return (KT == 5 || KT == 3) && it >= 0;
-#else
-        (void)it;
-        return false;
-#endif
-    };
     // phase 1 (before the MFMAs of the previous chunk): issue the first PRE iterations' loads
     auto stage_load = [&](int chunk) __attribute__((always_inline)) {
         int cs;
@@ -250,10 +244,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     };
 
     // phase 2 (after them): transform + LDS write; iterations beyond PRE are loaded here in small batches
-    auto stage_write = [&](int chunk, int buf, bool hosted_done) __attribute__((always_inline)) {
+    auto stage_write = [&](int chunk, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < C::PRE; ++it)
-            if (!(hosted_done && stage_hosted(it))) write_one(chunk, buf, it, raw[it]);
+            write_one(chunk, buf, it, raw[it]);
         if (C::NIT > C::PRE) {
             int cs;
             const float* base = chunk_base(chunk, cs);
@@ -298,6 +292,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         }
     };
 
+    // LDS image: row = 64 B = 4 slots of 16 B (one k-quarter each), slot' = kq ^ (2 * ((row >> 2) & 1)): conflict-free for
+    // ds_read_b128 at every row offset (tap shift) and for the 8-byte staging stores.  Row of t-block tb is rowk + 16*tb, which
+    // leaves the swizzle term unchanged: one address per tap, t-blocks are immediate offsets.
+    auto tap_base = [&](int k) -> int __attribute__((always_inline)) {
+        const int rowk = (STRIDE == 1) ? (tl_lane + k) : ((k & 1) * (C::NT + 1) + tl_lane + (k >> 1));
+        return rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
+    };
     auto read_b = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int b0, int tb, Frag& bh, Frag& bl)
         __attribute__((always_inline)) {
 #ifdef TQ_ABL_NOLDS
@@ -310,98 +311,76 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         bl.u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);
     };
 
-    auto mma_tap = [&](int k, const unsigned char* hi_plane, const unsigned char* lo_plane, const Frag (&ah)[2],
-                       const Frag (&al)[2], int nv) __attribute__((always_inline)) {
-        // LDS image: row = 64 B = 4 slots of 16 B (one k-quarter each), slot' = kq ^ (2 * ((row >> 2) & 1)): conflict-free for
-        // ds_read_b128 at every row offset (tap shift) and for the 8-byte staging stores.  Row of t-block tb is rowk + 16*tb,
-        // which leaves the swizzle term unchanged: one address per tap, t-blocks are immediate offsets.
-        const int rowk = (STRIDE == 1) ? (tl_lane + k) : ((k & 1) * (C::NT + 1) + tl_lane + (k >> 1));
-        const int b0 = rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
 #ifndef TQ_LDS_DEPTH
 #define TQ_LDS_DEPTH 2
 #endif
-        // fragment reads run TQ_LDS_DEPTH t-blocks ahead of the MFMAs that consume them (6 MFMAs = 96 cycles per t-block do
-        // not cover the LDS latency under load with a single block of lookahead)
+    // Weight fragments live in two register buffers (taps alternate a, b, a, ...); after tap k its buffer is refilled with
+    // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
+    // b = tap 1 already in flight.
+    Frag wa_h[2], wa_l[2], wb_h[2], wb_l[2];
+
+    // MFMA phase of one chunk = ONE stream of NTAPS x 8 (tap, t-block) steps.  B fragments are read TQ_LDS_DEPTH steps ahead of
+    // the 6 MFMAs that consume them, across tap boundaries too (a per-tap restart exposed the LDS latency KT times per chunk).
+    auto mma_stream = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int s0, auto ntaps_c, auto first_tap_c)
+        __attribute__((always_inline)) {
+        constexpr int NTAPS = decltype(ntaps_c)::value, K0 = decltype(first_tap_c)::value;
+        constexpr int DEP = TQ_LDS_DEPTH, NB = TQ_LDS_DEPTH + 1, NS = NTAPS * 8;
+        Frag bh[NB], bl[NB];
+        int b0 = tap_base(K0), b0n = b0;
+#pragma unroll
+        for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bh[t], bl[t]);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int kk = st >> 3, tb = st & 7;
+            if (tb == 0 && kk + 1 < NTAPS) b0n = tap_base(K0 + kk + 1);
+            const int sn = st + DEP;  // step whose fragments are requested now
+            if (sn < NS) read_b(hi_plane, lo_plane, (sn >> 3) == kk ? b0 : b0n, sn & 7, bh[sn % NB], bl[sn % NB]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk & 1) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk)
+                    acc[cbk][tb] = mfma_x3(wb_h[cbk].v, wb_l[cbk].v, bh[st % NB].v, bl[st % NB].v, acc[cbk][tb]);
+            } else {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk)
+                    acc[cbk][tb] = mfma_x3(wa_h[cbk].v, wa_l[cbk].v, bh[st % NB].v, bl[st % NB].v, acc[cbk][tb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tb == 7) {  // tap done: refill its weight buffer two steps of the (chunk, tap) sequence ahead
+                const int nxt = (NTAPS == 1) ? (s0 + 1) : ((kk + 2 < NTAPS) ? (s0 + kk + 2) : ((kk & 1) ? (s0 + NTAPS + 1) : (s0 + NTAPS)));
+                if (kk & 1) load_w(nxt, wb_h, wb_l); else load_w(nxt, wa_h, wa_l);
+                b0 = b0n;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    auto compute = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const unsigned char* hi_plane = lds + buf * C::BUF;
+        mma_stream(hi_plane, hi_plane + C::PLANE, chunk * KT, std::integral_constant<int, KT>{}, std::integral_constant<int, 0>{});
+    };
+
+    // skip stage j: one (centre) tap.  Buffer a holds this step's weights and b the next one's (the last main chunk's
+    // wrap-around refills fetched skip steps 0 / 1 as "next chunk, taps 0 / 1"); the single-tap stream refills a with step + 1
+    // -- which b already holds -- so b is shifted into a and refilled instead: every buffer access stays statically indexed
+    // (a pointer select between a and b would demote both to scratch)
+    auto compute_skip = [&](int j, int buf) __attribute__((always_inline)) {
+        const unsigned char* hi_plane = lds + buf * C::BUF;
+        const unsigned char* lo_plane = hi_plane + C::PLANE;
         constexpr int DEP = TQ_LDS_DEPTH, NB = TQ_LDS_DEPTH + 1;
         Frag bh[NB], bl[NB];
+        const int b0 = tap_base(C::PAD);
 #pragma unroll
         for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bh[t], bl[t]);
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
             if (tb + DEP < 8) read_b(hi_plane, lo_plane, b0, tb + DEP, bh[(tb + DEP) % NB], bl[(tb + DEP) % NB]);
-#ifndef TQ_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
-                acc[cbk][tb] = mfma_x3(ah[cbk].v, al[cbk].v, bh[tb % NB].v, bl[tb % NB].v, acc[cbk][tb]);
-#ifndef TQ_INTERLEAVE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-#ifdef TQ_INTERLEAVE
-        // issue order inside the tap: fragment reads one t-block ahead, and after every MFMA up to `nv` VALU instructions of
-        // the staging transform hosted by this tap (they issue in the shadow of the 16-cycle MFMA instead of after the phase)
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
-            if (tb + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (nv == 1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                else if (nv == 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                else if (nv >= 3) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            }
-        }
-#else
-        (void)nv;
-#endif
-    };
-
-    // Weight fragments live in two register buffers (taps alternate a, b, a, ...); after tap k its buffer is refilled with
-    // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
-    // b = tap 1 already in flight.
-    Frag wa_h[2], wa_l[2], wb_h[2], wb_l[2];
-    // tap of the current chunk whose MFMAs host the transform of staging iteration `it` of the NEXT chunk (TQ_INTERLEAVE);
-    // the global loads of those iterations are issued right before tap 0, so the first tap(s) are left for them to land
-    auto stage_tap = [](int it) constexpr -> int {
-#ifdef TQ_INTERLEAVE
-        return KT == 5 ? (it < 2 ? 2 : (it < 4 ? 3 : 4)) : (KT == 3 ? (it < 2 ? 1 : 2) : -1);
-#else
-        (void)it;
-        return -1;
-#endif
-    };
-    auto compute = [&](int chunk, int buf, bool stage_next) __attribute__((always_inline)) {
-        const unsigned char* hi_plane = lds + buf * C::BUF;
-        const unsigned char* lo_plane = hi_plane + C::PLANE;
-        const int s0 = chunk * KT;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            int nhost = 0;
-#pragma unroll
-            for (int it = 0; it < C::PRE; ++it)
-                if (stage_tap(it) == k) {
-                    ++nhost;
-                    if (stage_next) write_one(chunk + 1, buf ^ 1, it, raw[it]);
-                }
-            const int nv = (nhost * 56 + 47) / 48;
-            if (k & 1) mma_tap(k, hi_plane, lo_plane, wb_h, wb_l, nv);
-            else       mma_tap(k, hi_plane, lo_plane, wa_h, wa_l, nv);
-            const int nxt = (KT == 1) ? (s0 + 1) : ((k + 2 < KT) ? (s0 + k + 2) : ((k & 1) ? (s0 + KT + 1) : (s0 + KT)));
-            if (k & 1) load_w(nxt, wb_h, wb_l); else load_w(nxt, wa_h, wa_l);
+                acc[cbk][tb] = mfma_x3(wa_h[cbk].v, wa_l[cbk].v, bh[tb % NB].v, bl[tb % NB].v, acc[cbk][tb]);
             __builtin_amdgcn_sched_barrier(0);
         }
-    };
-
-    // skip stage j: one (centre) tap. Buffer a holds this step's weights and b the next one's (the last main chunk's
-    // wrap-around refills fetched skip steps 0 / 1 as "next chunk, taps 0 / 1"); b is shifted into a afterwards, which
-    // keeps every buffer access statically indexed (a pointer select between a and b would demote both to scratch)
-    auto compute_skip = [&](int j, int buf) __attribute__((always_inline)) {
-        const unsigned char* hi_plane = lds + buf * C::BUF;
-        const unsigned char* lo_plane = hi_plane + C::PLANE;
-        mma_tap(C::PAD, hi_plane, lo_plane, wa_h, wa_l, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) { wa_h[i] = wb_h[i]; wa_l[i] = wb_l[i]; }
         load_w(nchunks * KT + j + 2, wb_h, wb_l);
@@ -414,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         load_w(0, wa_h, wa_l);
         if (KT > 1 || nskip > 0) load_w(1, wb_h, wb_l);
     }
-    stage_write(0, 0, false);
+    stage_write(0, 0);
     __syncthreads();
 #ifdef TQ_STAMP
     unsigned long long s_load = 0, s_mma = 0, s_write = 0, s_bar = 0;
@@ -431,12 +410,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #endif
         TQ_T(tB)
         if (wave_active) {
-            if (!FUSE || c < nchunks) compute(c, c & 1, true);
+            if (!FUSE || c < nchunks) compute(c, c & 1);
             else compute_skip(c - nchunks, c & 1);
         }
         TQ_T(tC)
 #ifndef TQ_ABL_NOSTAGE
-        stage_write(c + 1, (c + 1) & 1, wave_active && (!FUSE || c < nchunks));
+        stage_write(c + 1, (c + 1) & 1);
 #endif
         TQ_T(tD)
         __syncthreads();
@@ -446,7 +425,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #endif
     }
     if (wave_active) {
-        if (!FUSE || nskip == 0) compute(nstages - 1, (nstages - 1) & 1, false);
+        if (!FUSE || nskip == 0) compute(nstages - 1, (nstages - 1) & 1);
         else compute_skip(nskip - 1, (nstages - 1) & 1);
     }
 #ifdef TQ_STAMP
