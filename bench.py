@@ -193,6 +193,7 @@ def main():
         dist.barrier()
     from tqdne_amd import LightningEDM, paper_1d_unet_config, tiny_1d_unet_config
     from tqdne_amd.trainer import DataParallelTrainer
+    from tqdne_amd.edm import sampler_lanes
 
     cfg = paper_1d_unet_config() if args.config == "paper" else tiny_1d_unet_config()
     B, T = args.batch, args.length
@@ -314,7 +315,7 @@ def main():
             "config": {"workload": f"{args.config} 1-D EDM UNet ({sum(p.numel() for p in edm.unet.parameters())} params), "
                                    f"B={B}/GPU, 3x{T}: 1 train step (dropout 0.1, Adam, cosine LR) + {args.sample_steps}-step "
                                    f"Heun sample ({nfe} NFE)", "global_batch": world * B, "parallelism": f"dp{world}",
-                       "hip_graph": use_graph},
+                       "hip_graph": use_graph, "sampler_lanes": 1 if use_graph else sampler_lanes(B)},
             "parts": parts,
             "whole_step_algorithmic_tflops": work_flop / (dt / args.steps) / 1e12,
             "roofline": roofline,

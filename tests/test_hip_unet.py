@@ -249,6 +249,22 @@ def test_cond_signal_step_and_denoise_vs_oracle():
     assert rel_err(out.cpu(), ref) < TOL
 
 
+def test_two_lane_sampler_is_bit_identical():
+    """half batches on two streams (lanes=2, the default for B >= 16) integrate exactly the same per-sample arithmetic"""
+    edm, d = _edm_pair(4)
+    from oracle import edm as OE
+    sig = OE.sampling_sigmas(OE.EDMParams(), 4).to(dev())
+    g = torch.Generator().manual_seed(31)
+    B = 16
+    start = torch.randn(B, 3, 256, generator=g, dtype=torch.float64).to(dev()) * sig[0]
+    cond = torch.randn(B, 5, generator=g).to(dev())
+    one = edm.sample_deterministically(start, sig, None, cond, lanes=1)
+    two = edm.sample_deterministically(start, sig, None, cond, lanes=2)
+    four = edm.sample_deterministically(start, sig, None, cond, lanes=4)  # 4 per lane < 8: falls back to one lane
+    assert torch.equal(one, two) and torch.equal(one, four)
+    assert torch.isfinite(one).all()
+
+
 def test_autoencoder_vs_golden():
     from tqdne_amd import LightningAutoencoder
     sd, d = load_golden("micro_ae.npz")

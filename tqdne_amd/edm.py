@@ -13,6 +13,8 @@ the HIP kernels:
 
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Optional
 
@@ -74,6 +76,18 @@ class EDM:
         return sigma + gamma * sigma
 
 
+def sampler_lanes(B: int) -> int:
+    """Sub-batches (HIP streams) the deterministic sampler integrates concurrently: up to 4, at least 16 samples each.
+    TQDNE_SAMPLER_LANES overrides (1 = one stream)."""
+    env = os.environ.get("TQDNE_SAMPLER_LANES")
+    if env is not None:
+        return max(1, int(env))
+    for n in (4, 2):
+        if B % n == 0 and B // n >= 16:
+            return n
+    return 1
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -101,10 +115,11 @@ class LightningEDM(LightningModule):
                 param.requires_grad = False
         self.save_hyperparameters(ignore=("autoencoder"))
         self._scal = {}
+        self._lane = 0  # which set of static buffers / execution plan the calls below use (two-lane sampling)
 
     # ------------------------------------------------------------------ preconditioned network
     def _scalars(self, B, device):
-        key = (B, str(device))
+        key = (B, str(device), self._lane)
         s = self._scal.get(key)
         if s is None:
             s = th.empty(5, B, dtype=th.float32, device=device)  # c_in, c_out, c_skip, c_noise, loss weight
@@ -125,10 +140,10 @@ class LightningEDM(LightningModule):
                                  _p(sc[3]), _p(sc[4]), B, stream), "edm scalars")
         if cond_sample is not None:
             x_in = th.cat((sample * sc[0][:, None, None], cond_sample.to(sample.dtype)), dim=1).contiguous()
-            eng = self.unet._engine(B, T, dev)
+            eng = self.unet._engine(B, T, dev, self._lane)
             return eng.forward(x_in, sc[3], cond, in_scale=None, c_out=sc[1], c_skip=sc[2], skip_src=sample, train=train,
                                dropout_seed=dropout_seed)
-        eng = self.unet._engine(B, T, dev)
+        eng = self.unet._engine(B, T, dev, self._lane)
         return eng.forward(sample, sc[3], cond, in_scale=sc[0], c_out=sc[1], c_skip=sc[2], skip_src=sample, train=train,
                            dropout_seed=dropout_seed)
 
@@ -221,7 +236,7 @@ class LightningEDM(LightningModule):
         return sample
 
     def _sampler_buffers(self, eps):
-        key = ("smp", tuple(eps.shape), str(eps.device))
+        key = ("smp", tuple(eps.shape), str(eps.device), self._lane)
         bufs = self._scal.get(key)
         if bufs is None:
             f64 = lambda: th.empty(eps.shape, dtype=th.float64, device=eps.device)
@@ -230,12 +245,68 @@ class LightningEDM(LightningModule):
         return bufs
 
     @th.no_grad()
-    def sample_deterministically(self, eps, sigmas, cond_sample=None, cond=None, use_graph=False):
+    def sample_deterministically(self, eps, sigmas, cond_sample=None, cond=None, use_graph=False, lanes=None):
         """Deterministic Heun sampler (edm.py:171-196): ``eps`` is the fp64 start state (already scaled by sigmas[0]),
-        ``sigmas`` the fp32 schedule ending in 0.  NFE = 2*len(sigmas) - 3 when the last sigma is the appended 0."""
-        lib = _lib.load()
+        ``sigmas`` the fp32 schedule ending in 0.  NFE = 2*len(sigmas) - 3 when the last sigma is the appended 0.
+
+        ``lanes``: samples are independent, so the batch can be integrated as ``lanes`` sub-batches on as many HIP streams, each
+        with its own execution plan.  Workgroups of one launch run in lockstep (all in their load prologue, then all in their MFMA loop,
+        then all in their store epilogue); streams drift out of phase, so one lane's prologue / epilogue bursts overlap another
+        lane's matrix work (measured on single layers: 1.0-1.17x, tools/desync_test.py; 18-step sample at B = 64: 2 lanes
+        -5.5 %, 4 lanes -9 %, 8 lanes +16 %: launches too small and too many).  Results are bit-identical to one lane.
+        Default: ``sampler_lanes(B)``; 1 under graph replay."""
         if not eps.is_cuda:
             raise RuntimeError("tqdne_amd samples on MI355X HIP kernels only; got a CPU start state")
+        B = eps.shape[0]
+        if lanes is None:
+            lanes = sampler_lanes(B)
+        if use_graph or lanes < 2 or B % lanes or B // lanes < 8:
+            run = self._heun_lane(eps, sigmas, cond_sample, cond, use_graph)
+            for _ in run:
+                pass
+            return run.result.clone()
+        dev = eps.device
+        h = B // lanes
+        cut = lambda t, i: None if t is None else t[i * h:(i + 1) * h].contiguous()
+        main = th.cuda.current_stream(dev)
+        streams = [main] + [self._side_stream(dev, i) for i in range(1, lanes)]
+        for st in streams[1:]:
+            st.wait_stream(main)
+        runs = []
+        try:
+            for i, st in enumerate(streams):
+                self._lane = i
+                with th.cuda.stream(st):
+                    runs.append(self._heun_lane(cut(eps, i), sigmas, cut(cond_sample, i), cut(cond, i), False))
+            # one sampler step of lane 0, then of lane 1, ...: all queues stay fed well ahead of the GPU
+            while not all(r.done for r in runs):
+                for i, (r, st) in enumerate(zip(runs, streams)):
+                    if not r.done:
+                        self._lane = i
+                        with th.cuda.stream(st):
+                            r.advance()
+        finally:
+            self._lane = 0
+        out = th.empty_like(eps)
+        for i, st in enumerate(streams[1:], 1):
+            with th.cuda.stream(st):
+                out[i * h:(i + 1) * h].copy_(runs[i].result)
+            main.wait_stream(st)
+        out[:h].copy_(runs[0].result)
+        return out
+
+    def _side_stream(self, dev, i=1):
+        key = ("side_stream", str(dev), i)
+        s = self._scal.get(key)
+        if s is None:
+            s = th.cuda.Stream(device=dev)
+            self._scal[key] = s
+        return s
+
+    def _heun_lane(self, eps, sigmas, cond_sample, cond, use_graph):
+        """The Heun integration of one (half) batch as a resumable object: ``advance()`` enqueues one sampler step on the current
+        stream with the current lane's plan and buffers; ``result`` is the fp64 state buffer once ``done``."""
+        lib = _lib.load()
         dev = eps.device
         sigmas = sigmas.to(device=dev, dtype=th.float32).contiguous()
         if cond is not None:
@@ -243,26 +314,48 @@ class LightningEDM(LightningModule):
         if cond_sample is not None:
             cond_sample = cond_sample.contiguous().float()
         bufs = self._sampler_buffers(eps)
-        x, xn, d, x32 = bufs["x"], bufs["xn"], bufs["d"], bufs["x32"]
-        x.copy_(eps)
-        x32.copy_(eps)  # fp64 -> fp32 rounding, as sample_curr.to(self.dtype)
-        n = x.numel()
-        nsteps = sigmas.numel() - 1
-        sp = sigmas.data_ptr()
-        stream = th.cuda.current_stream(dev).cuda_stream
-        denoise = lambda sig_ptr: self._denoise_static(x32, _RawPtr(sig_ptr), 0, cond, cond_sample=cond_sample)
-        if use_graph:
-            denoise = self._graph_denoiser(bufs, x32, cond, cond_sample)
-        for i in range(nsteps):
-            s_i, s_n = sp + 4 * i, sp + 4 * (i + 1)
-            den = denoise(s_i)
-            check(lib.tq_heun_euler(_p(x), _p(den), s_i, s_n, _p(d), _p(xn), _p(x32), n, stream), "heun euler")
-            if i < self.num_sampling_steps - 1:
-                den = denoise(s_n)
-                check(lib.tq_heun_correct(_p(x), _p(xn), _p(den), _p(d), s_i, s_n, _p(x), _p(x32), n, stream), "heun correct")
-            else:
-                x, xn = xn, x
-        return x.clone()
+        edm = self
+
+        class _Run:
+            def __init__(r):
+                r.x, r.xn, r.d, r.x32 = bufs["x"], bufs["xn"], bufs["d"], bufs["x32"]
+                r.x.copy_(eps)
+                r.x32.copy_(eps)  # fp64 -> fp32 rounding, as sample_curr.to(self.dtype)
+                r.i, r.nsteps = 0, sigmas.numel() - 1
+                r.keep = (sigmas, cond, cond_sample, eps)
+                if use_graph:
+                    r.denoise = edm._graph_denoiser(bufs, r.x32, cond, cond_sample)
+                else:
+                    r.denoise = lambda sig_ptr: edm._denoise_static(r.x32, _RawPtr(sig_ptr), 0, cond, cond_sample=cond_sample)
+
+            @property
+            def done(r):
+                return r.i >= r.nsteps
+
+            @property
+            def result(r):
+                return r.x
+
+            def advance(r):
+                i, n, sp = r.i, r.x.numel(), sigmas.data_ptr()
+                stream = th.cuda.current_stream(dev).cuda_stream
+                s_i, s_n = sp + 4 * i, sp + 4 * (i + 1)
+                den = r.denoise(s_i)
+                check(lib.tq_heun_euler(_p(r.x), _p(den), s_i, s_n, _p(r.d), _p(r.xn), _p(r.x32), n, stream), "heun euler")
+                if i < edm.num_sampling_steps - 1:
+                    den = r.denoise(s_n)
+                    check(lib.tq_heun_correct(_p(r.x), _p(r.xn), _p(den), _p(r.d), s_i, s_n, _p(r.x), _p(r.x32), n, stream),
+                          "heun correct")
+                else:
+                    r.x, r.xn = r.xn, r.x
+                r.i += 1
+
+            def __iter__(r):
+                while not r.done:
+                    r.advance()
+                    yield r.i
+
+        return _Run()
 
     def _graph_denoiser(self, bufs, x32, cond, cond_sample=None):
         """One preconditioned UNet evaluation (~160 launches) captured once in a HIP graph and replayed per NFE; sigma is fed

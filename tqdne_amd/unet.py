@@ -184,8 +184,9 @@ class UNetModel(nn.Module):
         self._engine_cache = {}
 
     # ------------------------------------------------------------------ execution
-    def _engine(self, B: int, T: int, device: torch.device) -> "engine.UNetEngine":
-        key = (B, T, str(device))
+    def _engine(self, B: int, T: int, device: torch.device, lane: int = 0) -> "engine.UNetEngine":
+        """The execution plan for this shape.  ``lane`` > 0: an independent plan (own static buffers) for a second stream."""
+        key = (B, T, str(device), lane)
         eng = self._engine_cache.get(key)
         if eng is None:
             eng = engine.UNetEngine(self, B, T, device)
