@@ -5,10 +5,13 @@ Training (``step``, iCT) is not part of BASELINE.json's configs and is not imple
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib, engine
 from ._lib import check
+from .edm import sampler_lanes
 from .lightning_compat import LightningModule
 
 
@@ -26,11 +29,11 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         self.lognormal_mean, self.lognormal_std, self.lr = lognormal_mean, lognormal_std, lr
         self._scal = {}
 
-    def _forward_static(self, sample, sigma, cond):
+    def _forward_static(self, sample, sigma, cond, lane=0):
         lib = _lib.load()
         B, _, T = sample.shape
         dev = sample.device
-        key = (B, str(dev))
+        key = (B, str(dev), lane)
         sc = self._scal.get(key)
         if sc is None:
             sc = torch.empty(2, B, device=dev)
@@ -38,7 +41,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         stream = torch.cuda.current_stream(dev).cuda_stream
         check(lib.tq_cm_scalars(_p(sigma), 1, float(self.sigma_data), float(self.sigma_min), _p(sc[0]), _p(sc[1]), B, stream),
               "cm scalars")
-        eng = self.net._engine(B, T, dev)
+        eng = self.net._engine(B, T, dev, lane)
         return eng.forward(sample, sigma, cond, in_scale=None, c_out=sc[0], c_skip=sc[1], skip_src=sample)
 
     def forward(self, sample, sigma, cond_sample=None, cond=None):
@@ -46,7 +49,40 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         engine.require_device(sample)
         if cond_sample is not None:
             raise NotImplementedError("cond_sample concatenation is not used by any 1-D consistency config")
-        return self._forward_static(sample.contiguous(), sigma.contiguous().float(), cond).clone()
+        sample, sigma = sample.contiguous(), sigma.contiguous().float()
+        B = sample.shape[0]
+        lanes = 1  # one forward cannot amortise 4x the launches (measured 8.3 vs 6.5 ms at B = 64); kept for TQDNE experiments
+        if os.environ.get("TQDNE_CM_LANES"):
+            lanes = int(os.environ["TQDNE_CM_LANES"])
+        if lanes > 1 and (B % lanes or torch.is_grad_enabled()):
+            lanes = 1
+        if lanes < 2:
+            return self._forward_static(sample, sigma, cond).clone()
+        # independent samples: sub-batches on separate HIP streams run out of phase (see LightningEDM.sample_deterministically)
+        dev = sample.device
+        h = B // lanes
+        main = torch.cuda.current_stream(dev)
+        out = torch.empty_like(sample[:, : self.net.out_channels])
+        for i in range(lanes):
+            st = main if i == 0 else self._side_stream(dev, i)
+            if i:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                sl = slice(i * h, (i + 1) * h)
+                y = self._forward_static(sample[sl].contiguous(), sigma[sl].contiguous(),
+                                         None if cond is None else cond[sl].contiguous(), lane=i)
+                out[sl].copy_(y)
+        for i in range(1, lanes):
+            main.wait_stream(self._side_stream(dev, i))
+        return out
+
+    def _side_stream(self, dev, i):
+        key = ("side_stream", str(dev), i)
+        s = self._scal.get(key)
+        if s is None:
+            s = torch.cuda.Stream(device=dev)
+            self._scal[key] = s
+        return s
 
     @torch.no_grad()
     def sample(self, shape, sigmas=[1.0], cond_sample=None, cond=None):

@@ -260,7 +260,7 @@ class LightningEDM(LightningModule):
         B = eps.shape[0]
         if lanes is None:
             lanes = sampler_lanes(B)
-        if use_graph or lanes < 2 or B % lanes or B // lanes < 8:
+        if lanes < 2 or B % lanes or B // lanes < 8:
             run = self._heun_lane(eps, sigmas, cond_sample, cond, use_graph)
             for _ in run:
                 pass
@@ -277,7 +277,7 @@ class LightningEDM(LightningModule):
             for i, st in enumerate(streams):
                 self._lane = i
                 with th.cuda.stream(st):
-                    runs.append(self._heun_lane(cut(eps, i), sigmas, cut(cond_sample, i), cut(cond, i), False))
+                    runs.append(self._heun_lane(cut(eps, i), sigmas, cut(cond_sample, i), cut(cond, i), use_graph))
             # one sampler step of lane 0, then of lane 1, ...: all queues stay fed well ahead of the GPU
             while not all(r.done for r in runs):
                 for i, (r, st) in enumerate(zip(runs, streams)):
