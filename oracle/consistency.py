@@ -37,3 +37,39 @@ def sample(net, start_unit_noise: Tensor, sigmas: Sequence[float] = (),
         x = x + u * s
         x = forward(net, x, ones * s, cond_sample, cond, sigma_min, sigma_data)
     return x
+
+
+def ict_schedule(global_step: int, max_steps: int, initial_timesteps: int = 10, final_timesteps: int = 1280,
+                 sigma_min: float = 0.002, sigma_max: float = 80.0, rho: float = 7.0) -> Tensor:
+    """consistency_model.py:121-138: discretisation that doubles over training; returns the sigma grid (num_timesteps,)."""
+    import numpy as np
+    prime = np.floor(max_steps / (np.log2(np.floor(final_timesteps / initial_timesteps)) + 1))
+    num = initial_timesteps * 2 ** np.floor(global_step / prime)
+    num = min(num, final_timesteps) + 1
+    rho_inv = 1.0 / rho
+    steps = torch.arange(num) / (num - 1)
+    sig = sigma_min**rho_inv + steps * (sigma_max**rho_inv - sigma_min**rho_inv)
+    return sig**rho
+
+
+def ict_timestep_pdf(sigmas: Tensor, lognormal_mean: float = -1.1, lognormal_std: float = 2.0) -> Tensor:
+    """consistency_model.py:141-146: discretised lognormal over the sigma intervals."""
+    import numpy as np
+    z = lambda s: torch.erf((torch.log(s) - lognormal_mean) / (lognormal_std * np.sqrt(2)))
+    pdf = z(sigmas[1:]) - z(sigmas[:-1])
+    return pdf / pdf.sum()
+
+
+def ict_loss(net, sample: Tensor, sigmas: Tensor, timesteps: Tensor, epsilon: Tensor, cond=None,
+             sigma_min: float = 0.002, sigma_data: float = 0.5) -> Tensor:
+    """consistency_model.py:148-176 (eval-mode dropout; timesteps and epsilon injected): teacher at sigma_t without gradient,
+    student at sigma_{t+1}, pseudo-Huber distance with c = 0.00054 sqrt(dim), weighted by 1 / (sigma_{t+1} - sigma_t)."""
+    import numpy as np
+    t_sig, s_sig = sigmas[timesteps], sigmas[timesteps + 1]
+    with torch.no_grad():
+        target = forward(net, sample + epsilon * _bcast(t_sig, sample.dim()), t_sig, None, cond, sigma_min, sigma_data)
+    pred = forward(net, sample + epsilon * _bcast(s_sig, sample.dim()), s_sig, None, cond, sigma_min, sigma_data)
+    c = 0.00054 * np.sqrt(np.prod(sample.shape[2:]))
+    loss = torch.sqrt((pred - target) ** 2 + c**2) - c
+    w = (1 / (sigmas[1:] - sigmas[:-1]))[timesteps]
+    return (loss * _bcast(w, loss.dim())).mean()

@@ -5,7 +5,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import cfg_of, load_golden, rel_err
+import os
+
+from conftest import GOLDEN, cfg_of, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -398,3 +400,47 @@ def test_graph_replayed_sampler_matches_eager():
     c = edm.sample_deterministically(eps, sig, None, cond, use_graph=True)  # cached graph
     assert torch.equal(a, b) and torch.equal(a, c)
     assert rel_err(a.float().cpu(), d["sample:out"]) < TOL
+
+
+def test_consistency_training_step_vs_reference():
+    """iCT step (consistency_model.py:115-176): loss and gradients vs the reference's own step (micro_cm_step.npz), with its
+    multinomial / randn_like draws injected"""
+    import numpy as np
+    from tqdne_amd import UNetModel
+    from tqdne_amd.consistency_model import LithningConsistencyModel
+    sd, d = load_golden("micro_unet.npz")
+    s = np.load(os.path.join(GOLDEN, "micro_cm_step.npz"))
+    net = UNetModel(**cfg_of(d))
+    net.load_state_dict(sd)
+    cm = LithningConsistencyModel(net).to(dev()).eval()  # golden taken in eval mode
+    cm.max_steps, cm.global_step = int(s["max_steps"]), int(s["global_step"])
+    sched = cm._schedule()
+    from oracle import consistency as OC
+    assert rel_err(sched.cpu(), OC.ict_schedule(cm.global_step, cm.max_steps)) < 1e-6
+    o_m, o_r = torch.multinomial, torch.randn_like
+    seen = {}
+
+    def mult(pdf, n, replacement=True):
+        seen["pdf"] = pdf
+        return torch.from_numpy(s["timesteps"]).to(dev())
+
+    torch.multinomial, torch.randn_like = mult, (lambda t, **k: torch.from_numpy(s["eps"]).to(dev()))
+    try:
+        loss = cm.step({"signal": torch.from_numpy(s["sample"]).to(dev()), "cond": torch.from_numpy(s["cond"]).to(dev())})
+    finally:
+        torch.multinomial, torch.randn_like = o_m, o_r
+    assert rel_err(seen["pdf"].cpu(), s["pdf"]) < 1e-5
+    assert rel_err(loss.detach().cpu(), s["loss"]) < TOL
+    loss.backward()
+    grads = dict(net.named_parameters())
+    gmax = float(s["gnorm"].max())
+    for n, gn, gp in zip(s["gnames"], s["gnorm"], s["gproj"]):
+        g = grads[str(n)].grad.reshape(-1).double().cpu()
+        pat = torch.cos(torch.arange(g.numel(), dtype=torch.float64) * 0.37 + 0.1)
+        assert abs(float(g.norm()) - gn) < 1e-3 * max(gn, 1e-3 * gmax), n
+        assert abs(float((g * pat).sum()) - gp) < 1e-3 * max(gn, 1e-3 * gmax), n
+    for k in s.files:
+        if k.startswith("g:"):
+            ref = torch.from_numpy(s[k])
+            e = float((grads[k[2:]].grad.cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-3 * gmax))
+            assert e < TOL, (k, e)

@@ -133,3 +133,26 @@ def test_autoencoder_encode_decode():
     assert rel_err(mean, d["mean"]) < TOL and rel_err(log_std, d["log_std"]) < TOL
     assert rel_err(z, d["z"]) < TOL
     assert rel_err(xr, d["recon"]) < TOL
+
+
+def test_ict_training_step_vs_reference_step():
+    """consistency_model.py:115-176 restated (schedule, discretised lognormal, pseudo-Huber loss): loss, pdf and the gradient
+    norms of every parameter against the reference's own step (tools/make_cm_step_golden.py)"""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from oracle import consistency as OC, unet as OU
+    sd, d = load_golden("micro_unet.npz")
+    s = np.load(os.path.join(GOLDEN, "micro_cm_step.npz"))
+    cfg = cfg_of(d)
+    params = {k: v.clone().requires_grad_(k != "time_embed.W") for k, v in sd.items()}
+    net = lambda x, t, c: OU.unet_forward(params, cfg, x, t, c)
+    sig = OC.ict_schedule(int(s["global_step"]), int(s["max_steps"]))
+    assert len(sig) == len(s["pdf"]) + 1
+    assert rel_err(OC.ict_timestep_pdf(sig), s["pdf"]) < 1e-6
+    loss = OC.ict_loss(net, torch.from_numpy(s["sample"]), sig, torch.from_numpy(s["timesteps"]), torch.from_numpy(s["eps"]),
+                       torch.from_numpy(s["cond"]))
+    assert rel_err(loss.detach(), s["loss"]) < 1e-6
+    loss.backward()
+    for n, gn in zip(s["gnames"], s["gnorm"]):
+        assert abs(float(params[str(n)].grad.double().norm()) - gn) <= 1e-4 * max(gn, 1e-9), n

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 
 from . import _lib, engine
@@ -19,6 +20,41 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_seed = [0]
+
+
+class _ICTLossFn(torch.autograd.Function):
+    """loss = mean(w_t * (sqrt((f(x + s_{t+1} eps, s_{t+1}) - sg[f(x + s_t eps, s_t)])^2 + c^2) - c)),  c = 0.00054 sqrt(dim)."""
+
+    @staticmethod
+    def forward(ctx, module, sample, sigmas, timesteps, epsilon, cond, *params):
+        engine.require_device(sample)
+        B, nd = sample.shape[0], sample.dim()
+        _seed[0] += 1
+        seed = (int(torch.initial_seed()) * 1000003 + _seed[0]) & 0xFFFFFFFFFFFFFFFF  # one seed: teacher = student masks
+        train = module.training
+        t_sig, s_sig = sigmas[timesteps].float().contiguous(), sigmas[timesteps + 1].float().contiguous()
+        exp = lambda v: v[(...,) + (None,) * (nd - 1)]
+        target = module._forward_static((sample + epsilon * exp(t_sig)).contiguous(), t_sig, cond, train=train,
+                                        dropout_seed=seed).clone()
+        pred = module._forward_static((sample + epsilon * exp(s_sig)).contiguous(), s_sig, cond, train=train, dropout_seed=seed)
+        c = 0.00054 * float(np.sqrt(np.prod(sample.shape[2:])))
+        diff = pred - target
+        root = torch.sqrt(diff * diff + c * c)
+        w = exp((1 / (sigmas[1:] - sigmas[:-1]))[timesteps].float())
+        loss = ((root - c) * w).mean()
+        ctx.module, ctx.shape = module, tuple(sample.shape)
+        ctx.dpred = (diff / root * w / diff.numel()).contiguous()  # d loss / d prediction
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        B, _, T = ctx.shape
+        eng = ctx.module.net._engine(B, T, ctx.dpred.device)
+        grads = eng.backward(ctx.dpred, gloss)
+        return (None,) * 6 + tuple(grads)
+
+
 class LithningConsistencyModel(LightningModule):  # (sic) the reference's class name
     def __init__(self, net, sigma_min=0.002, sigma_max=80.0, rho=7.0, sigma_data=0.5, initial_timesteps=10,
                  final_timesteps=1280, lognormal_mean=-1.1, lognormal_std=2.0, lr=1e-4):
@@ -29,7 +65,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         self.lognormal_mean, self.lognormal_std, self.lr = lognormal_mean, lognormal_std, lr
         self._scal = {}
 
-    def _forward_static(self, sample, sigma, cond, lane=0):
+    def _forward_static(self, sample, sigma, cond, lane=0, train=False, dropout_seed=0):
         lib = _lib.load()
         B, _, T = sample.shape
         dev = sample.device
@@ -42,7 +78,8 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         check(lib.tq_cm_scalars(_p(sigma), 1, float(self.sigma_data), float(self.sigma_min), _p(sc[0]), _p(sc[1]), B, stream),
               "cm scalars")
         eng = self.net._engine(B, T, dev, lane)
-        return eng.forward(sample, sigma, cond, in_scale=None, c_out=sc[0], c_skip=sc[1], skip_src=sample)
+        return eng.forward(sample, sigma, cond, in_scale=None, c_out=sc[0], c_skip=sc[1], skip_src=sample, train=train,
+                           dropout_seed=dropout_seed)
 
     def forward(self, sample, sigma, cond_sample=None, cond=None):
         """consistency_model.py:63-79."""
@@ -98,6 +135,50 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
             sample = sample + u * sigma
             sample = self(sample, ones * sigma, cond_sample, cond)
         return sample
+
+    # ------------------------------------------------------------------ iCT training (consistency_model.py:115-190)
+    def _schedule(self):
+        """consistency_model.py:121-138.  ``trainer.max_steps`` / ``global_step`` are Lightning's; without a trainer the
+        attributes ``max_steps`` / ``global_step`` of the module are used."""
+        tr = getattr(self, "trainer", None)
+        max_steps = tr.max_steps if tr is not None else getattr(self, "max_steps", 1)
+        global_step = getattr(self, "global_step", 0)
+        prime = np.floor(max_steps / (np.log2(np.floor(self.final_timesteps / self.initial_timesteps)) + 1))
+        num = self.initial_timesteps * 2 ** np.floor(global_step / prime)
+        num = min(num, self.final_timesteps) + 1
+        rho_inv = 1.0 / self.rho
+        steps = torch.arange(num, device=self.device) / (num - 1)
+        sig = self.sigma_min**rho_inv + steps * (self.sigma_max**rho_inv - self.sigma_min**rho_inv)
+        return sig**self.rho
+
+    def step(self, batch):
+        """A single step of training or validation (consistency_model.py:115-176): teacher at sigma_t (no gradient, same
+        dropout masks as the student), student at sigma_{t+1}, weighted pseudo-Huber distance.  Both UNet passes and the
+        backward are HIP; the schedule, the (B,)-sized draws and the loss on the (B, C, T) outputs are torch glue."""
+        sample = batch["signal"]
+        if "cond_signal" in batch:
+            raise NotImplementedError("cond_signal is not used by any 1-D consistency config")
+        cond = batch["cond"] if "cond" in batch else None
+        sigmas = self._schedule()
+        z = lambda s_: torch.erf((torch.log(s_) - self.lognormal_mean) / (self.lognormal_std * np.sqrt(2)))
+        pdf = z(sigmas[1:]) - z(sigmas[:-1])
+        pdf = pdf / pdf.sum()
+        timesteps = torch.multinomial(pdf, sample.shape[0], replacement=True)
+        epsilon = torch.randn_like(sample)
+        return _ICTLossFn.apply(self, sample.contiguous(), sigmas, timesteps, epsilon, cond, *self.net.parameters())
+
+    def training_step(self, batch, batch_idx: int):
+        loss = self.step(batch)
+        self.log("train_loss", loss.item(), prog_bar=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx: int):
+        loss = self.step(batch)
+        self.log("val_loss", loss.item())
+        return loss
+
+    def configure_optimizers(self):
+        return torch.optim.RAdam(self.net.parameters(), lr=self.lr)
 
     def evaluate(self, batch, sigmas=[1]):
         sample = batch["signal"]
