@@ -81,3 +81,37 @@ def test_edm_surface():
     s = EDM().sampling_sigmas(18)
     assert s.shape == (19,) and s[-1] == 0
     assert all(k.startswith("unet.") for k in e.state_dict())
+
+
+def test_gpu_only_components_fail_loudly_on_cpu():
+    """no CPU fallbacks: the optimizer launch and the GPU representation refuse CPU tensors instead of computing elsewhere"""
+    import numpy as np
+    import pytest
+    import torch
+    from tqdne_amd.optim import FusedAdamEMA
+    from tqdne_amd.representation import Identity, MovingAverageEnvelope, Normalization
+
+    p = torch.nn.Parameter(torch.zeros(8))
+    with pytest.raises(RuntimeError):
+        FusedAdamEMA([("p", p)], lr=1e-3)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            MovingAverageEnvelope().get_representation(np.zeros((3, 256), np.float32))
+    x = np.arange(6.0).reshape(2, 3)
+    assert Identity().invert_representation(Identity().get_representation(x)) is x
+    n = Normalization(1.0, 2.0)
+    assert np.allclose(n.invert_representation(n.get_representation(x)), x)
+
+
+def test_sampler_lane_rule():
+    import os
+    from tqdne_amd.edm import sampler_lanes
+    old = os.environ.pop("TQDNE_SAMPLER_LANES", None)
+    try:
+        assert [sampler_lanes(b) for b in (1, 8, 16, 31, 32, 48, 64, 128, 66)] == [1, 1, 1, 1, 2, 2, 4, 4, 2]
+        os.environ["TQDNE_SAMPLER_LANES"] = "1"
+        assert sampler_lanes(64) == 1
+    finally:
+        os.environ.pop("TQDNE_SAMPLER_LANES", None)
+        if old is not None:
+            os.environ["TQDNE_SAMPLER_LANES"] = old

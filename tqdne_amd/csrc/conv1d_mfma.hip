@@ -86,6 +86,10 @@ struct ConvArgs {
     int sC0, sC1;
 };
 
+#ifndef TQ_STAGE_PRE
+#define TQ_STAGE_PRE 5
+#endif
+
 template <int KT, int STRIDE, int UPS, int WM, int WN>
 struct Cfg {
     static constexpr int NTHR = 64 * WM * WN;
@@ -93,7 +97,8 @@ struct Cfg {
     static constexpr int MT = 32 * WM;   // output channels per workgroup
     static constexpr int ROWS = (STRIDE == 1) ? (NT + KT - 1) : (2 * NT + 1);
     static constexpr int NIT = (ROWS * 8 + NTHR - 1) / NTHR;
-    static constexpr int PRE = NIT < 5 ? NIT : 5;  // staging iterations prefetched into registers across the MFMA phase
+    static constexpr int PRE_MAX = TQ_STAGE_PRE;   // staging iterations prefetched into registers across the MFMA phase
+    static constexpr int PRE = NIT < PRE_MAX ? NIT : PRE_MAX;
     static constexpr int SYNC_BATCH = 4;           // the rest is loaded+written synchronously in batches
     static constexpr int ITERS = (NIT <= PRE) ? NIT : PRE + ((NIT - PRE + SYNC_BATCH - 1) / SYNC_BATCH) * SYNC_BATCH;
     static constexpr int ROWS_PAD = (ITERS * NTHR + 7) / 8;  // every staging task lands in-bounds: no predicate

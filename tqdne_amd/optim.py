@@ -30,11 +30,11 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self._names = [n for n, _ in named]
         super().__init__([p for _, p in named], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.ema_decay = ema_decay
-        self._lib = _lib.load()  # raises when the HIP library is missing: there is no fallback update
         ps = self.param_groups[0]["params"]
         dev = ps[0].device
         if dev.type != "cuda":
             raise RuntimeError("FusedAdamEMA updates parameters on the GPU; move the module to cuda first")
+        self._lib = _lib.load()  # raises when the HIP library is missing: there is no fallback update
         offs, total = [], 0
         for p in ps:
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
