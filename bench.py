@@ -271,12 +271,16 @@ def main():
     if rank == 0:
         flops_fwd = conv_flops_per_sample(edm.unet, T)
         k_ms, k_flops, k_name, k_n = probe.result()
+        mx8 = os.environ.get("TQDNE_CONV_SCHEME", "f16mx8").lower() == "f16mx8" and "+skip" not in k_name
         roofline = dict(bound="mfma", achieved=(k_flops / (k_ms * 1e-3) / 1e12) if k_ms else None,
                         peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
                         kernel=k_name, launches_timed=k_n, avg_launch_ms=k_ms, algorithmic_flop_per_launch=k_flops,
-                        executed_mfma_flop_per_launch=3 * k_flops,
-                        note="fp32 operands as bf16 hi/lo, 3 MFMA products per algorithmic product (no TF32/xf32 on gfx950); "
-                             "frac = algorithmic FLOP/s over the dense bf16 MFMA peak, so 1/3 is the ceiling of this scheme")
+                        executed_mfma_flop_equiv_per_launch=(2 if mx8 else 3) * k_flops,
+                        note=("fp32 product contracted as 2 fp16 MFMAs + 1 block-scaled fp8 MFMA per 64 channels (TQ_WFMT_F16_MX8: "
+                              "the MFMA cycles of 2 bf16 products per algorithmic product; no TF32/xf32 on gfx950); frac = algorithmic "
+                              "FLOP/s over the dense bf16 MFMA peak, so 1/2 is the ceiling of this scheme") if mx8 else
+                             ("fp32 operands as bf16 hi/lo, 3 MFMA products per algorithmic product (no TF32/xf32 on gfx950); "
+                              "frac = algorithmic FLOP/s over the dense bf16 MFMA peak, so 1/3 is the ceiling of this scheme"))
         if roofline["achieved"]:
             roofline["frac"] = roofline["achieved"] / roofline["peak"]
         # HBM traffic of the same launch from PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
@@ -311,7 +315,7 @@ def main():
             "metric": "waveforms/sec (train step + 18-step EDM sample), 3ch x 4096",
             "value": value, "unit": "waveforms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (contractions as bf16x3 MFMA, fp32 accumulate; sampler state f64)", "data": "synthetic",
+            "dtype": "f32 (contractions on MFMA with fp32 accumulate: bf16x3, and fp16 + block-scaled-fp8 corrections on the non-fused 128/256-channel forward convs; sampler state f64)", "data": "synthetic",
             "config": {"workload": f"{args.config} 1-D EDM UNet ({sum(p.numel() for p in edm.unet.parameters())} params), "
                                    f"B={B}/GPU, 3x{T}: 1 train step (dropout 0.1, Adam, cosine LR) + {args.sample_steps}-step "
                                    f"Heun sample ({nfe} NFE)", "global_batch": world * B, "parallelism": f"dp{world}",

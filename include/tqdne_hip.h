@@ -38,6 +38,14 @@ typedef struct ihipStream_t* hipStream_t;
 #define TQ_CONV_STATS 16   /* emit per-channel partial statistics of the output */
 #define TQ_CONV_DROPOUT 32 /* training-mode dropout on the activated input (unet.py:101) */
 
+/* TqConvDesc.wfmt: how the fp32 product x * w is contracted on the matrix cores (= format of the packed weights).
+ * BF16X3: both operands split into bf16 hi + lo, three bf16 MFMA products; fp32 range, ~2^-16 relative (pack modes 0 / 1).
+ * F16_MX8: per 64 channels two fp16 MFMAs plus one block-scaled fp8 MFMA carrying both first-order corrections; ~2^-15 relative at
+ * 2/3 of the MFMA cycles; the activation operand has fp16 RANGE (|x| clamped to 6e4, relative precision lost below 6e-5).  Built
+ * for stride-1 forward launches with 128 | C_out and 64 | every source's channels (pack mode 2). */
+#define TQ_WFMT_BF16X3 0
+#define TQ_WFMT_F16_MX8 1
+
 typedef struct TqConvDesc {
     int32_t B, T_in, T_out;
     int32_t C_in0, C_in1; /* channels of the two concatenated sources (C_in1 = 0: single source) */
@@ -50,6 +58,7 @@ typedef struct TqConvDesc {
     float dropout_p;
     uint64_t dropout_seed;
     int32_t C_skip0, C_skip1; /* tq_conv1d_fwd_skip only: channels of the fused 1x1 skip conv's (concatenated) input; else 0 */
+    int32_t wfmt;             /* TQ_WFMT_*: format of packed_w = contraction scheme of this launch */
 } TqConvDesc;
 
 /* flags of TqConvBwdDesc.flags: which stages the FORWARD conv applied to its input */
@@ -73,8 +82,9 @@ typedef struct TqConvBwdDesc {
 int tq_abi_version(void);
 
 /* ---- weights -------------------------------------------------------------------------------------------- */
-/* Pack a torch Conv1d weight (C_out, C_in, K) fp32 into per-lane bf16 hi/lo MFMA fragments.
- * mode 0: forward operand; mode 1: data-gradient operand (transposed + tap-flipped). */
+/* Pack a torch Conv1d weight (C_out, C_in, K) fp32 into per-lane MFMA fragments.
+ * mode 0: forward operand, TQ_WFMT_BF16X3; mode 1: data-gradient operand (transposed + tap-flipped), TQ_WFMT_BF16X3;
+ * mode 2: forward operand, TQ_WFMT_F16_MX8. */
 size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode);
 int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* packed, hipStream_t stream);
 int tq_conv_tile_co(int C_out);

@@ -2,6 +2,7 @@
 Tolerance: the north-star bar is 1e-3 relative; single kernels are held to 1e-4 (bf16x3 products are ~2e-5)."""
 
 import math
+import os
 
 import pytest
 import torch
@@ -52,6 +53,39 @@ def test_conv_plain(cin, cout, k, T):
     ref = F.conv1d(x, w, b, padding=k // 2)
     assert rel_err(ncw(y), ref) < TOL
     assert rel_err(st.cpu(), ref_stats(ref)) < TOL
+
+
+@pytest.mark.parametrize("cin0,cin1,cout,k,T,gn", [
+    (128, 0, 128, 5, 300, True), (256, 256, 256, 5, 200, True), (256, 128, 256, 1, 129, False), (64, 64, 256, 3, 260, True),
+    (256, 0, 768, 1, 512, True), (512, 0, 128, 5, 64, False),
+])
+def test_conv_both_contraction_schemes(cin0, cin1, cout, k, T, gn):
+    """shapes the fp16 + block-scaled-fp8 scheme serves (128 | C_out, 64 | sources): it and bf16x3 against fp32 PyTorch.
+    Tolerance 1e-4 for both (measured: bf16x3 ~1e-5, f16+mx8 ~3e-5)."""
+    from tqdne_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin0 + cin1 + cout + k + T)
+    B = 2
+    x0 = torch.randn(B, cin0, T, generator=g) * 1.5
+    x1 = torch.randn(B, cin1, T, generator=g) if cin1 else None
+    cin = cin0 + cin1
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    a, sh = (torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g)) if gn else (None, None)
+    d = dev()
+    assert _lib.forward_wfmt(cout, [cin0, cin1]) == _lib.TQ_WFMT_F16_MX8 or os.environ.get("TQDNE_CONV_SCHEME") == "bf16x3"
+    xin = torch.cat([x0, x1], 1) if cin1 else x0
+    if gn:
+        xin = F.silu(xin * a[:, :, None] + sh[:, :, None])
+    ref = F.conv1d(xin, w, b, padding=k // 2)
+    for wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX8):
+        y, st = ops.conv1d(cl(x0), w.to(d), b.to(d), x1=cl(x1) if cin1 else None, gscale=a.to(d) if gn else None,
+                           gshift=sh.to(d) if gn else None, silu=gn, wfmt=wfmt)
+        assert rel_err(ncw(y), ref) < TOL, wfmt
+        assert rel_err(st.cpu(), ref_stats(ref)) < TOL, wfmt
+    # fp16 range of the activation operand: huge inputs are clamped, not turned into inf / NaN
+    big = cl(x0 * 1e6)
+    y, _ = ops.conv1d(big, w[:, :cin0].contiguous().to(d), b.to(d), wfmt=_lib.TQ_WFMT_F16_MX8, stats=False)
+    assert torch.isfinite(y).all()
 
 
 def test_conv_fused_everything():

@@ -23,11 +23,13 @@ for (C0, C1, Co, K, T, gn) in LAYERS:
     gh = torch.randn(B, C0 + C1, device=dev) if gn else None
     y = torch.empty(B, T, Co, device=dev)
     st = torch.empty(B, (T + 127) // 128, Co, 2, device=dev)
-    wp = ops.pack_conv_weight(w, 0)
+    d_wfmt = _lib.forward_wfmt(Co, [C0, C1])
+    wp = ops.pack_conv_weight(w, 2 if d_wfmt == _lib.TQ_WFMT_F16_MX8 else 0)
     d = _lib.TqConvDesc()
     d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T, T, C0, C1, Co
     d.ktaps, d.stride, d.pad, d.upsample = K, 1, K // 2, 0
     d.flags = (3 if gn else 0) | 16
+    d.wfmt = d_wfmt
     stream = torch.cuda.current_stream().cuda_stream
     p = lambda t: None if t is None else t.data_ptr()
     def run():

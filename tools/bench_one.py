@@ -18,10 +18,12 @@ gs = torch.rand(B, C0 + C1, device=dev) + 0.5
 gh = torch.randn(B, C0 + C1, device=dev)
 y = torch.empty(B, T, Co, device=dev)
 st = torch.empty(B, (T + 127) // 128, Co, 2, device=dev)
-wp = ops.pack_conv_weight(w, 0)
+wfmt = _lib.forward_wfmt(Co, [C0, C1])
+wp = ops.pack_conv_weight(w, 2 if wfmt == _lib.TQ_WFMT_F16_MX8 else 0)
 d = _lib.TqConvDesc()
 d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T, T, C0, C1, Co
 d.ktaps, d.stride, d.pad, d.upsample, d.flags = K, 1, K // 2, 0, 3 | 16
+d.wfmt = wfmt
 p = lambda t: None if t is None else t.data_ptr()
 for _ in range(reps):
     assert lib.tq_conv1d_fwd(C.byref(d), p(x0), p(x1), p(gs), p(gh), p(wp), p(b), None, None, p(y), p(st), torch.cuda.current_stream().cuda_stream) == 0

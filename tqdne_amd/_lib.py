@@ -17,6 +17,18 @@ F = C.c_float
 SZ = C.c_size_t
 
 TQ_CONV_GN, TQ_CONV_SILU, TQ_CONV_EMB, TQ_CONV_RES, TQ_CONV_STATS, TQ_CONV_DROPOUT = 1, 2, 4, 8, 16, 32
+TQ_WFMT_BF16X3, TQ_WFMT_F16_MX8 = 0, 1
+
+
+def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False) -> int:
+    """Contraction scheme of a forward conv launch (include/tqdne_hip.h, TQ_WFMT_*): fp16 + block-scaled-fp8 corrections where
+    the kernel is built for the shape (stride 1, 128 | C_out, 64 | every source's channels, no fused skip conv), bf16x3 elsewhere.
+    TQDNE_CONV_SCHEME=bf16x3 forces the fp32-range three-product scheme everywhere."""
+    v = os.environ.get("TQDNE_CONV_SCHEME", "f16mx8").lower()
+    if v not in ("bf16x3", "f16mx8"):
+        raise ValueError(f"TQDNE_CONV_SCHEME={v!r}: expected bf16x3 or f16mx8")
+    ok = stride == 1 and not upsample and not fused_skip and C_out % 128 == 0 and all(c % 64 == 0 for c in sources if c)
+    return TQ_WFMT_F16_MX8 if (v == "f16mx8" and ok) else TQ_WFMT_BF16X3
 TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_DROPOUT, TQ_BWD_ACCUM, TQ_BWD_STATS = 1, 2, 4, 8, 16
 STAT_SLOT = 128
 
@@ -28,7 +40,7 @@ class TqConvDesc(C.Structure):
         ("ktaps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("upsample", C.c_int32), ("flags", C.c_int32), ("emb_stride", C.c_int32),
         ("dropout_site", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
-        ("C_skip0", C.c_int32), ("C_skip1", C.c_int32),
+        ("C_skip0", C.c_int32), ("C_skip1", C.c_int32), ("wfmt", C.c_int32),
     ]
 
 

@@ -84,25 +84,38 @@ struct ConvArgs {
     const float* sx1;
     const float* sbias;
     int sC0, sC1;
+    int wfmt;  // TQ_WFMT_*: packed weight format = contraction scheme
 };
 
 #ifndef TQ_STAGE_PRE
 #define TQ_STAGE_PRE 5
 #endif
 
-template <int KT, int STRIDE, int UPS, int WM, int WN>
+// SCH (contraction scheme of the fp32 product x * w; both operands arrive as fp32):
+//   0  "bf16x3": x = xh + xl, w = wh + wl in bf16; xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_bf16, 32-channel chunks.
+//   1  "f16+mx8": per 64-channel chunk two v_mfma_f32_16x16x32_f16 on xh = fp16(x), wh = fp16(w), plus ONE block-scaled fp8 MFMA
+//      (v_mfma_scale_f32_16x16x128_f8f6f4) for both first-order corrections: a lane's bytes 0..15 carry fp8(xl * 2^12) against
+//      fp8(w), bytes 16..31 fp8(x) against fp8(wl * 2^12), uniform E8M0 scales 2^0 (A) and 2^-12 (B).  The corrections are 2^-12
+//      of the product, so fp8's 2^-4 leaves ~2^-15 like bf16x3, at 2/3 of its MFMA cycles.  fp16 RANGE applies to x (clamped to
+//      +-60000, relative precision lost below 6e-5): forward activations only.
+template <int KT, int STRIDE, int UPS, int WM, int WN, int SCH = 0>
 struct Cfg {
+    static constexpr int CH = SCH ? 64 : 32;     // channels per chunk
+    static constexpr int ROWB = 2 * CH;          // bytes per row of one LDS plane
+    static constexpr int TPR = CH / 4;           // staging threads per row (4 channels each)
+    static constexpr int NW = SCH ? 8 : 4;       // 16-byte weight fragments per lane and (chunk, tap): 2 co blocks x NW/2
+    static constexpr int NBF = SCH ? 4 : 2;      // 16-byte activation fragments per lane and (tap, t-block)
     static constexpr int NTHR = 64 * WM * WN;
     static constexpr int NT = 128 * WN;  // output positions per workgroup
     static constexpr int MT = 32 * WM;   // output channels per workgroup
     static constexpr int ROWS = (STRIDE == 1) ? (NT + KT - 1) : (2 * NT + 1);
-    static constexpr int NIT = (ROWS * 8 + NTHR - 1) / NTHR;
+    static constexpr int NIT = (ROWS * TPR + NTHR - 1) / NTHR;
     static constexpr int PRE_MAX = TQ_STAGE_PRE;   // staging iterations prefetched into registers across the MFMA phase
     static constexpr int PRE = NIT < PRE_MAX ? NIT : PRE_MAX;
     static constexpr int SYNC_BATCH = 4;           // the rest is loaded+written synchronously in batches
     static constexpr int ITERS = (NIT <= PRE) ? NIT : PRE + ((NIT - PRE + SYNC_BATCH - 1) / SYNC_BATCH) * SYNC_BATCH;
-    static constexpr int ROWS_PAD = (ITERS * NTHR + 7) / 8;  // every staging task lands in-bounds: no predicate
-    static constexpr int PLANE = (ROWS_PAD > ROWS ? ROWS_PAD : ROWS) * 64;  // bytes per hi (or lo) plane
+    static constexpr int ROWS_PAD = (ITERS * NTHR + TPR - 1) / TPR;  // every staging task lands in-bounds: no predicate
+    static constexpr int PLANE = (ROWS_PAD > ROWS ? ROWS_PAD : ROWS) * ROWB;  // bytes per plane
     static constexpr int BUF = 2 * PLANE;         // hi + lo
     static constexpr int LDS_BYTES = 2 * BUF;     // double buffered
     static constexpr int PAD = (STRIDE == 1) ? (KT / 2) : 1;
@@ -111,9 +124,10 @@ struct Cfg {
 // ACT (compile time): prologue applied while staging -- 0 none, 1 folded GN, 2 GN + SiLU, 3 GN + SiLU + dropout
 // FUSE: the ResBlock's 1x1 skip convolution (unet.py:112,143) is accumulated into the same MFMA accumulators as extra
 // 32-channel stages read from the block input (plain, centre tap), instead of a separate launch + residual round trip
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
-    using C = Cfg<KT, STRIDE, UPS, WM, WN>;
+    static_assert(SCH == 0 || (EPI == 0 && STRIDE == 1 && UPS == 0), "the fp16-range scheme serves stride-1 forward launches");
+    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef TQ_STAMP
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -148,13 +162,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     const bool wave_active = co_wave < p.C_out;
 
     const int Cin = p.C0 + p.C1;
-    const int nchunks = Cin >> 5;
-    const int nskip = FUSE ? ((p.sC0 + p.sC1) >> 5) : 0;
+    const int nchunks = Cin / C::CH;
+    const int nskip = FUSE ? ((p.sC0 + p.sC1) / C::CH) : 0;
     const int nstages = nchunks + nskip;  // stage s < nchunks: main chunk (KT taps); else skip chunk (centre tap)
     const int T_src = UPS ? 2 * p.T_in : p.T_in;  // extent of the (virtually upsampled) input
 
-    // ---- staging bookkeeping: thread owns 4 consecutive channels (m) of rows i = (tid + it*NTHR) >> 3
-    const int m = tid & 7;
+    // ---- staging bookkeeping: thread owns 4 consecutive channels (m) of rows i = (tid + it*NTHR) / TPR
+    const int m = tid % C::TPR;
     const int wslot = m >> 1, whalf = m & 1;  // 16-byte slot (k quarter) and 8-byte half owned by this thread
     float4 raw[C::PRE];
     float4 g_a, g_s;
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     auto chunk_base = [&](int stage, int& cs) -> const float* __attribute__((always_inline)) {
         const bool sk = FUSE && stage >= nchunks;
-        const int cb = (sk ? stage - nchunks : stage) << 5;
+        const int cb = (sk ? stage - nchunks : stage) * C::CH;
         const float* a0 = sk ? p.sx0 : p.x0;
         const float* a1 = sk ? p.sx1 : p.x1;
         const int c0 = sk ? p.sC0 : p.C0, c1 = sk ? p.sC1 : p.C1;
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // branch-free: out-of-range rows load a clamped (valid) row and are zeroed in write_one -- an exec-masked load would put
     // control flow in front of the MFMA phase and make hipcc drain every outstanding load there (s_waitcnt vmcnt(0))
     auto load_one = [&](const float* base, int cs, int it) -> float4 __attribute__((always_inline)) {
-        const int i = (tid + it * C::NTHR) >> 3;
+        const int i = (tid + it * C::NTHR) / C::TPR;
         int pos = src_pos(i);
         pos = pos < 0 ? 0 : (pos >= T_src ? T_src - 1 : pos);
         const int srow = UPS ? (pos >> 1) : pos;
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     auto write_one = [&](int chunk, int buf, int it, const float4& rv) __attribute__((always_inline)) {
         unsigned char* hi_plane = lds + buf * C::BUF;
         unsigned char* lo_plane = hi_plane + C::PLANE;
-        const int i = (tid + it * C::NTHR) >> 3;
+        const int i = (tid + it * C::NTHR) / C::TPR;
         const int pos = src_pos(i);
         const float msk = (pos >= 0 && pos < T_src) ? 1.f : 0.f;
         float u[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -210,29 +224,56 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                 u[j] = u[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[j] * -1.4426950408889634f));
         }
         if (ACT == 3 && act) {
-            const int cb = chunk << 5;
+            const int cb = chunk * C::CH;
             const int pc = pos < 0 ? 0 : pos;
             const uint64_t e0 = ((uint64_t)b * T_src + pc) * Cin + cb + 4 * m;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 u[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? u[j] * p.drop_scale : 0.f;
         }
-        uint32_t hb[4];
-        float lo[4];
+        if constexpr (SCH == 0) {
+            uint32_t hb[4];
+            float lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u[j] *= msk;
-            hb[j] = __float_as_uint(u[j]) & 0xFFFF0000u;  // hi = x truncated to bf16; lo (rounded) carries the remainder
-            lo[j] = u[j] - __uint_as_float(hb[j]);
+            for (int j = 0; j < 4; ++j) {
+                u[j] *= msk;
+                hb[j] = __float_as_uint(u[j]) & 0xFFFF0000u;  // hi = x truncated to bf16; lo (rounded) carries the remainder
+                lo[j] = u[j] - __uint_as_float(hb[j]);
+            }
+            uint2 hv;
+            hv.x = (hb[0] >> 16) | hb[1];
+            hv.y = (hb[2] >> 16) | hb[3];
+            bf16x4 l;
+            l[0] = (__bf16)lo[0]; l[1] = (__bf16)lo[1]; l[2] = (__bf16)lo[2]; l[3] = (__bf16)lo[3];
+            const int off = i * 64 + ((wslot ^ (((i >> 2) & 1) << 1)) << 4) + (whalf << 3);
+            *reinterpret_cast<uint2*>(hi_plane + off) = hv;
+            *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
+        } else {
+            // 128-byte rows of 8 x 16-byte units, unit' = unit ^ (row & 7): conflict-free for ds_read_b128 at every row offset.
+            // Main plane: fp16(x) (round to nearest), unit = channel / 8.  Correction plane: unit g (= channel / 16) holds
+            // fp8(xl * 2^12) of channels 16g..16g+15 and unit 4 + g holds fp8(x) of the same channels, so a lane group's two
+            // reads sit at byte offsets b and b ^ 64 of the row in both planes.
+            f16x4 hv;
+            float xl[4], xc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u[j] = __builtin_amdgcn_fmed3f(u[j] * msk, -60000.f, 60000.f);
+                hv[j] = (_Float16)u[j];
+                xl[j] = __builtin_amdgcn_fmed3f(u[j] - (float)hv[j], -0.109375f, 0.109375f);  // * 2^12 stays inside e4m3 (448)
+                xc[j] = __builtin_amdgcn_fmed3f(u[j], -448.f, 448.f);                           // (the conversions do not saturate)
+            }
+            i16x2 c8 = {0, 0};
+            c8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(c8, xl[0], xl[1], 0.000244140625f, false);  // divides by the scale
+            c8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(c8, xl[2], xl[3], 0.000244140625f, true);
+            int x8 = __builtin_amdgcn_cvt_pk_fp8_f32(xc[0], xc[1], 0, false);
+            x8 = __builtin_amdgcn_cvt_pk_fp8_f32(xc[2], xc[3], x8, true);
+            const int sw = i & 7;
+            const int row = i * 128;
+            *reinterpret_cast<f16x4*>(hi_plane + row + ((wslot ^ sw) << 4) + (whalf << 3)) = hv;
+            const int g = m >> 2, byte = (m & 3) << 2;
+            *reinterpret_cast<i16x2*>(lo_plane + row + ((g ^ sw) << 4) + byte) = c8;
+            *reinterpret_cast<int*>(lo_plane + row + (((4 + g) ^ sw) << 4) + byte) = x8;
         }
-        uint2 hv;
-        hv.x = (hb[0] >> 16) | hb[1];
-        hv.y = (hb[2] >> 16) | hb[3];
-        bf16x4 l;
-        l[0] = (__bf16)lo[0]; l[1] = (__bf16)lo[1]; l[2] = (__bf16)lo[2]; l[3] = (__bf16)lo[3];
-        const int off = i * 64 + ((wslot ^ (((i >> 2) & 1) << 1)) << 4) + (whalf << 3);
-        *reinterpret_cast<uint2*>(hi_plane + off) = hv;
-        *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
     };
 
     // phase 1 (before the MFMAs of the previous chunk): issue the first PRE iterations' loads
@@ -242,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #pragma unroll
         for (int it = 0; it < C::PRE; ++it) raw[it] = load_one(base, cs, it);
         if (ACT >= 1) {  // folded GroupNorm coefficients of this thread's 4 channels (skip stages: clamped, unused)
-            const int cb = (chunk < nchunks ? chunk : nchunks - 1) << 5;
+            const int cb = (chunk < nchunks ? chunk : nchunks - 1) * C::CH;
             g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
             g_s = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cb + 4 * m);
         }
@@ -275,15 +316,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     const int kq = lane >> 4;
     const int tl_lane = wn * 128 + (lane & 15);
-    const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * 2) * 64 + lane;
-    const size_t wstep = (size_t)p.ncob_pad * 2 * 64;  // uint4 per (chunk, tap)
+    const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * (C::NW / 2)) * 64 + lane;
+    const size_t wstep = (size_t)p.ncob_pad * (C::NW / 2) * 64;  // uint4 per (chunk, tap)
 
     // ---- MFMA phase of one chunk.  Written as straight-line code (no branches inside: hipcc's waitcnt insertion falls back to
     // s_waitcnt vmcnt(0) / lgkmcnt(0) at every control-flow join, which serialises each prefetch with its consumer) and pinned
     // with sched_barrier so that (1) the weight fragments of tap k+2 are requested before the MFMAs of tap k+1 and (2) the
     // LDS reads of t-block tb+1 are in flight under the MFMAs of t-block tb.
     const int last_step = nchunks * KT + nskip - 1;
-    auto load_w = [&](int step, Frag (&ah)[2], Frag (&al)[2]) __attribute__((always_inline)) {
+    // w[cbk * NW/2 + q]: scheme 0: q = 0 hi, 1 lo; scheme 1: q = 0, 1 fp16 fragments of channels [0,32), [32,64) of the chunk,
+    // q = 2 | 3 the 32 correction bytes (fp8(w) | fp8(wl * 2^12)) of channels 16 * (lane >> 4) ...
+    auto load_w = [&](int step, Frag (&w)[C::NW]) __attribute__((always_inline)) {
         const int st = step < last_step ? step : last_step;  // clamped: the final refills re-read the last fragments
 #ifdef TQ_ABL_NOW
         const uint4* wp = wbase + (size_t)(st & 1) * wstep;  // ablation: weights stay L1-resident
@@ -291,29 +334,62 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         const uint4* wp = wbase + (size_t)st * wstep;
 #endif
 #pragma unroll
-        for (int cbk = 0; cbk < 2; ++cbk) {
-            ah[cbk].u = wp[(cbk * 2 + 0) * 64];
-            al[cbk].u = wp[(cbk * 2 + 1) * 64];
-        }
+        for (int q = 0; q < C::NW; ++q) w[q].u = wp[q * 64];
     };
 
-    // LDS image: row = 64 B = 4 slots of 16 B (one k-quarter each), slot' = kq ^ (2 * ((row >> 2) & 1)): conflict-free for
+    // scheme 0 LDS image: row = 64 B = 4 slots of 16 B (one k-quarter each), slot' = kq ^ (2 * ((row >> 2) & 1)): conflict-free for
     // ds_read_b128 at every row offset (tap shift) and for the 8-byte staging stores.  Row of t-block tb is rowk + 16*tb, which
-    // leaves the swizzle term unchanged: one address per tap, t-blocks are immediate offsets.
+    // leaves the swizzle term unchanged (both schemes): one address per tap, t-blocks are immediate offsets.
     auto tap_base = [&](int k) -> int __attribute__((always_inline)) {
-        const int rowk = (STRIDE == 1) ? (tl_lane + k) : ((k & 1) * (C::NT + 1) + tl_lane + (k >> 1));
-        return rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
+        int tl = tl_lane;
+        if constexpr (SCH == 1) {
+            // recomputed per tap (4 VALU): hoisted out of the chunk loop the per-tap addresses are live across it, get spilled,
+            // and each reload waits for vmcnt(0), i.e. for the staging loads in flight
+            asm volatile("" : "+v"(tl));
+        }
+        const int rowk = (STRIDE == 1) ? (tl + k) : ((k & 1) * (C::NT + 1) + tl + (k >> 1));
+        if constexpr (SCH == 0) return rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
+        else return rowk * 128 + ((kq ^ (rowk & 7)) << 4);
     };
-    auto read_b = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int b0, int tb, Frag& bh, Frag& bl)
+    auto read_b = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int b0, int tb, Frag (&f)[C::NBF])
         __attribute__((always_inline)) {
 #ifdef TQ_ABL_NOLDS
         const int toff = 0;
         (void)tb;
 #else
-        const int toff = tb * 16 * 64;
+        const int toff = tb * 16 * C::ROWB;
 #endif
-        bh.u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);
-        bl.u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);
+        if constexpr (SCH == 0) {
+            f[0].u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);
+            f[1].u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);
+        } else {
+            f[0].u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);          // fp16, channels 8 kq ...
+            f[1].u = *reinterpret_cast<const uint4*>(hi_plane + (b0 ^ 64) + toff);   // fp16, channels 32 + 8 kq ...
+            f[2].u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);          // fp8(xl * 2^12), channels 16 kq ...
+            f[3].u = *reinterpret_cast<const uint4*>(lo_plane + (b0 ^ 64) + toff);   // fp8(x), same channels
+        }
+    };
+    // the MFMAs of one (tap, t-block) step for both 16-channel blocks of the wave
+    auto mma_step = [&](const Frag (&w)[C::NW], const Frag (&f)[C::NBF], int tb) __attribute__((always_inline)) {
+        if constexpr (SCH == 0) {
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = mfma_x3(w[cbk * 2].v, w[cbk * 2 + 1].v, f[0].v, f[1].v, acc[cbk][tb]);
+        } else {
+            const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
+                              (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
+            const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const Frag& c0 = w[cbk * 4 + 2];
+                const Frag& c1 = w[cbk * 4 + 3];
+                const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
+                // E8M0 scales: A 127 (2^0), B 115 (2^-12) on every lane: both correction products carry 2^-12
+                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 0, 0, 0, 127, 0, 115);
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 0].u), b0v, acc[cbk][tb], 0, 0, 0);
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 1].u), b1v, acc[cbk][tb], 0, 0, 0);
+            }
+        }
     };
 
 #ifndef TQ_LDS_DEPTH
@@ -322,38 +398,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // Weight fragments live in two register buffers (taps alternate a, b, a, ...); after tap k its buffer is refilled with
     // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
     // b = tap 1 already in flight.
-    Frag wa_h[2], wa_l[2], wb_h[2], wb_l[2];
+    Frag wa[C::NW], wb[C::NW];
+    constexpr int LDS_DEP = SCH ? 1 : TQ_LDS_DEPTH;  // scheme 1: 128 MFMA cycles per step, and registers are tight
 
-    // MFMA phase of one chunk = ONE stream of NTAPS x 8 (tap, t-block) steps.  B fragments are read TQ_LDS_DEPTH steps ahead of
-    // the 6 MFMAs that consume them, across tap boundaries too (a per-tap restart exposed the LDS latency KT times per chunk).
+    // MFMA phase of one chunk = ONE stream of NTAPS x 8 (tap, t-block) steps.  B fragments are read LDS_DEP steps ahead of the
+    // MFMAs that consume them, across tap boundaries too (a per-tap restart exposed the LDS latency KT times per chunk).
     auto mma_stream = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int s0, auto ntaps_c, auto first_tap_c)
         __attribute__((always_inline)) {
         constexpr int NTAPS = decltype(ntaps_c)::value, K0 = decltype(first_tap_c)::value;
-        constexpr int DEP = TQ_LDS_DEPTH, NB = TQ_LDS_DEPTH + 1, NS = NTAPS * 8;
-        Frag bh[NB], bl[NB];
+        constexpr int DEP = LDS_DEP, NB = LDS_DEP + 1, NS = NTAPS * 8;
+        Frag bf[NB][C::NBF];
         int b0 = tap_base(K0), b0n = b0;
 #pragma unroll
-        for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bh[t], bl[t]);
+        for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bf[t]);
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
             const int kk = st >> 3, tb = st & 7;
             if (tb == 0 && kk + 1 < NTAPS) b0n = tap_base(K0 + kk + 1);
             const int sn = st + DEP;  // step whose fragments are requested now
-            if (sn < NS) read_b(hi_plane, lo_plane, (sn >> 3) == kk ? b0 : b0n, sn & 7, bh[sn % NB], bl[sn % NB]);
+            if (sn < NS) read_b(hi_plane, lo_plane, (sn >> 3) == kk ? b0 : b0n, sn & 7, bf[sn % NB]);
             __builtin_amdgcn_sched_barrier(0);
-            if (kk & 1) {
-#pragma unroll
-                for (int cbk = 0; cbk < 2; ++cbk)
-                    acc[cbk][tb] = mfma_x3(wb_h[cbk].v, wb_l[cbk].v, bh[st % NB].v, bl[st % NB].v, acc[cbk][tb]);
-            } else {
-#pragma unroll
-                for (int cbk = 0; cbk < 2; ++cbk)
-                    acc[cbk][tb] = mfma_x3(wa_h[cbk].v, wa_l[cbk].v, bh[st % NB].v, bl[st % NB].v, acc[cbk][tb]);
-            }
+            if (kk & 1) mma_step(wb, bf[st % NB], tb); else mma_step(wa, bf[st % NB], tb);
             __builtin_amdgcn_sched_barrier(0);
             if (tb == 7) {  // tap done: refill its weight buffer two steps of the (chunk, tap) sequence ahead
                 const int nxt = (NTAPS == 1) ? (s0 + 1) : ((kk + 2 < NTAPS) ? (s0 + kk + 2) : ((kk & 1) ? (s0 + NTAPS + 1) : (s0 + NTAPS)));
-                if (kk & 1) load_w(nxt, wb_h, wb_l); else load_w(nxt, wa_h, wa_l);
+                if (kk & 1) load_w(nxt, wb); else load_w(nxt, wa);
                 b0 = b0n;
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -366,37 +435,34 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     };
 
     // skip stage j: one (centre) tap.  Buffer a holds this step's weights and b the next one's (the last main chunk's
-    // wrap-around refills fetched skip steps 0 / 1 as "next chunk, taps 0 / 1"); the single-tap stream refills a with step + 1
-    // -- which b already holds -- so b is shifted into a and refilled instead: every buffer access stays statically indexed
-    // (a pointer select between a and b would demote both to scratch)
+    // wrap-around refills fetched skip steps 0 / 1 as "next chunk, taps 0 / 1"); b is shifted into a afterwards and refilled:
+    // every buffer access stays statically indexed (a pointer select between a and b would demote both to scratch)
     auto compute_skip = [&](int j, int buf) __attribute__((always_inline)) {
         const unsigned char* hi_plane = lds + buf * C::BUF;
         const unsigned char* lo_plane = hi_plane + C::PLANE;
-        constexpr int DEP = TQ_LDS_DEPTH, NB = TQ_LDS_DEPTH + 1;
-        Frag bh[NB], bl[NB];
+        constexpr int DEP = LDS_DEP, NB = LDS_DEP + 1;
+        Frag bf[NB][C::NBF];
         const int b0 = tap_base(C::PAD);
 #pragma unroll
-        for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bh[t], bl[t]);
+        for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bf[t]);
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) {
-            if (tb + DEP < 8) read_b(hi_plane, lo_plane, b0, tb + DEP, bh[(tb + DEP) % NB], bl[(tb + DEP) % NB]);
+            if (tb + DEP < 8) read_b(hi_plane, lo_plane, b0, tb + DEP, bf[(tb + DEP) % NB]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cbk = 0; cbk < 2; ++cbk)
-                acc[cbk][tb] = mfma_x3(wa_h[cbk].v, wa_l[cbk].v, bh[tb % NB].v, bl[tb % NB].v, acc[cbk][tb]);
+            mma_step(wa, bf[tb % NB], tb);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { wa_h[i] = wb_h[i]; wa_l[i] = wb_l[i]; }
-        load_w(nchunks * KT + j + 2, wb_h, wb_l);
+        for (int q = 0; q < C::NW; ++q) wa[q] = wb[q];
+        load_w(nchunks * KT + j + 2, wb);
         __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- main loop over the stages (32-channel chunks of the conv input, then of the fused skip input)
     stage_load(0);
     if (wave_active) {
-        load_w(0, wa_h, wa_l);
-        if (KT > 1 || nskip > 0) load_w(1, wb_h, wb_l);
+        load_w(0, wa);
+        if (KT > 1 || nskip > 0) load_w(1, wb);
     }
     stage_write(0, 0);
     __syncthreads();
@@ -575,10 +641,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #endif
 }
 
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH = 0>
 int launch(const ConvArgs& a, hipStream_t stream) {
-    using C = Cfg<KT, STRIDE, UPS, WM, WN>;
-    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE>;
+    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -596,6 +662,16 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 
 template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
+    if (a.wfmt == TQ_WFMT_F16_MX8) {  // built for stride-1 forward launches with 128 | C_out and 64-channel sources, without the
+        // fused skip conv (its extra live state does not fit the 256 registers of two waves per SIMD next to this scheme's)
+        if constexpr (STRIDE == 1 && UPS == 0 && EPI == 0 && !FUSE) {
+            if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
+            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
+            if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
+        }
+        return TQ_ERR_SHAPE;
+    }
+    if (a.wfmt != TQ_WFMT_BF16X3) return TQ_ERR_ARG;
     // 256 output channels: one 8-wave workgroup stages each input tile once instead of two 4-wave workgroups staging it
     // twice (measured -32 % for pointwise convs, which are staging-bound, and -2...-5 % for k = 5)
     if constexpr (STRIDE == 1 && UPS == 0) {
@@ -697,6 +773,7 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.drop_scale = 1.0f / (1.0f - pdrop);
     a.fx0 = a.fx1 = a.fgs = a.fgh = nullptr; a.y1 = nullptr; a.OC0 = d->C_out; a.bflags = 0;
     a.sx0 = skip_x0; a.sx1 = skip_x1; a.sbias = skip_bias; a.sC0 = d->C_skip0; a.sC1 = d->C_skip1;
+    a.wfmt = d->wfmt;
 
     if (d->stride == 2 || d->upsample) {
         if (a.flags & (TQ_CONV_GN | TQ_CONV_SILU | TQ_CONV_DROPOUT)) return TQ_ERR_SHAPE;  // resampling convs take raw inputs
@@ -745,6 +822,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.drop_scale = 1.0f / (1.0f - pdrop);
     a.fx0 = x0; a.fx1 = x1; a.fgs = gscale; a.fgh = gshift; a.y1 = dx1; a.OC0 = d->C_dx0;
     a.sx0 = a.sx1 = a.sbias = nullptr; a.sC0 = a.sC1 = 0;
+    a.wfmt = TQ_WFMT_BF16X3;  // gradients keep fp32 range
     switch (d->ktaps) {
         case 1: return dispatch_tile<1, 1, 0, 1, 0>(a, stream);
         case 3: return dispatch_tile<3, 1, 0, 1, 0>(a, stream);
@@ -758,8 +836,54 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
 //   lane l holds A[row = cob*16 + (l&15)][k = chunk*32 + 8*(l>>4) + j], j = 0..7
 // mode 0: A[row=co][k=ci] = W[co][ci][tap]                           (forward)
 // mode 1: A[row=ci][k=co] = W[co][ci][K-1-tap]                       (data gradient: transposed, flipped)
+// mode 2: forward, TQ_WFMT_F16_MX8 (same total size as mode 0 when 64 | C_in): per 64-channel chunk, tap and 16-row block four
+//   16-byte fragments per lane (row = cob*16 + (l&15), kq = l>>4):  [0] fp16 W of channels 8 kq + j,  [1] of 32 + 8 kq + j (j < 8);
+//   [2] fp8(W) of channels 16 kq + j,  [3] fp8((W - fp16(W)) * 2^12) of the same channels (j < 16)
 // ------------------------------------------------------------------------------------------------
 namespace {
+__global__ void pack_conv_weight_mx_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
+                                           uint4* __restrict__ out) {
+    const int nchunks = (C_in + 63) / 64;
+    const size_t total = (size_t)nchunks * K * ncob_pad * 64;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int lane = gid & 63;
+    size_t r = gid >> 6;
+    const int cob = r % ncob_pad; r /= ncob_pad;
+    const int tap = r % K;
+    const int chunk = r / K;
+    const int row = cob * 16 + (lane & 15), kq = lane >> 4;
+    auto wv = [&](int ch) -> float {
+        return (row < C_out && ch < C_in) ? w[((size_t)row * C_in + ch) * K + tap] : 0.f;
+    };
+    f16x8 m0, m1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m0[j] = (_Float16)wv(chunk * 64 + 8 * kq + j);
+        m1[j] = (_Float16)wv(chunk * 64 + 32 + 8 * kq + j);
+    }
+    int c0[4], c1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = wv(chunk * 64 + 16 * kq + 4 * q + j);
+            a[j] = __builtin_amdgcn_fmed3f(v, -448.f, 448.f);
+            l[j] = __builtin_amdgcn_fmed3f((v - (float)(_Float16)v) * 4096.f, -448.f, 448.f);
+        }
+        c0[q] = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false);
+        c0[q] = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], c0[q], true);
+        c1[q] = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], l[1], 0, false);
+        c1[q] = __builtin_amdgcn_cvt_pk_fp8_f32(l[2], l[3], c1[q], true);
+    }
+    const size_t o = ((((size_t)chunk * K + tap) * ncob_pad + cob) * 4) * 64 + lane;
+    out[o] = __builtin_bit_cast(uint4, m0);
+    out[o + 64] = __builtin_bit_cast(uint4, m1);
+    out[o + 128] = make_uint4((unsigned)c0[0], (unsigned)c0[1], (unsigned)c0[2], (unsigned)c0[3]);
+    out[o + 192] = make_uint4((unsigned)c1[0], (unsigned)c1[1], (unsigned)c1[2], (unsigned)c1[3]);
+}
+
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int mode,
                                         int rows, int kdim, int ncob_pad, uint4* __restrict__ out) {
     const int nchunks = (kdim + 31) / 32;
@@ -792,6 +916,10 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int C_out, 
 }  // namespace
 
 extern "C" size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode) {
+    if (mode == 2) {
+        const int tile2 = tq_conv_tile_co(C_out);
+        return (size_t)((C_in + 63) / 64) * K * (((C_out + tile2 - 1) / tile2) * tile2 / 16) * 4 * 64 * 16;
+    }
     const int rows = mode == 0 ? C_out : C_in;
     const int kdim = mode == 0 ? C_in : C_out;
     const int tile = tq_conv_tile_co(rows);
@@ -801,11 +929,18 @@ extern "C" size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode
 }
 
 extern "C" int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* out, hipStream_t stream) {
-    if (!w || !out || C_out <= 0 || C_in <= 0 || K <= 0 || (mode != 0 && mode != 1)) return TQ_ERR_ARG;
-    const int rows = mode == 0 ? C_out : C_in;
-    const int kdim = mode == 0 ? C_in : C_out;
+    if (!w || !out || C_out <= 0 || C_in <= 0 || K <= 0 || mode < 0 || mode > 2) return TQ_ERR_ARG;
+    const int rows = mode != 1 ? C_out : C_in;
+    const int kdim = mode != 1 ? C_in : C_out;
     const int tile = tq_conv_tile_co(rows);
     const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
+    if (mode == 2) {
+        const size_t total2 = (size_t)((C_in + 63) / 64) * K * ncob_pad * 64;
+        hipLaunchKernelGGL(pack_conv_weight_mx_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, w, C_out,
+                           C_in, K, ncob_pad, reinterpret_cast<uint4*>(out));
+        TQ_CHECK_LAUNCH();
+        return 0;
+    }
     const int nchunks = (kdim + 31) / 32;
     const size_t total = (size_t)nchunks * K * ncob_pad * 64;
     const unsigned grid = (unsigned)((total + 255) / 256);

@@ -73,7 +73,7 @@ class ConvRec:
 class ConvSite:
     """One convolution's weights: torch parameter + packed bf16 hi/lo MFMA fragments."""
 
-    __slots__ = ("weight", "bias", "packed", "packed_t", "C_out", "C_in", "K", "version", "name")
+    __slots__ = ("weight", "bias", "packed", "packed_t", "C_out", "C_in", "K", "version", "name", "pack_mode")
 
     def __init__(self, name, weight, bias, device, lib, packed=None, tail_bytes=0):
         self.name = name
@@ -82,6 +82,7 @@ class ConvSite:
         nbytes = lib.tq_conv_weight_pack_bytes(self.C_out, self.C_in, self.K, 0)
         # tail_bytes: room for a second conv's fragments right behind this one's (fused skip conv, tq_conv1d_fwd_skip)
         self.packed = packed if packed is not None else torch.empty(nbytes + tail_bytes, dtype=torch.uint8, device=device)
+        self.pack_mode = 0     # tq_pack_conv_weight mode of `packed` (2: TQ_WFMT_F16_MX8), set by the plan builder
         self.packed_t = None  # transposed / tap-flipped fragments for the data gradient (training only)
         self.version = -1
 
@@ -198,6 +199,12 @@ class UNetEngine:
             flags |= TQ_CONV_STATS
         d.flags = flags
         d.emb_stride = self.emb_total
+        srcs_c = [d.C_in0, d.C_in1] + ([a.C for a in skip[0]] if skip is not None else [])
+        d.wfmt = _lib.forward_wfmt(site.C_out, srcs_c, stride, upsample, fused_skip=skip is not None) if launch else 0
+        if launch:
+            site.pack_mode = 2 if d.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+            if skip is not None:
+                skip[1].pack_mode = site.pack_mode
         d.dropout_site = dropout_site or 0
         d.dropout_p = 0.0
         d.dropout_seed = 0
@@ -366,7 +373,7 @@ class UNetEngine:
             return
         lib = self.lib
         for s in self.conv_sites:
-            check(lib.tq_pack_conv_weight(s.weight.data_ptr(), s.C_out, s.C_in, s.K, 0, s.packed.data_ptr(), stream),
+            check(lib.tq_pack_conv_weight(s.weight.data_ptr(), s.C_out, s.C_in, s.K, s.pack_mode, s.packed.data_ptr(), stream),
                   "pack " + s.name)
         with torch.no_grad():
             for rb in self.res_blocks:

@@ -34,7 +34,7 @@ def pack_conv_weight(w: torch.Tensor, mode: int = 0) -> torch.Tensor:
 
 
 def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=False, emb=None, residual=None,
-           stride=1, upsample=False, stats=True, dropout_p=0.0, dropout_seed=0, dropout_site=0, skip=None):
+           stride=1, upsample=False, stats=True, dropout_p=0.0, dropout_seed=0, dropout_site=0, skip=None, wfmt=None):
     """x0/x1 (B, T, C) channels-last fp32; weight (C_out, C_in, K) torch layout.  Returns (y, stats|None).
     skip=(sx0, sx1|None, w_skip (C_out, Cs, 1), b_skip|None): fused 1x1 conv of the un-activated sx (tq_conv1d_fwd_skip)."""
     lib = _lib.load()
@@ -64,12 +64,17 @@ def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=Fal
     d.flags = f
     d.emb_stride = 0 if emb is None else emb.stride(0)
     d.dropout_site, d.dropout_p, d.dropout_seed = dropout_site, dropout_p, dropout_seed
-    wp = pack_conv_weight(weight, 0)
+    if wfmt is None:
+        srcs = [C0, C1] + ([skip[0].shape[2], 0 if skip[1] is None else skip[1].shape[2]] if skip is not None else [])
+        wfmt = _lib.forward_wfmt(C_out, srcs, stride, upsample, fused_skip=skip is not None)
+    d.wfmt = wfmt
+    pmode = 2 if wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+    wp = pack_conv_weight(weight, pmode)
     if skip is not None:
         sx0, sx1, wsk, bsk = skip
         assert residual is None
         d.C_skip0, d.C_skip1 = sx0.shape[2], (0 if sx1 is None else sx1.shape[2])
-        wp = torch.cat([wp, pack_conv_weight(wsk, 0)])
+        wp = torch.cat([wp, pack_conv_weight(wsk, pmode)])
         check(lib.tq_conv1d_fwd_skip(C.byref(d), _p(x0), _p(x1), _p(gscale), _p(gshift), _p(wp), _p(bias), _p(emb), _p(sx0),
                                      _p(sx1), _p(bsk), _p(y), _p(st), _stream(x0.device)), "conv1d_skip")
         return y, st
