@@ -126,7 +126,7 @@ struct Cfg {
 // 32-channel stages read from the block input (plain, centre tap), instead of a separate launch + residual round trip
 template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
-    static_assert(SCH == 0 || (EPI == 0 && STRIDE == 1 && UPS == 0), "the fp16-range scheme serves stride-1 forward launches");
+    static_assert(SCH == 0 || (EPI == 0 && STRIDE == 1), "the fp16-range scheme serves stride-1 forward launches");
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef TQ_STAMP
@@ -664,9 +664,11 @@ template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     if (a.wfmt == TQ_WFMT_F16_MX8) {  // built for stride-1 forward launches with 128 | C_out and 64-channel sources, without the
         // fused skip conv (its extra live state does not fit the 256 registers of two waves per SIMD next to this scheme's)
-        if constexpr (STRIDE == 1 && UPS == 0 && EPI == 0 && !FUSE) {
+        if constexpr (STRIDE == 1 && EPI == 0 && !FUSE) {
             if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
-            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
+            if constexpr (UPS == 0) {
+                if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
+            }
             if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
         }
         return TQ_ERR_SHAPE;
