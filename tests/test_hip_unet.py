@@ -444,3 +444,28 @@ def test_consistency_training_step_vs_reference():
             ref = torch.from_numpy(s[k])
             e = float((grads[k[2:]].grad.cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-3 * gmax))
             assert e < TOL, (k, e)
+
+
+def test_two_lane_training_step_matches_one_lane():
+    """fused training step on two streams (sub-batches of 16): same loss and gradients as one stream (summation order only)"""
+    from tqdne_amd import LightningEDM
+    from tqdne_amd.autograd import edm_loss_and_grads
+    sd, _ = load_golden("micro_unet.npz")
+    _, d = load_golden("micro_edm.npz")
+    edm = LightningEDM(dict(cfg_of(d), dropout=0.0), {"learning_rate": 1e-3, "max_steps": 10, "eta_min": 0.0})
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev()).train()
+    g = torch.Generator().manual_seed(12)
+    B, T = 32, 256
+    sig = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev())
+    cond = torch.randn(B, 5, generator=g).to(dev())
+    eps, noise = torch.randn(B, generator=g).to(dev()), torch.randn(B, 3, T, generator=g).to(dev())
+    l1, f1 = edm_loss_and_grads(edm, sig, eps, noise, cond, lanes=1)
+    g1 = {n: p.grad.clone() for n, p in edm.unet.named_parameters() if p.grad is not None}
+    l2, f2 = edm_loss_and_grads(edm, sig, eps, noise, cond, lanes=2)
+    assert rel_err(l2.cpu(), l1.cpu()) < 1e-6
+    gmax = max(float(v.abs().max()) for v in g1.values())
+    for n, p in edm.unet.named_parameters():
+        if n in g1:
+            e = float((p.grad - g1[n]).abs().max()) / max(float(g1[n].abs().max()), 1e-3 * gmax)
+            assert e < 1e-4, (n, e)

@@ -27,7 +27,7 @@ class _EDMLossFn(th.autograd.Function):
         per = sample[0].numel()
         dev = sample.device
         stream = th.cuda.current_stream(dev).cuda_stream
-        key = ("train", tuple(sample.shape), str(dev))
+        key = ("train", tuple(sample.shape), str(dev), module._lane)
         bufs = module._scal.get(key)
         if bufs is None:
             bufs = dict(sigma=th.empty(B, device=dev), x=th.empty_like(sample), loss=th.empty(1, device=dev),
@@ -53,30 +53,74 @@ class _EDMLossFn(th.autograd.Function):
     def backward(ctx, gloss):
         module, bufs = ctx.module, ctx.bufs
         B, _, T = ctx.shape
-        eng = module.unet._engine(B, T, bufs["x"].device)
+        eng = module.unet._engine(B, T, bufs["x"].device, module._lane)
         sc = module._scalars(B, bufs["x"].device)
         grads = eng.backward(bufs["dpred"], gloss, c_out=sc[1], in_scale=None if ctx.concat else sc[0])
         return (None, None, None, None, None, None) + tuple(grads)
 
 
-def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None):
+def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, lanes=None):
     """Fused training step without the autograd round trip: runs the HIP forward and backward back to back and leaves the
     gradients in the backward plan's flat buffer; ``p.grad`` of every UNet parameter is (re)bound to its view of that buffer.
     Returns (loss, flat_gradient_buffer).  Used by DataParallelTrainer (one all-reduce over the flat buffer, no per-parameter
-    accumulation kernels)."""
+    accumulation kernels).
+
+    ``lanes`` > 1: the batch is split into sub-batches whose forward + backward run on separate HIP streams with their own plans
+    (see LightningEDM.sample_deterministically); the loss is the mean of the sub-batch losses (``gloss = 1 / lanes`` scales each
+    backward) and the lanes' flat gradient buffers are summed into lane 0's.  Default ``train_lanes(B)``."""
     params = list(module.unet.parameters())
+    B = sample.shape[0]
+    if lanes is None:
+        lanes = train_lanes(B)
+    if lanes < 2 or B % lanes:
+        lanes = 1
+    dev = sample.device
+    h = B // lanes
+    main = th.cuda.current_stream(dev)
+    streams = [main] + [module._side_stream(dev, i) for i in range(1, lanes)]
+    cut = lambda t, i: None if t is None else t[i * h:(i + 1) * h].contiguous()
+    losses, flats = [], []
     with th.no_grad():
-        loss = _EDMLossFn.forward(_Ctx, module, sample, eps, unit_noise, cond, cond_sample, *params)
-        bufs = _Ctx.bufs
-        B, _, T = _Ctx.shape
-        eng = module.unet._engine(B, T, bufs["x"].device)
-        one = th.ones((), device=bufs["x"].device)
-        sc = module._scalars(B, bufs["x"].device)
-        grads = eng.backward(bufs["dpred"], one, clone=False, c_out=sc[1], in_scale=None if cond_sample is not None else sc[0])
-        for p, g in zip(params, grads):
+        for st in streams[1:]:
+            st.wait_stream(main)
+        try:
+            for i, st in enumerate(streams):
+                module._lane = i
+                with th.cuda.stream(st):
+                    loss = _EDMLossFn.forward(_Ctx, module, cut(sample, i) if lanes > 1 else sample, cut(eps, i) if lanes > 1 else eps,
+                                              cut(unit_noise, i) if lanes > 1 else unit_noise, cut(cond, i) if lanes > 1 else cond,
+                                              cut(cond_sample, i) if lanes > 1 else cond_sample, *params)
+                    bufs = _Ctx.bufs
+                    Bl, _, T = _Ctx.shape
+                    eng = module.unet._engine(Bl, T, dev, i)
+                    scale = th.full((), 1.0 / lanes, device=dev)
+                    grads = eng.backward(bufs["dpred"], scale, clone=False)
+                    losses.append(loss)
+                    flats.append(eng._bwd.flat)
+                    if i == 0:
+                        grads0 = grads
+        finally:
+            module._lane = 0
+        for i, st in enumerate(streams[1:], 1):
+            main.wait_stream(st)
+        for f in flats[1:]:
+            flats[0].add_(f)
+        for p, g in zip(params, grads0):
             if g is not None and (p.grad is None or p.grad.data_ptr() != g.data_ptr()):
                 p.grad = g
-    return loss, eng._bwd.flat
+        loss = losses[0] if lanes == 1 else th.stack(losses).mean()
+    return loss, flats[0]
+
+
+def train_lanes(B: int) -> int:
+    """Sub-batches the fused training step runs concurrently: 1 unless TQDNE_TRAIN_LANES asks for more (measured at B = 64:
+    2 lanes -5 % on the train step = 0.7 % of the bench step, 4 lanes 0; not the default, so that the bench's HIP-event probe
+    times B = 64 launches that run alone on their stream)."""
+    import os
+    env = os.environ.get("TQDNE_TRAIN_LANES")
+    if env is not None:
+        return max(1, int(env))
+    return 1
 
 
 class _Ctx:
