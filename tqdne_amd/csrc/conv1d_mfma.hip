@@ -587,31 +587,40 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         // on x is handled by tq_gn_bwd_finalize / tq_gn_bwd_apply from the partial sums (sum g, sum g*x) emitted here)
         const int slot = (t0 >> 7) + wn;
         const int Ctot = p.C_out;
+        // as in the forward epilogue: t-block outer, channel block inner, so the two halves of a 128-byte line are stored together
+        float* dst[2]; const float* fx[2]; int cs[2], cc[2];
+        float4 ga[2], gs[2];
+        float s1[2][4], s2[2][4];
 #pragma unroll
         for (int cbk = 0; cbk < 2; ++cbk) {
             const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
-            float* dst; const float* fx; int cs, cc;
-            if (co < p.OC0) { dst = p.y; fx = p.fx0; cs = p.OC0; cc = co; }
-            else            { dst = p.y1; fx = p.fx1; cs = Ctot - p.OC0; cc = co - p.OC0; }
-            float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), gs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < p.OC0) { dst[cbk] = p.y; fx[cbk] = p.fx0; cs[cbk] = p.OC0; cc[cbk] = co; }
+            else            { dst[cbk] = p.y1; fx[cbk] = p.fx1; cs[cbk] = Ctot - p.OC0; cc[cbk] = co - p.OC0; }
+            ga[cbk] = make_float4(1.f, 1.f, 1.f, 1.f); gs[cbk] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bflags & TQ_BWD_GN) {
-                ga = *reinterpret_cast<const float4*>(p.fgs + (size_t)b * Ctot + co);
-                gs = *reinterpret_cast<const float4*>(p.fgh + (size_t)b * Ctot + co);
+                ga[cbk] = *reinterpret_cast<const float4*>(p.fgs + (size_t)b * Ctot + co);
+                gs[cbk] = *reinterpret_cast<const float4*>(p.fgh + (size_t)b * Ctot + co);
             }
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int tb = 0; tb < 8; ++tb) {
-                const int t = t0 + wn * 128 + tb * 16 + (lane & 15);
-                if (t < p.T_out) {
-                    const size_t o = ((size_t)b * p.T_out + t) * cs + cc;
+            for (int j = 0; j < 4; ++j) { s1[cbk][j] = 0.f; s2[cbk][j] = 0.f; }
+        }
+#pragma unroll
+        for (int tb = 0; tb < 8; ++tb) {
+            const int t = t0 + wn * 128 + tb * 16 + (lane & 15);
+            if (t < p.T_out) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk) {
+                    const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+                    const size_t o = ((size_t)b * p.T_out + t) * cs[cbk] + cc[cbk];
                     float v[4] = {acc[cbk][tb][0], acc[cbk][tb][1], acc[cbk][tb][2], acc[cbk][tb][3]};
                     float xv[4] = {0.f, 0.f, 0.f, 0.f};
                     if (p.bflags & (TQ_BWD_GN | TQ_BWD_SILU | TQ_BWD_STATS)) {
-                        const float4 x4 = *reinterpret_cast<const float4*>(fx + o);
+                        const float4 x4 = *reinterpret_cast<const float4*>(fx[cbk] + o);
                         xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
                     }
                     if (p.bflags & TQ_BWD_SILU) {
-                        const float a4[4] = {ga.x, ga.y, ga.z, ga.w}, h4[4] = {gs.x, gs.y, gs.z, gs.w};
+                        const float a4[4] = {ga[cbk].x, ga[cbk].y, ga[cbk].z, ga[cbk].w};
+                        const float h4[4] = {gs[cbk].x, gs[cbk].y, gs[cbk].z, gs[cbk].w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] *= dsilu_f(a4[j] * xv[j] + h4[j]);
                     }
@@ -622,27 +631,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                             v[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
                     }
                     if (p.bflags & TQ_BWD_ACCUM) {
-                        const float4 r = *reinterpret_cast<const float4*>(dst + o);
+                        const float4 r = *reinterpret_cast<const float4*>(dst[cbk] + o);
                         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
                     }
-                    *reinterpret_cast<float4*>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst[cbk] + o) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * xv[j]; }
+                    for (int j = 0; j < 4; ++j) { s1[cbk][j] += v[j]; s2[cbk][j] += v[j] * xv[j]; }
                 }
             }
-            if (p.bflags & TQ_BWD_STATS) {
+        }
+        if (p.bflags & TQ_BWD_STATS) {
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) {
-                        s1[j] += __shfl_xor(s1[j], o);
-                        s2[j] += __shfl_xor(s2[j], o);
+                        s1[cbk][j] += __shfl_xor(s1[cbk][j], o);
+                        s2[cbk][j] += __shfl_xor(s2[cbk][j], o);
                     }
                 }
                 if ((lane & 15) == 0 && slot < p.nslots) {
                     float* st = p.stats + (((size_t)b * p.nslots + slot) * Ctot + co) * 2;
-                    *reinterpret_cast<float4*>(st) = make_float4(s1[0], s2[0], s1[1], s2[1]);
-                    *reinterpret_cast<float4*>(st + 4) = make_float4(s1[2], s2[2], s1[3], s2[3]);
+                    *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
+                    *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
                 }
             }
         }
