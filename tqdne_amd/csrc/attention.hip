@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nqt = (T + QT - 1) / QT;
-    int bid = blockIdx.x;
+    int bid = xcd_group_id(blockIdx.x, nqt, gridDim.x / nqt);  // the tiles of one (b, h) share an XCD's L2
     const int qt = bid % nqt; bid /= nqt;
     const int h = bid % H;
     const int b = bid / H;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int nqt = (T + 127) / 128;
-    int bid = blockIdx.x;
+    int bid = xcd_group_id(blockIdx.x, nqt, gridDim.x / nqt);  // the tiles of one (b, h) share an XCD's L2
     const int qt = bid % nqt; bid /= nqt;
     const int h = bid % H;
     const int b = bid / H;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nqt = (T + 63) / 64;
-    int bid = blockIdx.x;
+    int bid = xcd_group_id(blockIdx.x, nqt, gridDim.x / nqt);  // the tiles of one (b, h) share an XCD's L2
     const int qt = bid % nqt; bid /= nqt;
     const int h = bid % H;
     const int b = bid / H;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dkv_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkt = (T + 63) / 64;
-    int bid = blockIdx.x;
+    int bid = xcd_group_id(blockIdx.x, nkt, gridDim.x / nkt);  // the tiles of one (b, h) share an XCD's L2
     const int kt = bid % nkt; bid /= nkt;
     const int h = bid % H;
     const int b = bid / H;

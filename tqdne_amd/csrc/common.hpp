@@ -60,6 +60,16 @@ __device__ __forceinline__ f32x4 mfma_x3(const bf16x8& ah, const bf16x8& al, con
     return c;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): ids i and i + 8 share an L2.  Kernels whose `inner`
+// consecutive workgroups re-read the same operand (the query tiles of one (batch, head) all stream its K / V) remap the linear id
+// so that those workgroups land on ONE XCD: on XCD x the s-th workgroup gets outer = x + 8 * (s / inner), inner index s % inner.
+// Falls back to the identity when the outer count is not a multiple of 8.
+__device__ __forceinline__ int xcd_group_id(int bid, int inner, int n_outer) {
+    if (n_outer & 7) return bid;
+    const int x = bid & 7, s = bid >> 3;
+    return (x + 8 * (s / inner)) * inner + (s % inner);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
