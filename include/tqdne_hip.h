@@ -104,6 +104,13 @@ int tq_conv1d_fwd_skip(const TqConvDesc* desc, const float* x0, const float* x1,
                        const void* packed_w_main_then_skip, const float* bias, const float* emb, const float* skip_x0,
                        const float* skip_x1, const float* skip_bias, float* y, float* stats_partial, hipStream_t stream);
 
+/* Inference form of the AttentionBlock's qkv projection (blocks.py:127-145): 1x1 conv of GN(x) whose K and V output channels are
+ * written directly as the pre-split bf16 planes tq_attention_fwd_presplit streams (K pre-scaled by D^-1/4), q as fp32 into
+ * qkv (B, T, 3 H D) (its K / V part is left untouched).  kv_planes: tq_attention_workspace_bytes(B, T, H, D) bytes whose rows
+ * t >= T (padding to a multiple of 64) must be zero.  desc: ktaps 1, single source, C_out = 3 H D, flags none or TQ_CONV_GN. */
+int tq_conv1d_fwd_qkv(const TqConvDesc* desc, const float* x, const float* gscale, const float* gshift, const void* packed_w,
+                      const float* bias, float* qkv, void* kv_planes, int H, int D, hipStream_t stream);
+
 /* Data gradient of tq_conv1d_fwd (stride 1): g = (W^T * dy) chained through the forward prologue (dropout, SiLU,
  * folded GN scale); packed_w_t from tq_pack_conv_weight(mode 1).  x0/x1/gscale/gshift are the FORWARD conv's inputs.
  * Autograd counterpart of the ATen conv/SiLU/dropout backward chain Lightning runs for edm.py:136 training_step. */
@@ -182,6 +189,8 @@ int tq_attention_fwd(const float* qkv, float* out, float* lse /* (B,H,T) log-sum
                      int H, int D, hipStream_t stream);
 /* backward of the above (recomputes P from qkv and lse): dqkv (B, T, 3*H*D) from dout (B, T, H*D);
  * delta (B,H,T) is scratch.  Two passes: queries-stationary for dq, keys-stationary for dk/dv (no atomics). */
+/* attention core on q from qkv and K / V planes already written by tq_conv1d_fwd_qkv (no log-sum-exp output: inference) */
+int tq_attention_fwd_presplit(const float* qkv, const void* kv_planes, float* out, int B, int T, int H, int D, hipStream_t stream);
 int tq_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv, int B,
                      int T, int H, int D, hipStream_t stream);
 

@@ -469,3 +469,33 @@ def test_two_lane_training_step_matches_one_lane():
         if n in g1:
             e = float((p.grad - g1[n]).abs().max()) / max(float(g1[n].abs().max()), 1e-3 * gmax)
             assert e < 1e-4, (n, e)
+
+
+@pytest.mark.parametrize("which", ["micro", "paper"])
+def test_inference_forward_matches_backward_capable_forward(which):
+    """infer=True plans (qkv projection writing the attention kernel's pre-split K / V planes itself, no fp32 K / V, no split
+    pass) compute the same arithmetic as the default plan: bit-identical outputs; and they refuse a backward"""
+    from tqdne_amd import UNetModel, paper_1d_unet_config
+    if which == "micro":
+        sd, d = load_golden("micro_unet.npz")
+        cfg, T = cfg_of(d), 248  # heads of 32 channels, ragged T (padding rows of the planes)
+        net = UNetModel(**cfg)
+        net.load_state_dict(sd)
+    else:
+        cfg, T = paper_1d_unet_config(), 4096
+        torch.manual_seed(0)
+        net = UNetModel(**cfg)
+        net.load_state_dict(perturbed_state(net, 3))
+    net = net.to(dev()).eval()
+    g = torch.Generator().manual_seed(4)
+    B = 2
+    x = torch.randn(B, cfg["in_channels"], T, generator=g).to(dev())
+    t = torch.randn(B, generator=g).to(dev())
+    cond = torch.randn(B, 5, generator=g).to(dev())
+    eng = net._engine(B, T, dev())
+    a = eng.forward(x, t, cond).clone()
+    b = eng.forward(x, t, cond, infer=True).clone()
+    assert torch.equal(a, b)
+    assert any(op[2].endswith("+split") for op in eng.ops_infer) and len(eng.ops) == len(eng.ops_infer)
+    with pytest.raises(RuntimeError):
+        eng.backward(torch.zeros_like(a), torch.ones((), device=dev()))

@@ -73,6 +73,8 @@ _PROTOS = {
     "tq_embed_fwd": (I, [VP] * 14 + [I, I, I, VP]),
     "tq_linear_fwd": (I, [VP] * 4 + [I, I, I, VP]),
     "tq_attention_fwd": (I, [VP, VP, VP, VP, I, I, I, I, VP]),
+    "tq_attention_fwd_presplit": (I, [VP, VP, VP, I, I, I, I, VP]),
+    "tq_conv1d_fwd_qkv": (I, [C.POINTER(TqConvDesc)] + [VP] * 7 + [I, I, VP]),
     "tq_attention_workspace_bytes": (SZ, [I, I, I, I]),
     "tq_attention_bwd": (I, [VP] * 6 + [I, I, I, I, VP]),
     "tq_edm_scalars": (I, [VP, I, F, VP, VP, VP, VP, VP, I, VP]),

@@ -65,7 +65,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         self.lognormal_mean, self.lognormal_std, self.lr = lognormal_mean, lognormal_std, lr
         self._scal = {}
 
-    def _forward_static(self, sample, sigma, cond, lane=0, train=False, dropout_seed=0):
+    def _forward_static(self, sample, sigma, cond, lane=0, train=False, dropout_seed=0, infer=False):
         lib = _lib.load()
         B, _, T = sample.shape
         dev = sample.device
@@ -79,7 +79,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
               "cm scalars")
         eng = self.net._engine(B, T, dev, lane)
         return eng.forward(sample, sigma, cond, in_scale=None, c_out=sc[0], c_skip=sc[1], skip_src=sample, train=train,
-                           dropout_seed=dropout_seed)
+                           dropout_seed=dropout_seed, infer=infer)
 
     def forward(self, sample, sigma, cond_sample=None, cond=None):
         """consistency_model.py:63-79."""
@@ -94,7 +94,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         if lanes > 1 and (B % lanes or torch.is_grad_enabled()):
             lanes = 1
         if lanes < 2:
-            return self._forward_static(sample, sigma, cond).clone()
+            return self._forward_static(sample, sigma, cond, infer=not torch.is_grad_enabled()).clone()
         # independent samples: sub-batches on separate HIP streams run out of phase (see LightningEDM.sample_deterministically)
         dev = sample.device
         h = B // lanes
@@ -107,7 +107,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
             with torch.cuda.stream(st):
                 sl = slice(i * h, (i + 1) * h)
                 y = self._forward_static(sample[sl].contiguous(), sigma[sl].contiguous(),
-                                         None if cond is None else cond[sl].contiguous(), lane=i)
+                                         None if cond is None else cond[sl].contiguous(), lane=i, infer=True)
                 out[sl].copy_(y)
         for i in range(1, lanes):
             main.wait_stream(self._side_stream(dev, i))

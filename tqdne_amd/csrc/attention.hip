@@ -466,13 +466,15 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
 }
 
 template <int D>
-int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int T, int H, hipStream_t stream) {
+int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int T, int H, hipStream_t stream, bool presplit = false) {
     const int Tp = (T + 63) / 64 * 64;
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
-    const size_t n = (size_t)B * H * Tp * (D / 4);
-    hipLaunchKernelGGL(attn_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, qkv,
-                       reinterpret_cast<unsigned char*>(ws), T, Tp, H, D, scale, n);
-    TQ_CHECK_LAUNCH();
+    if (!presplit) {
+        const size_t n = (size_t)B * H * Tp * (D / 4);
+        hipLaunchKernelGGL(attn_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, qkv,
+                           reinterpret_cast<unsigned char*>(ws), T, Tp, H, D, scale, n);
+        TQ_CHECK_LAUNCH();
+    }
     constexpr int ROWB = 2 * D + 32;
     const size_t sh = 2 * 4 * 64 * ROWB;
     if (sh > 64 * 1024)
@@ -502,6 +504,15 @@ extern "C" int tq_attention_fwd(const float* qkv, float* out, float* lse, void* 
     if (D == 64) return launch_attn<64>(qkv, out, lse, B, T, H, stream);
     if (D == 32) return launch_attn<32>(qkv, out, lse, B, T, H, stream);
     if (D == 128) return launch_attn<128>(qkv, out, lse, B, T, H, stream);
+    return TQ_ERR_SHAPE;
+}
+
+extern "C" int tq_attention_fwd_presplit(const float* qkv, const void* kv_planes, float* out, int B, int T, int H, int D,
+                                         hipStream_t stream) {
+    if (!qkv || !kv_planes || !out) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || H <= 0) return TQ_ERR_SHAPE;
+    if (D == 64) return launch_attn2<64>(qkv, out, nullptr, const_cast<void*>(kv_planes), B, T, H, stream, true);
+    if (D == 32) return launch_attn2<32>(qkv, out, nullptr, const_cast<void*>(kv_planes), B, T, H, stream, true);
     return TQ_ERR_SHAPE;
 }
 

@@ -22,6 +22,7 @@
 //     conflict-free for any tap shift.  The K taps are row shifts of the same LDS image (no im2col).
 //   * double-buffered LDS, global loads for chunk c+1 issued before the MFMAs of chunk c.
 //   * epilogue: accumulator lane = 4 consecutive co at one t -> one 16-byte store per 16x16 tile.
+#include <cmath>
 #include <type_traits>
 
 #include "common.hpp"
@@ -85,6 +86,10 @@ struct ConvArgs {
     const float* sbias;
     int sC0, sC1;
     int wfmt;  // TQ_WFMT_*: packed weight format = contraction scheme
+    // EPI == 2 (qkv projection at inference): K / V channels go straight to the attention kernel's pre-split planes
+    unsigned char* kv;
+    int kvH, kvD, kvTp;
+    float kvscale;
 };
 
 #ifndef TQ_STAGE_PRE
@@ -126,7 +131,7 @@ struct Cfg {
 // 32-channel stages read from the block input (plain, centre tap), instead of a separate launch + residual round trip
 template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
-    static_assert(SCH == 0 || (EPI == 0 && STRIDE == 1), "the fp16-range scheme serves stride-1 forward launches");
+    static_assert(SCH == 0 || (EPI != 1 && STRIDE == 1), "the fp16-range scheme serves stride-1 forward launches");
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef TQ_STAMP
@@ -515,7 +520,48 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     // ---- epilogue
     if (!wave_active) return;
-    if constexpr (EPI == 0) {
+    if constexpr (EPI == 2) {
+        // qkv projection feeding attention_fwd2 (blocks.py:139-145): q stays fp32 in the (B, T, 3 H D) tensor, k (scaled by
+        // D^-1/4 like q inside the kernel) and v are written as the bf16 hi / lo planes kv[b][h][K hi, K lo, V hi, V lo][t][d]
+        // the attention kernel streams -- instead of fp32 here plus a separate split pass over them (tq_attention_fwd)
+        const int HD = p.kvH * p.kvD;
+        const size_t plane = (size_t)p.kvTp * p.kvD * 2;  // bytes
+        float4 add[2];
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+            const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+            add[cbk] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int tb = 0; tb < 8; ++tb) {
+            const int t = t0 + wn * 128 + tb * 16 + (lane & 15);
+            if (t < p.T_out) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk) {
+                    const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+                    const float v[4] = {acc[cbk][tb][0] + add[cbk].x, acc[cbk][tb][1] + add[cbk].y,
+                                        acc[cbk][tb][2] + add[cbk].z, acc[cbk][tb][3] + add[cbk].w};
+                    const int sec = co / HD;
+                    if (sec == 0) {
+                        *reinterpret_cast<float4*>(p.y + ((size_t)b * p.T_out + t) * p.C_out + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        const int r = co - sec * HD, h = r / p.kvD, d = r - h * p.kvD;
+                        const float sc = sec == 1 ? p.kvscale : 1.0f;
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            __bf16 a, c;
+                            split_bf16(v[j] * sc, a, c);
+                            hi[j] = a; lo[j] = c;
+                        }
+                        unsigned char* base = p.kv + (((size_t)b * p.kvH + h) * 4 + (sec == 1 ? 0 : 2)) * plane + ((size_t)t * p.kvD + d) * 2;
+                        *reinterpret_cast<bf16x4*>(base) = hi;
+                        *reinterpret_cast<bf16x4*>(base + plane) = lo;
+                    }
+                }
+            }
+        }
+    } else if constexpr (EPI == 0) {
     const int slot = (t0 >> 7) + wn;
     const float* emb_b = (p.flags & TQ_CONV_EMB) ? p.emb + (size_t)b * p.emb_stride : nullptr;
     // The two 16-channel blocks of a wave are the two 64-byte halves of one 128-byte output line: they are stored back to back
@@ -691,7 +737,7 @@ template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     if (a.wfmt == TQ_WFMT_F16_MX8) {  // built for stride-1 forward launches with 128 | C_out and 64-channel sources, without the
         // fused skip conv (its extra live state does not fit the 256 registers of two waves per SIMD next to this scheme's)
-        if constexpr (STRIDE == 1 && EPI == 0 && !FUSE) {
+        if constexpr (STRIDE == 1 && EPI != 1 && !FUSE) {
             if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
             if constexpr (UPS == 0) {
                 if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
@@ -745,7 +791,19 @@ extern "C" int tq_conv_tile_co(int C_out) {
 
 static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale, const float* gshift,
                            const void* wpk, const float* bias, const float* emb, const float* res, const float* skip_x0,
-                           const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream);
+                           const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream,
+                           unsigned char* kv_planes = nullptr, int kvH = 0, int kvD = 0, int kvTp = 0, float kvscale = 1.f);
+
+extern "C" int tq_conv1d_fwd_qkv(const TqConvDesc* d, const float* x, const float* gscale, const float* gshift, const void* wpk,
+                                 const float* bias, float* qkv, void* kv_planes, int H, int D, hipStream_t stream) {
+    if (!d || !kv_planes || H <= 0 || (D != 32 && D != 64)) return TQ_ERR_ARG;
+    if (d->ktaps != 1 || d->stride != 1 || d->upsample || d->C_in1 || d->C_out != 3 * H * D || (d->C_skip0 | d->C_skip1)) return TQ_ERR_SHAPE;
+    if (d->flags & (TQ_CONV_EMB | TQ_CONV_RES | TQ_CONV_STATS | TQ_CONV_DROPOUT | TQ_CONV_SILU)) return TQ_ERR_ARG;
+    const int Tp = (d->T_out + 63) / 64 * 64;
+    const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
+    return conv1d_fwd_impl(d, x, nullptr, gscale, gshift, wpk, bias, nullptr, nullptr, nullptr, nullptr, nullptr, qkv, nullptr, stream,
+                           reinterpret_cast<unsigned char*>(kv_planes), H, D, Tp, scale);
+}
 
 extern "C" int tq_conv1d_fwd(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale,
                              const float* gshift, const void* wpk, const float* bias, const float* emb,
@@ -767,7 +825,8 @@ extern "C" int tq_conv1d_fwd_skip(const TqConvDesc* d, const float* x0, const fl
 
 static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale, const float* gshift,
                            const void* wpk, const float* bias, const float* emb, const float* res, const float* skip_x0,
-                           const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream) {
+                           const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream,
+                           unsigned char* kv_planes, int kvH, int kvD, int kvTp, float kvscale) {
     if (!d || !x0 || !wpk || !y) return TQ_ERR_ARG;
     if (d->C_in0 <= 0 || d->C_in0 % 32 || d->C_in1 < 0 || d->C_in1 % 32 || d->C_out <= 0 || d->C_out % 32) return TQ_ERR_SHAPE;
     if (d->C_in1 > 0 && !x1) return TQ_ERR_ARG;
@@ -803,6 +862,7 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.fx0 = a.fx1 = a.fgs = a.fgh = nullptr; a.y1 = nullptr; a.OC0 = d->C_out; a.bflags = 0;
     a.sx0 = skip_x0; a.sx1 = skip_x1; a.sbias = skip_bias; a.sC0 = d->C_skip0; a.sC1 = d->C_skip1;
     a.wfmt = d->wfmt;
+    a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale;
 
     if (d->stride == 2 || d->upsample) {
         if (a.flags & (TQ_CONV_GN | TQ_CONV_SILU | TQ_CONV_DROPOUT)) return TQ_ERR_SHAPE;  // resampling convs take raw inputs
@@ -810,6 +870,10 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
         if (d->ktaps == 5) return dispatch_tile<5, 1, 1, 0, 0>(a, stream);
         if (d->ktaps == 3) return dispatch_tile<3, 1, 1, 0, 0>(a, stream);
         return TQ_ERR_SHAPE;
+    }
+    if (a.kv) {  // qkv projection with the pre-split K / V epilogue: k = 1, plain or folded-GN prologue
+        if (a.flags & TQ_CONV_GN) return dispatch_tile<1, 1, 0, 2, 1>(a, stream);
+        return dispatch_tile<1, 1, 0, 2, 0>(a, stream);
     }
     switch (d->ktaps) {
         case 1: return dispatch_act<1>(a, stream);
@@ -852,6 +916,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.fx0 = x0; a.fx1 = x1; a.fgs = gscale; a.fgh = gshift; a.y1 = dx1; a.OC0 = d->C_dx0;
     a.sx0 = a.sx1 = a.sbias = nullptr; a.sC0 = a.sC1 = 0;
     a.wfmt = TQ_WFMT_BF16X3;  // gradients keep fp32 range
+    a.kv = nullptr; a.kvH = a.kvD = a.kvTp = 0; a.kvscale = 1.f;
     switch (d->ktaps) {
         case 1: return dispatch_tile<1, 1, 0, 1, 0>(a, stream);
         case 3: return dispatch_tile<3, 1, 0, 1, 0>(a, stream);

@@ -126,7 +126,7 @@ class LightningEDM(LightningModule):
             self._scal[key] = s
         return s
 
-    def _denoise_static(self, sample, sigma, sigma_stride, cond, train=False, dropout_seed=0, cond_sample=None):
+    def _denoise_static(self, sample, sigma, sigma_stride, cond, train=False, dropout_seed=0, cond_sample=None, infer=False):
         """Fused preconditioned forward (edm.py:105-113); returns the engine's static output buffer.
         ``sigma``: device tensor; ``sigma_stride`` 1 (per-sample) or 0 (one value shared by the batch).
         ``cond_sample``: conditioning signal concatenated on the channel axis behind the scaled sample (edm.py:108-109); the
@@ -142,10 +142,10 @@ class LightningEDM(LightningModule):
             x_in = th.cat((sample * sc[0][:, None, None], cond_sample.to(sample.dtype)), dim=1).contiguous()
             eng = self.unet._engine(B, T, dev, self._lane)
             return eng.forward(x_in, sc[3], cond, in_scale=None, c_out=sc[1], c_skip=sc[2], skip_src=sample, train=train,
-                               dropout_seed=dropout_seed)
+                               dropout_seed=dropout_seed, infer=infer)
         eng = self.unet._engine(B, T, dev, self._lane)
         return eng.forward(sample, sc[3], cond, in_scale=sc[0], c_out=sc[1], c_skip=sc[2], skip_src=sample, train=train,
-                           dropout_seed=dropout_seed)
+                           dropout_seed=dropout_seed, infer=infer)
 
     def forward(self, sample, sigma, cond_sample=None, cond=None):
         """Make a forward pass through the network with skip connection (edm.py:105-113)."""
@@ -159,11 +159,11 @@ class LightningEDM(LightningModule):
             if self.training and th.is_grad_enabled():
                 from .autograd import denoise_with_grad
                 return denoise_with_grad(self, sample, sigma, cond)
-            return self._denoise_static(sample, sigma, 1, cond).clone()
+            return self._denoise_static(sample, sigma, 1, cond, infer=True).clone()
         if self.training and th.is_grad_enabled():
             from .autograd import denoise_with_grad
             return denoise_with_grad(self, sample, sigma, cond)
-        return self._denoise_static(sample, sigma, 1, cond, cond_sample=cond_sample.contiguous()).clone()
+        return self._denoise_static(sample, sigma, 1, cond, cond_sample=cond_sample.contiguous(), infer=True).clone()
 
     # ------------------------------------------------------------------ training
     def step(self, batch, batch_idx):
@@ -326,7 +326,7 @@ class LightningEDM(LightningModule):
                 if use_graph:
                     r.denoise = edm._graph_denoiser(bufs, r.x32, cond, cond_sample)
                 else:
-                    r.denoise = lambda sig_ptr: edm._denoise_static(r.x32, _RawPtr(sig_ptr), 0, cond, cond_sample=cond_sample)
+                    r.denoise = lambda sig_ptr: edm._denoise_static(r.x32, _RawPtr(sig_ptr), 0, cond, cond_sample=cond_sample, infer=True)
 
             @property
             def done(r):
@@ -365,11 +365,11 @@ class LightningEDM(LightningModule):
         key = (None if cond is None else cond.data_ptr(), None if cond_sample is None else cond_sample.data_ptr())
         if g is None or bufs.get("graph_cond") != key:
             slot = th.zeros(1, device=x32.device)
-            self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample)  # warm-up outside capture (plan build, packing)
+            self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample, infer=True)  # warm-up outside capture (plan build, packing)
             th.cuda.synchronize(x32.device)
             graph = th.cuda.CUDAGraph()
             with th.cuda.graph(graph):
-                out = self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample)
+                out = self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample, infer=True)
             g = (graph, slot, out)
             bufs["graph"], bufs["graph_cond"] = g, key
         graph, slot, out = g

@@ -111,7 +111,8 @@ class UNetEngine:
         self.B, self.T, self.dev = B, T, device
         self.E = 4 * getattr(model, "model_channels", 0)
         self._keep = []          # ctypes structs / tensors referenced by raw pointers
-        self.ops: List[Tuple] = []
+        self.ops: List[Tuple] = []          # launches of a forward whose backward may follow
+        self.ops_infer: List[Tuple] = []    # same order and length; inference-only variants where they exist
         self.conv_sites: List[ConvSite] = []
         self.dropout_descs: List[TqConvDesc] = []
         self.acts: List[Act] = []
@@ -154,20 +155,25 @@ class UNetEngine:
         return s, t
 
     # ------------------------------------------------------------------ op builders
+    def _emit(self, op, infer_op=None):
+        """append a launch to the plan; ``infer_op`` replaces it in forwards that no backward will follow"""
+        self.ops.append(op)
+        self.ops_infer.append(op if infer_op is None else infer_op)
+
     def _gn(self, srcs: Sequence[Act], norm: torch.nn.GroupNorm):
         C_ = sum(s.C for s in srcs)
         gscale, gshift = self._empty(self.B, C_), self._empty(self.B, C_)
         mean_rstd = self._empty(self.B, 32, 2)
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) > 1 else None
-        self.ops.append((self.lib.tq_gn_finalize, (
+        self._emit((self.lib.tq_gn_finalize, (
             _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
             _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize", 0))
         return gscale, gshift, mean_rstd
 
     def _conv(self, srcs: Sequence[Act], site: ConvSite, *, gn=None, silu=False, emb_ptr=None, res: Optional[Act] = None,
               stats=True, stride=1, upsample=False, dropout_site: Optional[int] = None, launch: bool = True,
-              skip: Optional[Tuple[Sequence[Act], ConvSite]] = None) -> Optional[Act]:
+              skip: Optional[Tuple[Sequence[Act], ConvSite]] = None, qkv_planes=None) -> Optional[Act]:
         """launch=False only records the conv (descriptor for its gradients): its product is formed by another launch.
         skip=(srcs, 1x1 site): fuse that convolution of the un-activated srcs into this launch (site.packed holds both)."""
         s0 = srcs[0]
@@ -217,16 +223,23 @@ class UNetEngine:
             k0, k1 = ksrcs[0], (ksrcs[1] if len(ksrcs) > 1 else None)
             assert res is None and k0.T == T_out and ksite.C_out == site.C_out
             d.C_skip0, d.C_skip1 = k0.C, (k1.C if k1 else 0)
-            self.ops.append((self.lib.tq_conv1d_fwd_skip, (
+            self._emit((self.lib.tq_conv1d_fwd_skip, (
                 C.byref(d), _p(s0.buf), _p(s1.buf) if s1 else None, _p(gn[0]) if gn else None, _p(gn[1]) if gn else None,
                 _p(site.packed), _p(site.bias), emb_ptr, _p(k0.buf), _p(k1.buf) if k1 else None, _p(ksite.bias),
                 _p(out.buf), _p(out.stats)),
                 "conv:" + site.name + "+skip", flops + 2 * ksite.C_in * site.C_out * T_out * self.B))
         elif launch:
-            self.ops.append((self.lib.tq_conv1d_fwd, (
+            op = (self.lib.tq_conv1d_fwd, (
                 C.byref(d), _p(s0.buf), _p(s1.buf) if s1 else None, _p(gn[0]) if gn else None, _p(gn[1]) if gn else None,
                 _p(site.packed), _p(site.bias), emb_ptr, _p(res.buf) if res else None, _p(out.buf), _p(out.stats)),
-                "conv:" + site.name, flops))
+                "conv:" + site.name, flops)
+            infer_op = None
+            if qkv_planes is not None:  # (ws, H, D): K / V straight into the attention kernel's pre-split planes
+                ws, H_, D_ = qkv_planes
+                infer_op = (self.lib.tq_conv1d_fwd_qkv, (
+                    C.byref(d), _p(s0.buf), _p(gn[0]) if gn else None, _p(gn[1]) if gn else None, _p(site.packed), _p(site.bias),
+                    _p(out.buf), _p(ws), H_, D_), "conv:" + site.name + "+split", flops)
+            self._emit(op, infer_op)
         self.last_rec = ConvRec(site, d, list(srcs), gn, out, stride, upsample, silu, dropout_site is not None)
         return out
 
@@ -324,16 +337,24 @@ class UNetEngine:
 
     def _attention(self, x: Act, ab, name: str) -> Act:
         g = self._gn([x], ab.norm)
-        qkv = self._conv([x], self._site(name + ".qkv", ab.qkv), gn=g, silu=False, stats=False)
-        rec_qkv = self.last_rec
-        att = self._act(ab.channels, x.T, False)
-        lse = self._empty(self.B, ab.num_heads, x.T)
         D = ab.channels // ab.num_heads
         if D not in (32, 64, 128):
             raise NotImplementedError(f"attention head dim {D} (kernels exist for 32, 64 and 128)")
         ws = self._attn_workspace(self.lib.tq_attention_workspace_bytes(self.B, x.T, ab.num_heads, D))
-        self.ops.append((self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), _p(lse), _p(ws), self.B, x.T, ab.num_heads, D), "attention",
-                         4 * ab.channels * x.T * x.T * self.B))
+        # inference forwards: the qkv projection writes K / V as the attention kernel's bf16 hi / lo planes itself (no fp32 K / V,
+        # no split pass: -134 MB and one launch per block); forwards a backward may follow keep fp32 qkv for tq_attention_bwd
+        split = (ws, ab.num_heads, D) if D in (32, 64) else None
+        qkv = self._conv([x], self._site(name + ".qkv", ab.qkv), gn=g, silu=False, stats=False, qkv_planes=split)
+        rec_qkv = self.last_rec
+        att = self._act(ab.channels, x.T, False)
+        lse = self._empty(self.B, ab.num_heads, x.T)
+        flops = 4 * ab.channels * x.T * x.T * self.B
+        op = (self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), _p(lse), _p(ws), self.B, x.T, ab.num_heads, D), "attention", flops)
+        infer_op = None
+        if split is not None:
+            infer_op = (self.lib.tq_attention_fwd_presplit, (_p(qkv.buf), _p(ws), _p(att.buf), self.B, x.T, ab.num_heads, D),
+                        "attention", flops)
+        self._emit(op, infer_op)
         out = self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
         self.tape.append(("attn", dict(ab=ab, x=x, g=g, qkv=qkv, att=att, lse=lse, out=out, rec_qkv=rec_qkv,
                                        rec_proj=self.last_rec, D=D)))
@@ -344,7 +365,7 @@ class UNetEngine:
         ws = getattr(self, "_attn_ws", None)
         if ws is None or ws.numel() < nbytes:
             assert ws is None, "attention blocks of one plan share a shape"
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)  # padding rows (t >= T) stay zero
             self._keep.append(ws)
             self._attn_ws = ws
         return ws
@@ -395,8 +416,9 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ run
     def forward(self, x, timesteps, cond=None, *, in_scale=None, c_out=None, c_skip=None, skip_src=None,
-                train: bool = False, dropout_seed: int = 0):
-        """Run the UNet.  Returns the static (B, C_out, T) output buffer (overwritten by the next call)."""
+                train: bool = False, dropout_seed: int = 0, infer: bool = False):
+        """Run the UNet.  Returns the static (B, C_out, T) output buffer (overwritten by the next call).
+        ``infer``: no backward will follow this forward -- launches may skip what only the backward reads (``ops_infer``)."""
         m, lib, B, T = self.m, self.lib, self.B, self.T
         if tuple(x.shape) != (B, m.in_channels, T):
             raise ValueError(f"plan was built for {(B, m.in_channels, T)}, got {tuple(x.shape)}")
@@ -430,13 +452,14 @@ class UNetEngine:
                                    _p(self.stem_out.stats), B, m.in_channels, T, stem.out_channels, stem.kernel_size[0],
                                    stream), "stem conv")
         probe = self._probe
+        ops = self.ops_infer if (infer and not train) else self.ops
         if probe is None or torch.cuda.is_current_stream_capturing():
-            for fn, args, what, _ in self.ops:
+            for fn, args, what, _ in ops:
                 rc = fn(*args, stream)
                 if rc:
                     check(rc, what)
         else:
-            for i, (fn, args, what, _) in enumerate(self.ops):
+            for i, (fn, args, what, _) in enumerate(ops):
                 if i == probe.idx:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -448,7 +471,7 @@ class UNetEngine:
                 if rc:
                     check(rc, what)
         self._last = dict(x=x, in_scale=in_scale, c_out=c_out, timesteps=timesteps, cond=cond, train=train,
-                          dropout_p=p, dropout_seed=dropout_seed)
+                          dropout_p=p, dropout_seed=dropout_seed, infer=infer and not train)
         head = m.out[2]
         check(lib.tq_head_conv_fwd(_p(self.final.buf), _p(self.head_gn[0]), _p(self.head_gn[1]), _p(head.weight),
                                    _p(head.bias), _p(c_out), _p(c_skip), _p(skip_src), _p(self.out_nct), B, T,

@@ -285,8 +285,8 @@ class BackwardPlan:
     def run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True):
         e, m, lib = self.e, self.m, self.lib
         last = e._last
-        if not last.get("train", False) and m.dropout:
-            pass  # eval-mode forward: gradients are those of the eval network (dropout inactive), still well defined
+        if last.get("infer", False):
+            raise RuntimeError("the last forward of this plan was an inference forward (infer=True): it kept nothing for a backward")
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         e.repack_transposed(stream)
         self.flat.zero_()
