@@ -308,41 +308,36 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
 namespace {
 __device__ __forceinline__ void gemv_rows(const float* __restrict__ w, const float* __restrict__ bias,
                                           const float* in_sh, int n_in, int n_out, float* out_sh, bool accumulate) {
-    // wave-per-output dot products, 8 outputs in flight per wave; 16-byte weight loads when the row length allows
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int U = 8;
+    // out[o] = bias[o] + sum_i w[o][i] * in[i] for a 256-thread workgroup.  LPO lanes share an output (1 for short rows, 4 for long
+    // ones) and walk its row in interleaved 16-byte pieces, so every output's dependent-load chain is n_in / (4 LPO) deep and all
+    // 256 / LPO outputs of a pass are in flight together (a wave-per-output reduction kept 3/4 of the lanes idle on 64-long rows
+    // and paid 6 shuffles per output: 78 us for the embedding MLPs).
+    const int tid = threadIdx.x;
+    const int LPO = (n_in > 64 && (n_in & 15) == 0) ? 4 : 1;
+    const int r = tid % LPO, o_local = tid / LPO;
+    const int per_pass = 256 / LPO;
     const bool vec = (n_in & 3) == 0;
-    for (int o0 = wave * U; o0 < n_out; o0 += 4 * U) {
-        float a[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = 0.f;
-        if (vec) {
-            for (int i = 4 * lane; i < n_in; i += 256) {
-                const float4 xv = *reinterpret_cast<const float4*>(in_sh + i);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (o0 + u < n_out) {
-                        const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(o0 + u) * n_in + i);
-                        a[u] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
-                    }
-            }
-        } else {
-            for (int i = lane; i < n_in; i += 64) {
-                const float xv = in_sh[i];
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (o0 + u < n_out) a[u] = fmaf(w[(size_t)(o0 + u) * n_in + i], xv, a[u]);
+    for (int o0 = 0; o0 < n_out; o0 += per_pass) {
+        const int o = o0 + o_local;
+        float a = 0.f;
+        if (o < n_out) {
+            const float* wr = w + (size_t)o * n_in;
+            if (vec) {
+                const int n4 = n_in >> 2;
+#pragma unroll 4
+                for (int q = r; q < n4; q += LPO) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * q);
+                    const float4 xv = *reinterpret_cast<const float4*>(in_sh + 4 * q);
+                    a += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+                }
+            } else {
+                for (int i = r; i < n_in; i += LPO) a = fmaf(wr[i], in_sh[i], a);
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = wave_sum(a[u]);
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (o0 + u < n_out) {
-                    const float v = a[u] + bias[o0 + u];
-                    out_sh[o0 + u] = accumulate ? out_sh[o0 + u] + v : v;
-                }
+        for (int sft = 1; sft < LPO; sft <<= 1) a += __shfl_xor(a, sft);
+        if (o < n_out && r == 0) {
+            const float v = a + bias[o];
+            out_sh[o] = accumulate ? out_sh[o] + v : v;
         }
     }
 }

@@ -264,6 +264,19 @@ class UNetEngine:
         self.emb_hidden = self._empty(B, 2, self.E)
         self.emb_w = self._empty(self.emb_total, self.E)
         self.emb_b = self._empty(self.emb_total)
+        # all 22 per-block Linear(SiLU(emb)) projections (unet.py:91-97) as ONE pointwise "conv" on the MFMA path: the B samples
+        # are the positions of a single (1, B, E) channels-last sequence, the concatenated weight a (emb_total, E, 1) kernel
+        self.emb_desc = None
+        if self.emb_total > 0 and self.E % 32 == 0 and self.emb_total % 32 == 0:
+            d = TqConvDesc()
+            d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = 1, B, B, self.E, 0, self.emb_total
+            d.ktaps, d.stride, d.pad, d.upsample, d.flags = 1, 1, 0, 0, 0
+            d.wfmt = _lib.forward_wfmt(self.emb_total, [self.E])
+            self.emb_pack_mode = 2 if d.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+            self.emb_packed = torch.empty(lib.tq_conv_weight_pack_bytes(self.emb_total, self.E, 1, self.emb_pack_mode),
+                                          dtype=torch.uint8, device=self.dev)
+            self._keep.append(d)
+            self.emb_desc = d
         self.emb_all = self._empty(B, self.emb_total)
 
         # stem (dynamic args: x, in_scale) -------------------------------------------------------
@@ -402,6 +415,9 @@ class UNetEngine:
                     o = self.emb_offsets[id(rb)]
                     self.emb_w[o:o + rb.out_channels].copy_(rb.emb_layers[1].weight)
                     self.emb_b[o:o + rb.out_channels].copy_(rb.emb_layers[1].bias)
+            if getattr(self, "emb_desc", None) is not None:
+                check(lib.tq_pack_conv_weight(self.emb_w.data_ptr(), self.emb_total, self.E, 1, self.emb_pack_mode,
+                                              self.emb_packed.data_ptr(), stream), "pack emb projections")
         self._w_version = v
 
     def repack_transposed(self, stream: int):
@@ -445,8 +461,12 @@ class UNetEngine:
             _p(cm[0].weight) if cm else None, _p(cm[0].bias) if cm else None, _p(cm[2].weight) if cm else None,
             _p(cm[2].bias) if cm else None, _p(self.emb), _p(self.silu_emb), _p(self.emb_hidden), B, m.model_channels,
             ncond, stream), "embed")
-        check(lib.tq_linear_fwd(_p(self.silu_emb), _p(self.emb_w), _p(self.emb_b), _p(self.emb_all), B, self.E,
-                                self.emb_total, stream), "emb projections")
+        if self.emb_desc is not None:
+            check(lib.tq_conv1d_fwd(C.byref(self.emb_desc), _p(self.silu_emb), None, None, None, _p(self.emb_packed), _p(self.emb_b),
+                                    None, None, _p(self.emb_all), None, stream), "emb projections")
+        else:
+            check(lib.tq_linear_fwd(_p(self.silu_emb), _p(self.emb_w), _p(self.emb_b), _p(self.emb_all), B, self.E,
+                                    self.emb_total, stream), "emb projections")
         stem = m.input_blocks[0][0]
         check(lib.tq_stem_conv_fwd(_p(x), _p(in_scale), _p(stem.weight), _p(stem.bias), _p(self.stem_out.buf),
                                    _p(self.stem_out.stats), B, m.in_channels, T, stem.out_channels, stem.kernel_size[0],
