@@ -82,10 +82,14 @@ def test_conv_both_contraction_schemes(cin0, cin1, cout, k, T, gn):
                            gshift=sh.to(d) if gn else None, silu=gn, wfmt=wfmt)
         assert rel_err(ncw(y), ref) < TOL, wfmt
         assert rel_err(st.cpu(), ref_stats(ref)) < TOL, wfmt
-    # fp16 range of the activation operand: huge inputs are clamped, not turned into inf / NaN
+    # fp16 range of the activation operand: inputs beyond 65504 surface as inf / NaN (loud), NaN inputs stay NaN
     big = cl(x0 * 1e6)
     y, _ = ops.conv1d(big, w[:, :cin0].contiguous().to(d), b.to(d), wfmt=_lib.TQ_WFMT_F16_MX8, stats=False)
-    assert torch.isfinite(y).all()
+    assert not torch.isfinite(y).all()
+    xn = cl(x0).clone()
+    xn[0, 5, 3] = float("nan")
+    y, _ = ops.conv1d(xn, w[:, :cin0].contiguous().to(d), b.to(d), wfmt=_lib.TQ_WFMT_F16_MX8, stats=False)
+    assert torch.isnan(y[0, 5]).any() and torch.isfinite(y[1]).all()
 
 
 def test_conv_fused_everything():
