@@ -400,11 +400,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #ifndef TQ_LDS_DEPTH
 #define TQ_LDS_DEPTH 2
 #endif
+#ifndef TQ_LDS_DEPTH1
+#define TQ_LDS_DEPTH1 1
+#endif
     // Weight fragments live in two register buffers (taps alternate a, b, a, ...); after tap k its buffer is refilled with
     // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
     // b = tap 1 already in flight.
     Frag wa[C::NW], wb[C::NW];
-    constexpr int LDS_DEP = SCH ? 1 : TQ_LDS_DEPTH;  // scheme 1: 128 MFMA cycles per step, and registers are tight
+    constexpr int LDS_DEP = SCH ? TQ_LDS_DEPTH1 : TQ_LDS_DEPTH;  // scheme 1: 128 MFMA cycles per step, and registers are tight
 
     // MFMA phase of one chunk = ONE stream of NTAPS x 8 (tap, t-block) steps.  B fragments are read LDS_DEP steps ahead of the
     // MFMAs that consume them, across tap boundaries too (a per-tap restart exposed the LDS latency KT times per chunk).
