@@ -499,3 +499,39 @@ def test_inference_forward_matches_backward_capable_forward(which):
     assert any(op[2].endswith("+split") for op in eng.ops_infer) and len(eng.ops) == len(eng.ops_infer)
     with pytest.raises(RuntimeError):
         eng.backward(torch.zeros_like(a), torch.ones((), device=dev()))
+
+
+def test_latent_edm_training_step_gradients_vs_oracle():
+    """BASELINE config 3 training (train_1d_latent_edm.py): the latent UNet has 16 input / output channels -- loss and every
+    gradient, incl. the 16-channel stem's (differentiated as a generic conv over a padded channels-last copy), vs autograd
+    through the CPU oracle.  (The frozen autoencoder only supplies the latent; a random latent stands in for it here.)"""
+    from oracle import edm as OE
+    from tqdne_amd import LightningEDM, tiny_1d_unet_config
+    cfg = dict(tiny_1d_unet_config(in_channels=16, out_channels=16), dropout=0.0)
+    torch.manual_seed(0)
+    edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
+    sd = perturbed_state(edm.unet, 8)
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev()).train()
+    g = torch.Generator().manual_seed(21)
+    B, T = 2, 1024
+    lat = 0.5 * torch.randn(B, 16, T, generator=g)
+    eps, noise = torch.randn(B, generator=g), torch.randn(B, 16, T, generator=g)
+    loss = edm.step_with_noise(lat.to(dev()), eps.to(dev()), noise.to(dev()))
+    loss.backward()
+    params = {("unet." + k): v.clone().requires_grad_(k != "time_embed.W") for k, v in sd.items()}
+    lo = OE.loss_step(OE.EDMParams(), OE.make_net(params, cfg), lat, eps, noise)
+    lo.backward()
+    assert rel_err(loss.detach().cpu(), lo.detach()) < TOL
+    gmax = max(float(v.grad.abs().max()) for v in params.values() if v.grad is not None)
+    worst, wname = 0.0, ""
+    for name, p in edm.unet.named_parameters():
+        if p.requires_grad:
+            r = params["unet." + name].grad
+            e = float((p.grad.cpu() - r).abs().max() / max(float(r.abs().max()), 1e-3 * gmax))
+            if e > worst:
+                worst, wname = e, name
+    print(f"latent step: loss {float(loss.detach()):.6f}; worst gradient rel err {worst:.2e} at {wname}")
+    assert worst < TOL
+    stem_err = rel_err(edm.unet.input_blocks[0][0].weight.grad.cpu(), params["unet.input_blocks.0.0.weight"].grad)
+    assert stem_err < TOL, stem_err

@@ -192,6 +192,23 @@ class BackwardPlan:
         assert so.gw
         self.stem_op = [lib.tq_stem_conv_bwd_weight, [_p(so.grad), None, None, _p(self.g(stem.weight)), B, m.in_channels, so.T,
                                                       stem.out_channels, stem.kernel_size[0]], "stem wgrad"]
+        # wide stems (the latent UNet's 16 input channels: 64 x 16 x 5 weights exceed the dedicated kernel's register budget)
+        # are differentiated as a generic fused conv over a (B, T, 32) channels-last copy of the pre-scaled input
+        self.stem_generic = stem.out_channels * m.in_channels * stem.kernel_size[0] > 2048
+        if self.stem_generic:
+            from ._lib import TqConvDesc
+            K = stem.kernel_size[0]
+            self.stem_x_btc = self._empty(B, so.T, 32)
+            self.stem_x_btc.zero_()
+            d = TqConvDesc()
+            d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, so.T, so.T, 32, 0, stem.out_channels
+            d.ktaps, d.stride, d.pad, d.upsample, d.flags = K, 1, K // 2, 0, 0
+            self._keep.append(d)
+            self.dw_stem32 = self._empty(stem.out_channels, 32, K)
+            self.ws_bytes = max(getattr(self, "ws_bytes", 0), lib.tq_conv1d_bwd_weight_workspace(C.byref(d)))
+            self._wgrad_ops.append(len(self.ops))
+            self.ops.append([lib.tq_conv1d_bwd_weight, [C.byref(d), _p(so.grad), _p(self.stem_x_btc), None, None, None,
+                                                        _p(self.dw_stem32), None, 0], "wgrad:stem (generic)"])
         self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None, None], "colsum:stem"])
         # shared workspace of the weight-gradient slabs
         self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=self.dev)
@@ -304,13 +321,20 @@ class BackwardPlan:
         fn, args, what = self.head_op
         args[0], args[1] = dpred.data_ptr(), cs.data_ptr()
         check(fn(*args, stream), what)
+        cin = m.in_channels
+        if self.stem_generic:
+            xs = last["x"] if last["in_scale"] is None else last["x"] * last["in_scale"][:, None, None]
+            self.stem_x_btc[:, :, :cin].copy_(xs.permute(0, 2, 1))
         for fn, args, what in self.ops:
             rc = fn(*args, stream)
             if rc:
                 check(rc, what)
-        fn, args, what = self.stem_op
-        args[1], args[2] = last["x"].data_ptr(), _p(last["in_scale"])
-        check(fn(*args, stream), what)
+        if self.stem_generic:
+            self.g(m.input_blocks[0][0].weight).copy_(self.dw_stem32[:, :cin, :])
+        else:
+            fn, args, what = self.stem_op
+            args[1], args[2] = last["x"].data_ptr(), _p(last["in_scale"])
+            check(fn(*args, stream), what)
         self._embedding_backward(last)
         out = self.flat.clone() if clone else self.flat  # clone: autograd may keep the returned tensors alive
         res = []
