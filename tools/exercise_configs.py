@@ -36,3 +36,15 @@ d = tempfile.mkdtemp(); f = os.path.join(d, "l.ckpt")
 checkpoint.save_checkpoint(edm, f, ema_state=tr2.ema_state(), optimizer=tr2.optimizer, lr_scheduler=tr2.scheduler, global_step=1)
 m2 = LightningEDM.load_from_checkpoint(f, autoencoder=ae, ema=True)
 print("latent EDM checkpoint round trip ok:", type(m2.edm).__name__, len(m2.state_dict()))
+# the experiments' real data shape (experiments/config.py:61-67): MovingAverageEnvelope representation, 6 channels x 4064
+from tqdne_amd.representation import MovingAverageEnvelope
+rep = MovingAverageEnvelope()
+wave = (torch.randn(2, 3, 4064, generator=g) * torch.linspace(0.1, 2.0, 4064)).to(dev)
+sig6 = rep.get_representation(wave)
+edm6 = LightningEDM(paper_1d_unet_config(in_channels=6, out_channels=6), {"learning_rate": 1e-4, "max_steps": 100, "eta_min": 0.0}, num_sampling_steps=3)
+perturb(edm6.unet); edm6 = edm6.to(dev).train()
+tr6 = DataParallelTrainer(edm6, world_size=1)
+print("6 x 4064 train step:", float(tr6.train_step({"signal": sig6, "cond": torch.randn(2, 5, generator=g).to(dev)})))
+edm6.eval()
+out6 = edm6.sample((2, 6, 4064), cond=torch.randn(2, 5, generator=g).to(dev))
+print("6 x 4064 sample -> waveform:", rep.invert_representation(out6).shape)
