@@ -535,3 +535,15 @@ def test_latent_edm_training_step_gradients_vs_oracle():
     assert worst < TOL
     stem_err = rel_err(edm.unet.input_blocks[0][0].weight.grad.cpu(), params["unet.input_blocks.0.0.weight"].grad)
     assert stem_err < TOL, stem_err
+
+
+def test_length_not_divisible_by_downsampling_raises_like_the_reference():
+    """T = 252 through two stride-2 levels: 252 -> 126 -> 63 -> up 126 ok; T = 250: 250 -> 125 -> 63 -> up 126 != 125"""
+    from tqdne_amd import UNetModel
+    sd, d = load_golden("micro_unet.npz")
+    net = UNetModel(**cfg_of(d))
+    net.load_state_dict(sd)
+    net = net.to(dev()).eval()
+    x = torch.randn(1, 3, 250, device=dev())
+    with pytest.raises(RuntimeError, match="must match"):
+        net(x, torch.zeros(1, device=dev()), torch.zeros(1, 5, device=dev()))

@@ -178,6 +178,10 @@ class UNetEngine:
         skip=(srcs, 1x1 site): fuse that convolution of the un-activated srcs into this launch (site.packed holds both)."""
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) > 1 else None
+        if s1 is not None and s1.T != s0.T:
+            # the reference fails in th.cat([h, hs.pop()], dim=1) (unet.py:396) when the length is not divisible by 2^levels
+            raise RuntimeError(f"Sizes of tensors must match except in dimension 1: lengths {s0.T} and {s1.T} at {site.name} "
+                               "(the signal length must be divisible by the UNet's total down-sampling factor)")
         T_in = s0.T
         if stride == 2:
             T_out = (T_in + 2 - site.K) // 2 + 1
