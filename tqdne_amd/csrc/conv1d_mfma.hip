@@ -742,9 +742,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // fused skip conv (its extra live state does not fit the 256 registers of two waves per SIMD next to this scheme's)
         if constexpr (STRIDE == 1 && EPI != 1 && !FUSE) {
             if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
-            if constexpr (UPS == 0) {
-                if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
-            }
+            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
             if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
         }
         return TQ_ERR_SHAPE;
