@@ -120,6 +120,16 @@ def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads):
     print(json.dumps(dict(stage="done", t_train=t_train, t_sample=t_sample)), flush=True)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=240):
     """Launch the worker with a hard timeout (a slow or oversubscribed host must not stall the bench)."""
     import subprocess
@@ -144,7 +154,7 @@ def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=240):
         t_sample = l.get("t_sample", t_sample)
     res = dict(value=None, unit="waveforms/s", cores=nthreads, kind="port", train_s=t_train, sample_s=t_sample,
                sample=f"{cfg_name} UNet, B={B}, 3x{T}: 1 train step + 1 x {nsample_steps}-step sample, torch {torch.__version__} CPU, "
-                      f"{nthreads} threads ({ncores} cores visible)")
+                      f"{nthreads} threads ({ncores} cores visible, {_cpu_model()})")
     if t_train is not None and t_sample is not None:
         res["value"] = B / (t_train + t_sample)
     else:
