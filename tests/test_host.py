@@ -115,3 +115,33 @@ def test_sampler_lane_rule():
         os.environ.pop("TQDNE_SAMPLER_LANES", None)
         if old is not None:
             os.environ["TQDNE_SAMPLER_LANES"] = old
+
+
+def test_c_abi_argument_checks_return_error_codes_without_a_gpu():
+    """entry points validate descriptors / pointers before touching the device: TQ_ERR_ARG (-1) / TQ_ERR_SHAPE (-2)"""
+    import ctypes as C
+    from tqdne_amd import _lib
+    lib = _lib.load()
+    d = _lib.TqConvDesc()
+    d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = 2, 128, 128, 64, 0, 64
+    d.ktaps, d.stride, d.pad, d.upsample, d.flags = 5, 1, 2, 0, 0
+    fake = 0x1000  # never dereferenced: every call below is rejected during validation
+    args = lambda **kw: [C.byref(d)] + [kw.get(k, fake) for k in ("x0", "x1", "gs", "gh", "w", "bias", "emb", "res", "y", "st")] + [None]
+    assert lib.tq_conv1d_fwd(None, *args()[1:]) == -1
+    assert lib.tq_conv1d_fwd(*args(x0=None)) == -1
+    d.C_in0 = 48
+    assert lib.tq_conv1d_fwd(*args()) == -2              # channels not a multiple of 32
+    d.C_in0, d.ktaps = 64, 7
+    d.pad = 3
+    assert lib.tq_conv1d_fwd(*args()) == -2              # unsupported kernel size
+    d.ktaps, d.pad, d.flags = 5, 2, _lib.TQ_CONV_GN
+    assert lib.tq_conv1d_fwd(*args(gs=None)) == -1       # GN prologue without coefficients
+    d.flags, d.wfmt = 0, 7
+    assert lib.tq_conv1d_fwd(*args()) == -1              # unknown weight format
+    d.wfmt, d.C_skip0 = 0, 64
+    assert lib.tq_conv1d_fwd(*args()) == -1              # fused-skip descriptors go through tq_conv1d_fwd_skip
+    assert lib.tq_pack_conv_weight(fake, 64, 64, 5, 9, fake, None) == -1
+    assert lib.tq_attention_fwd(fake, fake, None, None, 2, 128, 4, 48, None) == -2   # head dim without a kernel
+    assert lib.tq_envelope_fwd(fake, fake, 2, 3, 100, 128, 1e-6, 1e-6, None) == -2   # window longer than the signal
+    assert lib.tq_adam_ema_step(None, 3, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0.0, 1.0, 1.0, None) == -1
+    assert lib.tq_conv_weight_pack_bytes(256, 256, 5, 0) == lib.tq_conv_weight_pack_bytes(256, 256, 5, 2) > 0
