@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
     const int C3 = 3 * H * D;
     const int q0w = qt * 128 + wave * 32;
 
+    const float qscale = scale * 1.44269504088896341f;  // scores in log2 units
     // Q as the B operand of S^T = K Q^T: lane (col = query li, k = 8*g + j)
     Frag qh[QB][KS], ql[QB][KS];
 #pragma unroll
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
             if (ok) { a = *reinterpret_cast<const float4*>(qp + ks * 32); c = *reinterpret_cast<const float4*>(qp + ks * 32 + 4); }
             const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { __bf16 hh, ll; split_bf16(v[j] * scale, hh, ll); qh[qb][ks].v[j] = hh; ql[qb][ks].v[j] = ll; }
+            for (int j = 0; j < 8; ++j) { __bf16 hh, ll; split_bf16(v[j] * qscale, hh, ll); qh[qb][ks].v[j] = hh; ql[qb][ks].v[j] = ll; }
         }
     }
     f32x4 o[QB][CB];
@@ -380,35 +381,64 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
                 for (int qb = 0; qb < QB; ++qb) st[kb][qb] = mfma_x3(ah.v, al.v, qh[qb][ks].v, ql[qb][ks].v, st[kb][qb]);
             }
         }
-        // ---- online softmax per query (lane column), keys spread over kb, r (in-lane) and g (lanes li + 16 g)
+        // ---- online softmax per query (lane column), keys spread over kb, r (in-lane) and g (lanes li + 16 g); scores are in
+        //      log2 units (log2 e is folded into Q's scale), so p = exp2(s - m) is one v_sub + one v_exp
         float alpha[QB];
+        if (s0 + 64 <= T) {  // full key tile (every tile when 64 | T): no masking, every score finite
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float mx = -INFINITY;
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = st[0][qb][0];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (s0 + kb * 16 + 4 * g + r >= T) st[kb][qb][r] = -INFINITY;
-                    mx = fmaxf(mx, st[kb][qb][r]);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qb], mx);
-            alpha[qb] = (m_run[qb] == -INFINITY) ? 0.f : __expf(m_run[qb] - m_new);
-            float rs = 0.f;
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run[qb], mx);
+                alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);  // exp2(-inf) = 0 on the first tile
+                float rs = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = (st[kb][qb][r] == -INFINITY) ? 0.f : __expf(st[kb][qb][r] - m_new);
-                    st[kb][qb][r] = pv;
-                    rs += pv;
-                }
-            rs += __shfl_xor(rs, 16);
-            rs += __shfl_xor(rs, 32);
-            l_run[qb] = l_run[qb] * alpha[qb] + rs;
-            m_run[qb] = m_new;
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - m_new);
+                        st[kb][qb][r] = pv;
+                        rs += pv;
+                    }
+                rs += __shfl_xor(rs, 16);
+                rs += __shfl_xor(rs, 32);
+                l_run[qb] = l_run[qb] * alpha[qb] + rs;
+                m_run[qb] = m_new;
+            }
+        } else {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (s0 + kb * 16 + 4 * g + r >= T) st[kb][qb][r] = -INFINITY;
+                        mx = fmaxf(mx, st[kb][qb][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run[qb], mx);
+                alpha[qb] = (m_run[qb] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+                float rs = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = (st[kb][qb][r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[kb][qb][r] - m_new);
+                        st[kb][qb][r] = pv;
+                        rs += pv;
+                    }
+                rs += __shfl_xor(rs, 16);
+                rs += __shfl_xor(rs, 32);
+                l_run[qb] = l_run[qb] * alpha[qb] + rs;
+                m_run[qb] = m_new;
+            }
         }
         // ---- rescale O (rows = queries 4g + r of the block: fetch their alpha from the lane that owns that query)
 #pragma unroll
@@ -451,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
         const float inv_own = 1.0f / l_run[qb];
         if (lse && g == 0) {
             const int q = q0w + qb * 16 + li;
-            if (q < T) lse[((size_t)b * H + h) * T + q] = m_run[qb] + __logf(l_run[qb]);
+            if (q < T) lse[((size_t)b * H + h) * T + q] = m_run[qb] * 0.693147180559945309f + __logf(l_run[qb]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
