@@ -9,10 +9,11 @@ import ctypes as C
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
-# (C0, C1, Cout, K, T, gn+silu)
+# (C0, C1, Cout, K, T, prologue: 0 none, 1 GN + SiLU, 2 GN only)
 LAYERS = [(64, 0, 64, 5, 4096, 1), (128, 0, 128, 5, 2048, 1), (256, 0, 256, 5, 1024, 1), (256, 0, 256, 5, 512, 1),
           (256, 256, 256, 5, 1024, 1), (256, 128, 256, 5, 1024, 1), (256, 256, 256, 1, 1024, 0), (256, 0, 768, 1, 512, 1),
-          (128, 64, 128, 5, 2048, 1), (128, 64, 64, 5, 4096, 1)]
+          (128, 64, 128, 5, 2048, 1), (128, 64, 64, 5, 4096, 1),
+          (256, 0, 768, 1, 512, 2), (256, 0, 256, 1, 512, 0)]  # the attention block's qkv / proj_out
 lib = _lib.load()
 for (C0, C1, Co, K, T, gn) in LAYERS:
     x0 = torch.randn(B, T, C0, device=dev)
@@ -28,7 +29,7 @@ for (C0, C1, Co, K, T, gn) in LAYERS:
     d = _lib.TqConvDesc()
     d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T, T, C0, C1, Co
     d.ktaps, d.stride, d.pad, d.upsample = K, 1, K // 2, 0
-    d.flags = (3 if gn else 0) | 16
+    d.flags = {0: 0, 1: 3, 2: 1}[gn] | 16
     d.wfmt = d_wfmt
     stream = torch.cuda.current_stream().cuda_stream
     p = lambda t: None if t is None else t.data_ptr()

@@ -129,9 +129,14 @@ struct Cfg {
 // ACT (compile time): prologue applied while staging -- 0 none, 1 folded GN, 2 GN + SiLU, 3 GN + SiLU + dropout
 // FUSE: the ResBlock's 1x1 skip convolution (unet.py:112,143) is accumulated into the same MFMA accumulators as extra
 // 32-channel stages read from the block input (plain, centre tap), instead of a separate launch + residual round trip
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH>
+// PW ("pointwise, input-stationary"; 1x1 convs of the attention block, blocks.py:127-145): the whole input tile (all <= 4 chunks)
+// is staged ONCE into its own LDS buffers with every load in flight together, then the workgroup runs over all output-channel
+// tiles: no per-chunk barrier / load round trip (a 1x1 chunk has 1/5 of the MFMA work to hide one under) and no re-staging of
+// the same rows by 3 channel-tile workgroups (qkv).
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
     static_assert(SCH == 0 || (EPI != 1 && STRIDE == 1), "the fp16-range scheme serves stride-1 forward launches");
+    static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH == 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, f16+mx8");
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef TQ_STAMP
@@ -152,7 +157,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     int bid = blockIdx.x;
     int ct, tile;
     const int ntile = p.B * n_ttiles;
-    if (n_ctiles > 1 && (ntile & 7) == 0) {
+    if constexpr (PW) {
+        ct = 0;  // the workgroup visits every channel tile itself
+        tile = bid;
+    } else if (n_ctiles > 1 && (ntile & 7) == 0) {
         const int grp = bid / (8 * n_ctiles), within = bid % (8 * n_ctiles);
         ct = within >> 3;
         tile = grp * 8 + (within & 7);
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     const int tt = tile % n_ttiles;
     const int b = tile / n_ttiles;
     const int t0 = tt * C::NT;
-    const int co_wave = ct * C::MT + wm * 32;
+    int co_wave = ct * C::MT + wm * 32;
     const bool wave_active = co_wave < p.C_out;
 
     const int Cin = p.C0 + p.C1;
@@ -314,14 +322,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     };
 
     f32x4 acc[2][8];
+    if constexpr (!PW) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int pw_c0 = 0;  // PW: first chunk of the pair the MFMA stream works on ("taps" of that stream = chunks = LDS buffers)
 
     const int kq = lane >> 4;
     const int tl_lane = wn * 128 + (lane & 15);
-    const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * (C::NW / 2)) * 64 + lane;
+    const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * (C::NW / 2)) * 64 + lane;  // (PW: advanced per channel tile)
     const size_t wstep = (size_t)p.ncob_pad * (C::NW / 2) * 64;  // uint4 per (chunk, tap)
 
     // ---- MFMA phase of one chunk.  Written as straight-line code (no branches inside: hipcc's waitcnt insertion falls back to
@@ -352,6 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             // and each reload waits for vmcnt(0), i.e. for the staging loads in flight
             asm volatile("" : "+v"(tl));
         }
+        if constexpr (PW) return tl * 128 + ((kq ^ (tl & 7)) << 4) + (pw_c0 + k) * C::BUF;
         const int rowk = (STRIDE == 1) ? (tl + k) : ((k & 1) * (C::NT + 1) + tl + (k >> 1));
         if constexpr (SCH == 0) return rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
         else return rowk * 128 + ((kq ^ (rowk & 7)) << 4);
@@ -466,63 +478,109 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- main loop over the stages (32-channel chunks of the conv input, then of the fused skip input)
-    stage_load(0);
-    if (wave_active) {
+    const int npass = PW ? n_ctiles : 1;
+    if constexpr (PW) {
+        // every chunk's loads in flight together (64 + 32 registers, nothing else is live yet), then one transform + store pass
+        static_assert(!PW || C::NIT == C::PRE, "PW stages a chunk in PRE iterations");
+        float4 rr[4][C::PRE], ga4[4], gs4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cc = c < nchunks ? c : nchunks - 1;  // (fewer than 4 chunks: the spare buffers get a copy of the last one)
+            int cs;
+            const float* base = chunk_base(cc, cs);
+#pragma unroll
+            for (int it = 0; it < C::PRE; ++it) rr[c][it] = load_one(base, cs, it);
+            if (ACT >= 1) {
+                ga4[c] = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cc * C::CH + 4 * m);
+                gs4[c] = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cc * C::CH + 4 * m);
+            }
+        }
         load_w(0, wa);
-        if (KT > 1 || nskip > 0) load_w(1, wb);
-    }
-    stage_write(0, 0);
-    __syncthreads();
-#ifdef TQ_STAMP
-    unsigned long long s_load = 0, s_mma = 0, s_write = 0, s_bar = 0;
-    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    if (tid == 0 && blockIdx.x < 4096) {
-        unsigned long long* tl = tq_timeline + blockIdx.x * 8;
-        tl[0] = r_entry; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[4] = t_entry; tl[5] = t_begin;
-    }
-#endif
-    for (int c = 0; c + 1 < nstages; ++c) {
-        TQ_T(tA)
-#ifndef TQ_ABL_NOSTAGE
-        stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
-#endif
-        TQ_T(tB)
-        if (wave_active) {
-            if (!FUSE || c < nchunks) compute(c, c & 1);
-            else compute_skip(c - nchunks, c & 1);
+        load_w(1, wb);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (ACT >= 1) { g_a = ga4[c]; g_s = gs4[c]; }
+#pragma unroll
+            for (int it = 0; it < C::PRE; ++it) write_one(c < nchunks ? c : nchunks - 1, c, it, rr[c][it]);
         }
-        TQ_T(tC)
-#ifndef TQ_ABL_NOSTAGE
-        stage_write(c + 1, (c + 1) & 1);
-#endif
-        TQ_T(tD)
         __syncthreads();
-        TQ_T(tE)
-#ifdef TQ_STAMP
-        s_load += tB - tA; s_mma += tC - tB; s_write += tD - tC; s_bar += tE - tD;
-#endif
     }
-    if (wave_active) {
-        if (!FUSE || nskip == 0) compute(nstages - 1, (nstages - 1) & 1);
-        else compute_skip(nskip - 1, (nstages - 1) & 1);
-    }
-#ifdef TQ_STAMP
-    if (lane == 0) {
-        const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 7) {  // one workgroup's phase sums are enough (atomics from every wave perturb the kernel)
-            atomicAdd(&tq_stamps[0], s_load); atomicAdd(&tq_stamps[1], s_mma); atomicAdd(&tq_stamps[2], s_write);
-            atomicAdd(&tq_stamps[3], s_bar); atomicAdd(&tq_stamps[4], t_loop - t_begin); atomicAdd(&tq_stamps[5], 1ull);
+    int pass = 0;
+next_pass:  // (PW only: a loop statement here costs the other instantiations registers)
+    if constexpr (PW) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; 2 * j < nchunks; ++j) {
+            pw_c0 = 2 * j;
+            mma_stream(lds, lds + C::PLANE, 2 * j, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
         }
+        // the next channel tile's first weights are requested BEFORE this tile's stores: vmcnt retires in order, behind the
+        // stores they would only arrive once the whole output tile has drained
+        if (pass + 1 < npass) wbase += (size_t)(C::MT >> 4) * (C::NW / 2) * 64;
+        load_w(0, wa);
+        load_w(1, wb);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        // ---- main loop over the stages (32-channel chunks of the conv input, then of the fused skip input)
+        stage_load(0);
+        if (wave_active) {
+            load_w(0, wa);
+            if (KT > 1 || nskip > 0) load_w(1, wb);
+        }
+        stage_write(0, 0);
+        __syncthreads();
+#ifdef TQ_STAMP
+        unsigned long long s_load = 0, s_mma = 0, s_write = 0, s_bar = 0;
+        const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
         if (tid == 0 && blockIdx.x < 4096) {
             unsigned long long* tl = tq_timeline + blockIdx.x * 8;
-            tl[2] = __builtin_amdgcn_s_memrealtime(); tl[6] = t_loop;
+            tl[0] = r_entry; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[4] = t_entry; tl[5] = t_begin;
         }
-    }
+#endif
+        for (int c = 0; c + 1 < nstages; ++c) {
+            TQ_T(tA)
+#ifndef TQ_ABL_NOSTAGE
+            stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
+#endif
+            TQ_T(tB)
+            if (wave_active) {
+                if (!FUSE || c < nchunks) compute(c, c & 1);
+                else compute_skip(c - nchunks, c & 1);
+            }
+            TQ_T(tC)
+#ifndef TQ_ABL_NOSTAGE
+            stage_write(c + 1, (c + 1) & 1);
+#endif
+            TQ_T(tD)
+            __syncthreads();
+            TQ_T(tE)
+#ifdef TQ_STAMP
+            s_load += tB - tA; s_mma += tC - tB; s_write += tD - tC; s_bar += tE - tD;
+#endif
+        }
+        if (wave_active) {
+            if (!FUSE || nskip == 0) compute(nstages - 1, (nstages - 1) & 1);
+            else compute_skip(nskip - 1, (nstages - 1) & 1);
+        }
+#ifdef TQ_STAMP
+        if (lane == 0) {
+            const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 7) {  // one workgroup's phase sums are enough (atomics from every wave perturb the kernel)
+                atomicAdd(&tq_stamps[0], s_load); atomicAdd(&tq_stamps[1], s_mma); atomicAdd(&tq_stamps[2], s_write);
+                atomicAdd(&tq_stamps[3], s_bar); atomicAdd(&tq_stamps[4], t_loop - t_begin); atomicAdd(&tq_stamps[5], 1ull);
+            }
+            if (tid == 0 && blockIdx.x < 4096) {
+                unsigned long long* tl = tq_timeline + blockIdx.x * 8;
+                tl[2] = __builtin_amdgcn_s_memrealtime(); tl[6] = t_loop;
+            }
+        }
 #endif
 
+    }
     // ---- epilogue
-    if (!wave_active) return;
+    if (!PW && !wave_active) return;
     if constexpr (EPI == 2) {
         // qkv projection feeding attention_fwd2 (blocks.py:139-145): q stays fp32 in the (B, T, 3 H D) tensor, k (scaled by
         // D^-1/4 like q inside the kernel) and v are written as the bf16 hi / lo planes kv[b][h][K hi, K lo, V hi, V lo][t][d]
@@ -709,6 +767,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             }
         }
     }
+    if constexpr (PW) {
+        co_wave += C::MT;
+        if (++pass < npass) goto next_pass;
+    }
 #ifdef TQ_STAMP
     if (tid == 0 && blockIdx.x < 4096) {
         unsigned long long* tl = tq_timeline + blockIdx.x * 8;
@@ -717,21 +779,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #endif
 }
 
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH = 0>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH = 0, bool PW = false>
 int launch(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
-    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW>;
+    constexpr int LDS_BYTES = PW ? 4 * C::BUF : C::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int n_ttiles = (a.T_out + C::NT - 1) / C::NT;
     const int n_ctiles = (a.C_out + C::MT - 1) / C::MT;
-    const unsigned grid = (unsigned)(a.B * n_ttiles * n_ctiles);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, a);
+    const unsigned grid = (unsigned)(a.B * n_ttiles * (PW ? 1 : n_ctiles));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), LDS_BYTES, stream, a);
     TQ_CHECK_LAUNCH();
     return 0;
 }
@@ -742,6 +805,12 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // fused skip conv (its extra live state does not fit the 256 registers of two waves per SIMD next to this scheme's)
         if constexpr (STRIDE == 1 && EPI != 1 && !FUSE) {
             if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
+            if constexpr (KT == 1 && UPS == 0 && ACT <= 1) {  // the attention block's 1x1 convs: input-stationary variant
+                const int cin = a.C0 + a.C1;
+                // (one channel tile, i.e. proj_out: nothing to share, measured equal -> the generic path)
+                if (a.C_out % 256 == 0 && a.C_out >= 512 && (cin == 128 || cin == 256))
+                    return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1, true>(a, s);
+            }
             if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
             if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
         }
