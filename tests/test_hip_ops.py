@@ -92,6 +92,34 @@ def test_conv_both_contraction_schemes(cin0, cin1, cout, k, T, gn):
     assert torch.isnan(y[0, 5]).any() and torch.isfinite(y[1]).all()
 
 
+@pytest.mark.parametrize("cin0,cin1,cout,T,gn", [
+    (256, 0, 768, 500, True), (128, 128, 512, 129, True), (128, 0, 512, 64, False), (64, 64, 1024, 300, True), (256, 0, 512, 31, False),
+])
+def test_conv_pointwise_input_stationary(cin0, cin1, cout, T, gn):
+    """1x1 convs with several 256-channel output tiles and 128 / 256 input channels run the input-stationary variant (whole input
+    tile staged once, the workgroup loops over the channel tiles): GN-only prologue (AttentionBlock.norm, blocks.py:138), two
+    sources, embedding + residual epilogue, ragged T, statistics; and the bf16x3 generic path on the same data."""
+    from tqdne_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin0 + 3 * cin1 + cout + T)
+    B = 3
+    x0 = torch.randn(B, cin0, T, generator=g) * 2 + 0.5
+    x1 = torch.randn(B, cin1, T, generator=g) if cin1 else None
+    cin = cin0 + cin1
+    w = torch.randn(cout, cin, 1, generator=g) / math.sqrt(cin)
+    b, emb, res = torch.randn(cout, generator=g), torch.randn(B, cout, generator=g), torch.randn(B, cout, T, generator=g)
+    a, sh = (torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g)) if gn else (None, None)
+    d = dev()
+    xin = torch.cat([x0, x1], 1) if cin1 else x0
+    if gn:
+        xin = xin * a[:, :, None] + sh[:, :, None]
+    ref = F.conv1d(xin, w, b) + emb[:, :, None] + res
+    for wfmt in (_lib.TQ_WFMT_F16_MX8, _lib.TQ_WFMT_BF16X3):
+        y, st = ops.conv1d(cl(x0), w.to(d), b.to(d), x1=cl(x1) if cin1 else None, gscale=a.to(d) if gn else None,
+                           gshift=sh.to(d) if gn else None, silu=False, emb=emb.to(d), residual=cl(res), wfmt=wfmt)
+        assert rel_err(ncw(y), ref) < TOL, wfmt
+        assert rel_err(st.cpu(), ref_stats(ref)) < TOL, wfmt
+
+
 def test_conv_fused_everything():
     """GN scale/shift + SiLU + two concat sources + emb + residual, ragged T."""
     from tqdne_amd import ops
