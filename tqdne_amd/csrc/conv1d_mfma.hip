@@ -539,30 +539,53 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             tl[0] = r_entry; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[4] = t_entry; tl[5] = t_begin;
         }
 #endif
-        for (int c = 0; c + 1 < nstages; ++c) {
-            TQ_T(tA)
+        if constexpr (!FUSE) {
+            for (int c = 0; c + 1 < nstages; ++c) {
+                TQ_T(tA)
 #ifndef TQ_ABL_NOSTAGE
-            stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
+                stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
 #endif
-            TQ_T(tB)
-            if (wave_active) {
-                if (!FUSE || c < nchunks) compute(c, c & 1);
-                else compute_skip(c - nchunks, c & 1);
-            }
-            TQ_T(tC)
+                TQ_T(tB)
+                if (wave_active) {
+                    if (!FUSE || c < nchunks) compute(c, c & 1);
+                    else compute_skip(c - nchunks, c & 1);
+                }
+                TQ_T(tC)
 #ifndef TQ_ABL_NOSTAGE
-            stage_write(c + 1, (c + 1) & 1);
+                stage_write(c + 1, (c + 1) & 1);
 #endif
-            TQ_T(tD)
-            __syncthreads();
-            TQ_T(tE)
+                TQ_T(tD)
+                __syncthreads();
+                TQ_T(tE)
 #ifdef TQ_STAMP
-            s_load += tB - tA; s_mma += tC - tB; s_write += tD - tC; s_bar += tE - tD;
+                s_load += tB - tA; s_mma += tC - tB; s_write += tD - tC; s_bar += tE - tD;
 #endif
-        }
-        if (wave_active) {
-            if (!FUSE || nskip == 0) compute(nstages - 1, (nstages - 1) & 1);
-            else compute_skip(nskip - 1, (nstages - 1) & 1);
+            }
+            if (wave_active) {
+                if (!FUSE || nskip == 0) compute(nstages - 1, (nstages - 1) & 1);
+                else compute_skip(nskip - 1, (nstages - 1) & 1);
+            }
+        } else {
+            // Fused skip conv: main chunks and skip chunks run in SEPARATE loops (one loop with a per-stage branch between the
+            // two MFMA streams cost ~50 registers: both streams' live ranges end up merged across the loop)
+            for (int c = 0; c + 1 < nchunks; ++c) {
+                stage_load(c + 1);
+                if (wave_active) compute(c, c & 1);
+                stage_write(c + 1, (c + 1) & 1);
+                __syncthreads();
+            }
+            stage_load(nchunks);  // first skip chunk, under the last main chunk
+            if (wave_active) compute(nchunks - 1, (nchunks - 1) & 1);
+            stage_write(nchunks, nchunks & 1);
+            __syncthreads();
+            for (int j = 0; j + 1 < nskip; ++j) {
+                const int st = nchunks + j;
+                stage_load(st + 1);
+                if (wave_active) compute_skip(j, st & 1);
+                stage_write(st + 1, (st + 1) & 1);
+                __syncthreads();
+            }
+            if (wave_active) compute_skip(nskip - 1, (nstages - 1) & 1);
         }
 #ifdef TQ_STAMP
         if (lane == 0) {
@@ -801,9 +824,11 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 
 template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
-    if (a.wfmt == TQ_WFMT_F16_MX8) {  // built for stride-1 forward launches with 128 | C_out and 64-channel sources, without the
-        // fused skip conv (its extra live state does not fit the 256 registers of two waves per SIMD next to this scheme's)
-        if constexpr (STRIDE == 1 && EPI != 1 && !FUSE) {
+    if (a.wfmt == TQ_WFMT_F16_MX8) {  // built for stride-1 forward launches with 128 | C_out and 64-channel sources; with the fused
+        // skip conv only for the 256-channel tile (the 128-channel one has 4 of its 8 waves' worth of registers to hide latency
+        // with and spills > 100 of them)
+        if constexpr (STRIDE == 1 && EPI != 1) {
+            if (FUSE && a.C_out % 256) return TQ_ERR_SHAPE;
             if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
             if constexpr (KT == 1 && UPS == 0 && ACT <= 1) {  // the attention block's 1x1 convs: input-stationary variant
                 const int cin = a.C0 + a.C1;
@@ -812,7 +837,9 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
                     return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1, true>(a, s);
             }
             if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
-            if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
+            if constexpr (!FUSE) {
+                if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
+            }
         }
         return TQ_ERR_SHAPE;
     }
