@@ -22,15 +22,14 @@ TQ_WFMT_BF16X3, TQ_WFMT_F16_MX8 = 0, 1
 
 def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False) -> int:
     """Contraction scheme of a forward conv launch (include/tqdne_hip.h, TQ_WFMT_*): fp16 + block-scaled-fp8 corrections where
-    the kernel is built for the shape (stride 1 incl. the nearest-upsampling convs, 128 | C_out -- 256 | C_out with a fused skip conv --, 64 | every
-    source's channels), bf16x3 elsewhere.
+    the kernel is built for the shape (stride 1 incl. the nearest-upsampling convs, 128 | C_out, 64 | every source's channels incl. a fused skip conv's), bf16x3 elsewhere.
     TQDNE_CONV_SCHEME=bf16x3 forces the fp32-range three-product scheme everywhere."""
     v = os.environ.get("TQDNE_CONV_SCHEME", "f16mx8").lower()
     if v not in ("bf16x3", "f16mx8"):
         raise ValueError(f"TQDNE_CONV_SCHEME={v!r}: expected bf16x3 or f16mx8")
     ok = stride == 1 and C_out % 128 == 0 and all(c % 64 == 0 for c in sources if c)
-    if fused_skip:  # the 256-channel tile of the fused launch fits this scheme's registers, the 128-channel one does not
-        ok = ok and C_out % 256 == 0 and os.environ.get("TQDNE_FUSED_SKIP_MX8", "1") != "0"
+    if fused_skip:
+        ok = ok and os.environ.get("TQDNE_FUSED_SKIP_MX8", "1") != "0"
     return TQ_WFMT_F16_MX8 if (v == "f16mx8" and ok) else TQ_WFMT_BF16X3
 TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_DROPOUT, TQ_BWD_ACCUM, TQ_BWD_STATS = 1, 2, 4, 8, 16
 STAT_SLOT = 128

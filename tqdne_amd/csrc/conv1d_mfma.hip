@@ -115,7 +115,10 @@ struct Cfg {
     static constexpr int MT = 32 * WM;   // output channels per workgroup
     static constexpr int ROWS = (STRIDE == 1) ? (NT + KT - 1) : (2 * NT + 1);
     static constexpr int NIT = (ROWS * TPR + NTHR - 1) / NTHR;
-    static constexpr int PRE_MAX = TQ_STAGE_PRE;   // staging iterations prefetched into registers across the MFMA phase
+    // staging iterations prefetched into registers across the MFMA phase.  The 4-wave tile of scheme 1 stages twice as many rows
+    // per thread as the 8-wave one and has no registers left for them: with 5 in flight it spilled 36 registers into the chunk
+    // loop, with 1 (the rest loaded + written in batches after the MFMAs, covered by the co-resident workgroup) none: -4 ... -10 %
+    static constexpr int PRE_MAX = (SCH == 1 && WM == 4) ? 1 : TQ_STAGE_PRE;
     static constexpr int PRE = NIT < PRE_MAX ? NIT : PRE_MAX;
     static constexpr int SYNC_BATCH = 4;           // the rest is loaded+written synchronously in batches
     static constexpr int ITERS = (NIT <= PRE) ? NIT : PRE + ((NIT - PRE + SYNC_BATCH - 1) / SYNC_BATCH) * SYNC_BATCH;
@@ -183,7 +186,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // ---- staging bookkeeping: thread owns 4 consecutive channels (m) of rows i = (tid + it*NTHR) / TPR
     const int m = tid % C::TPR;
     const int wslot = m >> 1, whalf = m & 1;  // 16-byte slot (k quarter) and 8-byte half owned by this thread
-    float4 raw[C::PRE];
+    // (the fused-skip launch of the 8-wave scheme-1 tile prefetches 4 of its 5 staging iterations and loads the last one after the
+    // MFMAs: one float4 less in flight across the chunk loop is what it takes to keep that loop free of spills)
+    // (the dropout prologue of the training forward needs more still: 1 + 4)
+    constexpr bool TIGHT = SCH == 1 && WM == 8 && C::PRE == 5 && C::NIT == 5;
+    constexpr int PRE = (TIGHT && ACT == 3) ? 1 : (TIGHT && FUSE) ? 4 : C::PRE;
+    constexpr int SYNC_BATCH = (TIGHT && ACT == 3) ? 4 : (TIGHT && FUSE) ? 1 : C::SYNC_BATCH;
+    float4 raw[PRE];
     float4 g_a, g_s;
 
     auto src_pos = [&](int i) -> int __attribute__((always_inline)) {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         int cs;
         const float* base = chunk_base(chunk, cs);
 #pragma unroll
-        for (int it = 0; it < C::PRE; ++it) raw[it] = load_one(base, cs, it);
+        for (int it = 0; it < PRE; ++it) raw[it] = load_one(base, cs, it);
         if (ACT >= 1) {  // folded GroupNorm coefficients of this thread's 4 channels (skip stages: clamped, unused)
             const int cb = (chunk < nchunks ? chunk : nchunks - 1) * C::CH;
             g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
@@ -305,18 +314,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // phase 2 (after them): transform + LDS write; iterations beyond PRE are loaded here in small batches
     auto stage_write = [&](int chunk, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < C::PRE; ++it)
+        for (int it = 0; it < PRE; ++it)
             write_one(chunk, buf, it, raw[it]);
-        if (C::NIT > C::PRE) {
+        if (C::NIT > PRE) {
             int cs;
             const float* base = chunk_base(chunk, cs);
 #pragma unroll 1
-            for (int it0 = C::PRE; it0 < C::NIT; it0 += C::SYNC_BATCH) {
-                float4 tmp[C::SYNC_BATCH];
+            for (int it0 = PRE; it0 < C::NIT; it0 += SYNC_BATCH) {
+                float4 tmp[SYNC_BATCH];
 #pragma unroll
-                for (int j = 0; j < C::SYNC_BATCH; ++j) tmp[j] = load_one(base, cs, it0 + j);
+                for (int j = 0; j < SYNC_BATCH; ++j) tmp[j] = load_one(base, cs, it0 + j);
 #pragma unroll
-                for (int j = 0; j < C::SYNC_BATCH; ++j) write_one(chunk, buf, it0 + j, tmp[j]);
+                for (int j = 0; j < SYNC_BATCH; ++j) write_one(chunk, buf, it0 + j, tmp[j]);
             }
         }
     };
@@ -828,7 +837,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
         // skip conv only for the 256-channel tile (the 128-channel one has 4 of its 8 waves' worth of registers to hide latency
         // with and spills > 100 of them)
         if constexpr (STRIDE == 1 && EPI != 1) {
-            if (FUSE && a.C_out % 256) return TQ_ERR_SHAPE;
+
             if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
             if constexpr (KT == 1 && UPS == 0 && ACT <= 1) {  // the attention block's 1x1 convs: input-stationary variant
                 const int cin = a.C0 + a.C1;
@@ -837,9 +846,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
                     return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1, true>(a, s);
             }
             if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
-            if constexpr (!FUSE) {
-                if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
-            }
+            if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
         }
         return TQ_ERR_SHAPE;
     }
