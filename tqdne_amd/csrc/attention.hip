@@ -299,34 +299,6 @@ __device__ __forceinline__ void att_write(const uint4 (&stg)[NIT], unsigned char
     }
 }
 
-// the same with separate tile indices for the K planes (0, 1) and the V planes (2, 3); LDS buffer = tile index & 1
-template <int D, int NIT>
-__device__ __forceinline__ void att_load2(uint4 (&stg)[NIT], const unsigned char* kvb, size_t gplane, int ka, int va, int tid) {
-    constexpr int V16 = D / 8;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = tid + it * 256;
-        const int pl = i / (64 * V16), rem = i % (64 * V16);
-        const int row = rem / V16, c16 = rem % V16;
-        const int kt = pl < 2 ? ka : va;
-        stg[it] = *reinterpret_cast<const uint4*>(kvb + pl * gplane + ((size_t)(kt * 64 + row) * D) * 2 + c16 * 16);
-    }
-}
-template <int D, int NIT>
-__device__ __forceinline__ void att_write2(const uint4 (&stg)[NIT], unsigned char* lds, int ka, int va, int tid) {
-    constexpr int V16 = D / 8;
-    constexpr int ROWB = 2 * D + 32;
-    constexpr int PLANE = 64 * ROWB;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = tid + it * 256;
-        const int pl = i / (64 * V16), rem = i % (64 * V16);
-        const int row = rem / V16, c16 = rem % V16;
-        const int buf = (pl < 2 ? ka : va) & 1;
-        *reinterpret_cast<uint4*>(lds + buf * (4 * PLANE) + pl * PLANE + row * ROWB + c16 * 16) = stg[it];
-    }
-}
-
 #ifdef TQ_STAMP
 // diagnostic build only: per-workgroup phase stamps of the forward kernel (s_memrealtime, 10 ns ticks; [6], [7] = s_memtime)
 __device__ unsigned long long tq_att_timeline[4096 * 8];
@@ -397,15 +369,28 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
     const size_t gplane = (size_t)Tp * D * 2;
     const unsigned char* kvb = kv + (((size_t)b * H + h) * 4) * gplane;
     const int nkt = (T + 63) / 64;
-
-    // S^T tile of key tile j (its K planes sit in LDS buffer j & 1): sx[kb][qb], lane holds keys kb*16 + 4g + r of query qb*16 + li
-    auto scores = [&](int j, f32x4 (&sx)[4][QB]) {
-        const unsigned char* k_hi = lds + BUFB * (j & 1);
+    {
+        uint4 stg[NIT];
+        att_load<D, NIT>(stg, kvb, gplane, 0, tid);
+        att_write<D, NIT>(stg, lds, 0, tid);
+    }
+    __syncthreads();
+    ATT_T(2)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int s0 = kt * 64;
+        const bool more = (kt + 1) < nkt;
+        const unsigned char* k_hi = lds + BUFB * (kt & 1);
         const unsigned char* k_lo = k_hi + PLANE;
+        const unsigned char* v_hi = k_hi + 2 * PLANE;
+        const unsigned char* v_lo = k_hi + 3 * PLANE;
+        uint4 stg[NIT];
+        att_load<D, NIT>(stg, kvb, gplane, more ? kt + 1 : kt, tid);  // in flight under this tile's MFMAs, written to the other buffer afterwards
+        // ---- S^T tiles: st[kb][qb], lane holds keys kb*16 + 4g + r of query qb*16 + li
+        f32x4 st[4][QB];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) sx[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qb = 0; qb < QB; ++qb) st[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 Frag ah, al;
@@ -413,44 +398,69 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
                 ah.u = *reinterpret_cast<const uint4*>(k_hi + off);
                 al.u = *reinterpret_cast<const uint4*>(k_lo + off);
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) sx[kb][qb] = mfma_x3(ah.v, al.v, qh[qb][ks].v, ql[qb][ks].v, sx[kb][qb]);
+                for (int qb = 0; qb < QB; ++qb) st[kb][qb] = mfma_x3(ah.v, al.v, qh[qb][ks].v, ql[qb][ks].v, st[kb][qb]);
             }
         }
-    };
-    // online softmax per query (lane column), keys spread over kb, r (in-lane) and g (lanes li + 16 g); scores are in log2 units
-    // (log2 e is folded into Q's scale), so p = exp2(s - m) is one v_sub + one v_exp.  MASK only for a ragged last key tile.
-    float alpha[QB];
-    auto softmax = [&](f32x4 (&sx)[4][QB], int s0, auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
+        // ---- online softmax per query (lane column), keys spread over kb, r (in-lane) and g (lanes li + 16 g); scores are in
+        //      log2 units (log2 e is folded into Q's scale), so p = exp2(s - m) is one v_sub + one v_exp
+        float alpha[QB];
+        if (s0 + 64 <= T) {  // full key tile (every tile when 64 | T): no masking, every score finite
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float mx = -INFINITY;
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = st[0][qb][0];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (MASK && s0 + kb * 16 + 4 * g + r >= T) sx[kb][qb][r] = -INFINITY;
-                    mx = fmaxf(mx, sx[kb][qb][r]);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qb], mx);
-            alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);  // exp2(-inf) = 0 on the first tile (m_new is finite: a key tile
-            float rs = 0.f;                                         // holds at least one valid key)
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run[qb], mx);
+                alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);  // exp2(-inf) = 0 on the first tile
+                float rs = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(sx[kb][qb][r] - m_new);  // masked keys: exp2(-inf) = 0
-                    sx[kb][qb][r] = pv;
-                    rs += pv;
-                }
-            rs += __shfl_xor(rs, 16);
-            rs += __shfl_xor(rs, 32);
-            l_run[qb] = l_run[qb] * alpha[qb] + rs;
-            m_run[qb] = m_new;
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - m_new);
+                        st[kb][qb][r] = pv;
+                        rs += pv;
+                    }
+                rs += __shfl_xor(rs, 16);
+                rs += __shfl_xor(rs, 32);
+                l_run[qb] = l_run[qb] * alpha[qb] + rs;
+                m_run[qb] = m_new;
+            }
+        } else {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (s0 + kb * 16 + 4 * g + r >= T) st[kb][qb][r] = -INFINITY;
+                        mx = fmaxf(mx, st[kb][qb][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run[qb], mx);
+                alpha[qb] = (m_run[qb] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+                float rs = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = (st[kb][qb][r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[kb][qb][r] - m_new);
+                        st[kb][qb][r] = pv;
+                        rs += pv;
+                    }
+                rs += __shfl_xor(rs, 16);
+                rs += __shfl_xor(rs, 32);
+                l_run[qb] = l_run[qb] * alpha[qb] + rs;
+                m_run[qb] = m_new;
+            }
         }
-        // rescale O (rows = queries 4g + r of the block: fetch their alpha from the lane that owns that query)
+        // ---- rescale O (rows = queries 4g + r of the block: fetch their alpha from the lane that owns that query)
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -459,21 +469,17 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) o[qb][cb][r] *= ar;
             }
-    };
-    // O += P V for key tile j (V planes in LDS buffer j & 1); k-slot (g, j) of a 32-key step <-> key 16*(j>>2) + 4g + (j&3)
-    auto accumulate = [&](int j, const f32x4 (&sx)[4][QB]) {
-        const unsigned char* v_hi = lds + BUFB * (j & 1) + 2 * PLANE;
-        const unsigned char* v_lo = v_hi + PLANE;
+        // ---- O += P V, k-slot (g, j) of a 32-key step <-> key 16*(j>>2) + 4g + (j&3)
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
             Frag ph[QB], pl[QB];
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
+                for (int j = 0; j < 8; ++j) {
                     __bf16 hh, ll;
-                    split_bf16(sx[2 * ks2 + (jj >> 2)][qb][jj & 3], hh, ll);
-                    ph[qb].v[jj] = hh; pl[qb].v[jj] = ll;
+                    split_bf16(st[2 * ks2 + (j >> 2)][qb][j & 3], hh, ll);
+                    ph[qb].v[j] = hh; pl[qb].v[j] = ll;
                 }
             const int vrow = ks2 * 32 + 4 * g + ((lane >> 2) & 3);
 #pragma unroll
@@ -486,41 +492,10 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
                 for (int qb = 0; qb < QB; ++qb) o[qb][cb] = mfma_x3(ph[qb].v, pl[qb].v, bh.v, bl.v, o[qb][cb]);
             }
         }
-    };
-
-    // Software pipeline over key tiles: iteration kt issues the score MFMAs of tile kt + 1 next to the softmax VALU work of tile kt
-    // (independent instruction streams of one wave), then accumulates P V of tile kt.  K therefore runs one tile ahead of V in LDS:
-    // buffer j & 1 holds K(j) and V(j), K(kt + 2) and V(kt + 1) are in flight during iteration kt.
-    {
-        uint4 sa[NIT], sb[NIT];
-        att_load2<D, NIT>(sa, kvb, gplane, 0, 0, tid);
-        att_load2<D, NIT>(sb, kvb, gplane, nkt > 1 ? 1 : 0, 0, tid);
-        att_write2<D, NIT>(sa, lds, 0, 0, tid);
-        att_write2<D, NIT>(sb, lds, 1, 0, tid);  // (V(0) twice: harmless)
-    }
-    __syncthreads();
-    ATT_T(2)
-    f32x4 st[4][QB];
-    scores(0, st);
-    for (int kt = 0; kt + 1 < nkt; ++kt) {
-        uint4 stg[NIT];
-        att_load2<D, NIT>(stg, kvb, gplane, kt + 2 < nkt ? kt + 2 : nkt - 1, kt + 1, tid);
-        __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: a whole iteration of latency cover
-        f32x4 sn[4][QB];
-        scores(kt + 1, sn);
-        softmax(st, kt * 64, std::false_type{});
-        accumulate(kt, st);
-        att_write2<D, NIT>(stg, lds, kt + 2, kt + 1, tid);  // K(kt) and V(kt - 1) are dead since the previous barrier
+        att_write<D, NIT>(stg, lds + BUFB * ((kt + 1) & 1), 0, tid);  // (the last iteration re-stages its own tile: harmless)
         __syncthreads();
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) st[kb][qb] = sn[kb][qb];
     }
     ATT_T(3)
-    if (nkt * 64 == T) softmax(st, (nkt - 1) * 64, std::false_type{});
-    else softmax(st, (nkt - 1) * 64, std::true_type{});
-    accumulate(nkt - 1, st);
     ATT_T(4)
     // ---- normalise, store
 #pragma unroll
