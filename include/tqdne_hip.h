@@ -37,6 +37,12 @@ typedef struct ihipStream_t* hipStream_t;
 #define TQ_CONV_RES 8      /* add res[b, t, co] to the output (residual, unet.py:143 / blocks.py:145) */
 #define TQ_CONV_STATS 16   /* emit per-channel partial statistics of the output */
 #define TQ_CONV_DROPOUT 32 /* training-mode dropout on the activated input (unet.py:101) */
+/* TQ_CONV_POLY2 (tq_conv1d_fwd, stride 1, ktaps 3, no upsample): the launch is BOTH phases of "nearest x2 upsampling, then conv k = 5"
+ * (Upsample.forward, blocks.py:56-66) written as one k = 3 conv over the un-upsampled input -- even outputs see the taps
+ * (w0+w1, w2+w3, w4), odd outputs (w0, w1+w2, w3+w4), 3/5 of the multiply-adds.  C_out = 2*C: output channel block [p*C, (p+1)*C)
+ * is phase p and is stored to row 2t+p of a (B, 2*T_out, C) tensor; bias / emb / res are indexed by the real channel / row;
+ * statistics: 2*ceil(T_out/128) slots of C channels (slot = 2*tile + p; T_out must be a multiple of 128 with TQ_CONV_STATS). */
+#define TQ_CONV_POLY2 64
 
 /* TqConvDesc.wfmt: how the fp32 product x * w is contracted on the matrix cores (= format of the packed weights).
  * BF16X3: both operands split into bf16 hi + lo, three bf16 MFMA products; fp32 range, ~2^-16 relative (pack modes 0 / 1).

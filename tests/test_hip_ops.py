@@ -183,6 +183,46 @@ def test_conv_downsample(C, T):
     assert rel_err(st.cpu(), ref_stats(ref)) < TOL
 
 
+@pytest.mark.parametrize("C0,C1,Co,T", [(256, 0, 256, 256), (128, 0, 128, 384), (64, 64, 64, 128), (32, 0, 32, 128), (256, 0, 128, 512)])
+def test_conv_upsample_polyphase(C0, C1, Co, T):
+    """TQ_CONV_POLY2: nearest x2 upsampling + conv k = 5 (Upsample.forward, blocks.py:56-66) as one two-phase k = 3 conv over the
+    un-upsampled rows, through the C ABI: output, and the GroupNorm partial statistics summed over their slots."""
+    import ctypes as C_
+    from tqdne_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C0 + C1 + Co + T)
+    B, Cin = 2, C0 + C1
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Co, Cin, 5, generator=g) / math.sqrt(5 * Cin)
+    b = torch.randn(Co, generator=g)
+    ref = F.conv1d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=2)
+    w2 = torch.empty(2 * Co, Cin, 3)
+    w2[:Co, :, 0], w2[:Co, :, 1], w2[:Co, :, 2] = w[:, :, 0] + w[:, :, 1], w[:, :, 2] + w[:, :, 3], w[:, :, 4]
+    w2[Co:, :, 0], w2[Co:, :, 1], w2[Co:, :, 2] = w[:, :, 0], w[:, :, 1] + w[:, :, 2], w[:, :, 3] + w[:, :, 4]
+    d = dev()
+    x0, x1 = cl(x[:, :C0]), (cl(x[:, C0:]) if C1 else None)
+    for wfmt in {_lib.forward_wfmt(2 * Co, [C0, C1]), _lib.TQ_WFMT_BF16X3}:
+        wp = ops.pack_conv_weight(w2.to(d), 2 if wfmt == _lib.TQ_WFMT_F16_MX8 else 0)
+        y = torch.full((B, 2 * T, Co), float("nan"), device=d)
+        st = torch.full((B, 2 * T // 128, Co, 2), float("nan"), device=d)
+        desc = _lib.TqConvDesc()
+        desc.B, desc.T_in, desc.T_out, desc.C_in0, desc.C_in1, desc.C_out = B, T, T, C0, C1, 2 * Co
+        desc.ktaps, desc.stride, desc.pad, desc.upsample = 3, 1, 1, 0
+        desc.flags, desc.wfmt = _lib.TQ_CONV_STATS | _lib.TQ_CONV_POLY2, wfmt
+        bd = b.to(d)
+        p = lambda t: None if t is None else t.data_ptr()
+        rc = lib.tq_conv1d_fwd(C_.byref(desc), p(x0), p(x1), None, None, p(wp), p(bd), None, None, p(y), p(st),
+                               torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+        assert rel_err(ncw(y), ref) < TOL, wfmt
+        tot = st.cpu().double().sum(1)
+        assert rel_err(tot[..., 0].float(), ref.double().sum(-1).float()) < TOL
+        assert rel_err(tot[..., 1].float(), (ref.double() ** 2).sum(-1).float()) < TOL
+    desc.T_in = desc.T_out = T - 64  # statistics slots need whole 128-row tiles
+    assert lib.tq_conv1d_fwd(C_.byref(desc), p(x0), p(x1), None, None, p(wp), p(bd), None, None, p(y), p(st),
+                             torch.cuda.current_stream().cuda_stream) == -2  # TQ_ERR_SHAPE
+
+
 @pytest.mark.parametrize("C,T,k", [(128, 64, 5), (256, 127, 5), (64, 100, 3), (32, 62, 5)])
 def test_conv_upsample(C, T, k):
     from tqdne_amd import ops

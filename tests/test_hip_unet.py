@@ -492,13 +492,28 @@ def test_inference_forward_matches_backward_capable_forward(which):
     x = torch.randn(B, cfg["in_channels"], T, generator=g).to(dev())
     t = torch.randn(B, generator=g).to(dev())
     cond = torch.randn(B, 5, generator=g).to(dev())
-    eng = net._engine(B, T, dev())
+    import copy
+    import os
+    os.environ["TQDNE_POLYPHASE_UPSAMPLE"] = "0"
+    try:
+        eng = copy.deepcopy(net)._engine(B, T, dev())
+    finally:
+        del os.environ["TQDNE_POLYPHASE_UPSAMPLE"]
     a = eng.forward(x, t, cond).clone()
     b = eng.forward(x, t, cond, infer=True).clone()
     assert torch.equal(a, b)
     assert any(op[2].endswith("+split") for op in eng.ops_infer) and len(eng.ops) == len(eng.ops_infer)
     with pytest.raises(RuntimeError):
         eng.backward(torch.zeros_like(a), torch.ones((), device=dev()))
+    # default plan: the upsampling convs additionally run as two-phase k = 3 convs at inference (TQ_CONV_POLY2, where the
+    # un-upsampled length is a multiple of 128): same sums in a different order -> fp32-rounding-level differences only
+    eng2 = net._engine(B, T, dev())
+    a2 = eng2.forward(x, t, cond).clone()
+    b2 = eng2.forward(x, t, cond, infer=True).clone()
+    assert torch.equal(a2, a)
+    npoly = sum(op[2].endswith("+polyphase") for op in eng2.ops_infer)
+    assert npoly == (3 if which == "paper" else 0)
+    assert rel_err(b2.cpu(), a.cpu()) < 2e-5
 
 
 def test_latent_edm_training_step_gradients_vs_oracle():

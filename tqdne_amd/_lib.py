@@ -17,6 +17,7 @@ F = C.c_float
 SZ = C.c_size_t
 
 TQ_CONV_GN, TQ_CONV_SILU, TQ_CONV_EMB, TQ_CONV_RES, TQ_CONV_STATS, TQ_CONV_DROPOUT = 1, 2, 4, 8, 16, 32
+TQ_CONV_POLY2 = 64
 TQ_WFMT_BF16X3, TQ_WFMT_F16_MX8 = 0, 1
 
 

@@ -655,7 +655,13 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             }
         }
     } else if constexpr (EPI == 0) {
-    const int slot = (t0 >> 7) + wn;
+    // TQ_CONV_POLY2: the upper half of the (virtual) output channels is phase 1 of an upsampling conv: real channel co - C,
+    // real row 2t + 1 of a tensor with twice the rows and half the channels (a wave's 32 channels never straddle the phases)
+    const bool poly = p.flags & TQ_CONV_POLY2;
+    const int Cr = poly ? (p.C_out >> 1) : p.C_out;
+    const int ph = (poly && co_wave >= Cr) ? 1 : 0;
+    const int co_real = co_wave - ph * Cr;
+    const int slot = poly ? 2 * ((t0 >> 7) + wn) + ph : (t0 >> 7) + wn;
     const float* emb_b = (p.flags & TQ_CONV_EMB) ? p.emb + (size_t)b * p.emb_stride : nullptr;
     // The two 16-channel blocks of a wave are the two 64-byte halves of one 128-byte output line: they are stored back to back
     // (t-block outer, channel block inner).  With the channel block as the outer loop the halves reached L2 microseconds apart
@@ -664,7 +670,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
     float s1[2][4], s2[2][4];
 #pragma unroll
     for (int cbk = 0; cbk < 2; ++cbk) {
-        const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+        const int co = co_real + cbk * 16 + 4 * (lane >> 4);
         add[cbk] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) add[cbk] = *reinterpret_cast<const float4*>(p.bias + co);
         if (emb_b) {
@@ -684,8 +690,8 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
         if (t < p.T_out) {
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk) {
-                const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
-                const size_t o = ((size_t)b * p.T_out + t) * p.C_out + co;
+                const int co = co_real + cbk * 16 + 4 * (lane >> 4);
+                const size_t o = poly ? ((size_t)b * 2 * p.T_out + 2 * t + ph) * Cr + co : ((size_t)b * p.T_out + t) * p.C_out + co;
                 float4 v = make_float4(acc[cbk][tb][0] + add[cbk].x, acc[cbk][tb][1] + add[cbk].y,
                                        acc[cbk][tb][2] + add[cbk].z, acc[cbk][tb][3] + add[cbk].w);
                 if (p.flags & TQ_CONV_RES) {
@@ -704,7 +710,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
     if (p.flags & TQ_CONV_STATS) {
 #pragma unroll
         for (int cbk = 0; cbk < 2; ++cbk) {
-            const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+            const int co = co_real + cbk * 16 + 4 * (lane >> 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -714,7 +720,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                 }
             }
             if ((lane & 15) == 0 && slot < p.nslots) {
-                float* st = p.stats + (((size_t)b * p.nslots + slot) * p.C_out + co) * 2;
+                float* st = p.stats + (((size_t)b * p.nslots + slot) * Cr + co) * 2;
                 *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
                 *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
             }
@@ -956,6 +962,11 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     const int tile = tq_conv_tile_co(d->C_out);
     a.ncob_pad = ((d->C_out + tile - 1) / tile) * tile / 16;
     a.nslots = (d->T_out + STAT_SLOT - 1) / STAT_SLOT;
+    if (d->flags & TQ_CONV_POLY2) {
+        if (d->ktaps != 3 || d->stride != 1 || d->upsample || (d->C_out & 63) || kv_planes || d->C_skip0 || d->C_skip1) return TQ_ERR_SHAPE;
+        if ((d->flags & TQ_CONV_STATS) && d->T_out % STAT_SLOT) return TQ_ERR_SHAPE;
+        a.nslots *= 2;
+    }
     a.drop_site = d->dropout_site;
     a.drop_seed = d->dropout_seed;
     float pdrop = d->dropout_p;

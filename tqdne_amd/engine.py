@@ -114,6 +114,7 @@ class UNetEngine:
         self.ops: List[Tuple] = []          # launches of a forward whose backward may follow
         self.ops_infer: List[Tuple] = []    # same order and length; inference-only variants where they exist
         self.conv_sites: List[ConvSite] = []
+        self.poly_sites: List[Tuple[ConvSite, ConvSite]] = []   # (derived two-phase k = 3 site, the Upsample conv it restates)
         self.dropout_descs: List[TqConvDesc] = []
         self.acts: List[Act] = []
         self._probe = None
@@ -238,6 +239,9 @@ class UNetEngine:
                 _p(site.packed), _p(site.bias), emb_ptr, _p(res.buf) if res else None, _p(out.buf), _p(out.stats)),
                 "conv:" + site.name, flops)
             infer_op = None
+            if (upsample and site.K == 5 and T_in % STAT_SLOT == 0 and site.C_out % 32 == 0 and gn is None and res is None
+                    and emb_ptr is None and os.environ.get("TQDNE_POLYPHASE_UPSAMPLE", "1") != "0"):
+                infer_op = self._polyphase_op(site, d, s0, s1, out, flops)
             if qkv_planes is not None:  # (ws, H, D): K / V straight into the attention kernel's pre-split planes
                 ws, H_, D_ = qkv_planes
                 infer_op = (self.lib.tq_conv1d_fwd_qkv, (
@@ -246,6 +250,28 @@ class UNetEngine:
             self._emit(op, infer_op)
         self.last_rec = ConvRec(site, d, list(srcs), gn, out, stride, upsample, silu, dropout_site is not None)
         return out
+
+    def _polyphase_op(self, site: ConvSite, d: TqConvDesc, s0: Act, s1: Optional[Act], out: Act, flops: int):
+        """Inference form of Upsample (blocks.py:56-66: F.interpolate(nearest, x2), then conv k = 5): both output phases as ONE k = 3
+        conv over the un-upsampled rows (TQ_CONV_POLY2) -- even outputs use the taps (w0+w1, w2+w3, w4), odd ones (w0, w1+w2,
+        w3+w4): 3/5 of the multiply-adds, same result up to the fp32 rounding of the tap sums.  The training forward keeps the k = 5
+        launch its gradients are written for.  The two-phase weights are rebuilt by repack() with the packed fragments."""
+        Cr = site.C_out
+        w2 = torch.empty(2 * Cr, site.C_in, 3, device=self.dev)
+        ps = ConvSite(site.name + ":polyphase", w2, site.bias, self.dev, self.lib)
+        self.poly_sites.append((ps, site))
+        d2 = TqConvDesc()
+        d2.B, d2.T_in, d2.T_out = d.B, d.T_in, d.T_in
+        d2.C_in0, d2.C_in1, d2.C_out = d.C_in0, d.C_in1, 2 * Cr
+        d2.ktaps, d2.stride, d2.pad, d2.upsample = 3, 1, 1, 0
+        d2.flags = (d.flags & TQ_CONV_STATS) | _lib.TQ_CONV_POLY2
+        d2.emb_stride = 0
+        d2.wfmt = _lib.forward_wfmt(2 * Cr, [d.C_in0, d.C_in1])
+        ps.pack_mode = 2 if d2.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+        self._keep.append(d2)
+        return (self.lib.tq_conv1d_fwd, (
+            C.byref(d2), _p(s0.buf), _p(s1.buf) if s1 else None, None, None, _p(ps.packed), _p(site.bias), None, None,
+            _p(out.buf), _p(out.stats)), "conv:" + site.name + "+polyphase", flops)
 
     # ------------------------------------------------------------------ graph construction
     def _build(self):
@@ -413,6 +439,17 @@ class UNetEngine:
         for s in self.conv_sites:
             check(lib.tq_pack_conv_weight(s.weight.data_ptr(), s.C_out, s.C_in, s.K, s.pack_mode, s.packed.data_ptr(), stream),
                   "pack " + s.name)
+        with torch.no_grad():
+            for ps, src in self.poly_sites:  # two-phase k = 3 restatement of the upsampling convs (see _polyphase_op)
+                w, Cr = src.weight, src.C_out
+                ps.weight[:Cr, :, 0] = w[:, :, 0] + w[:, :, 1]
+                ps.weight[:Cr, :, 1] = w[:, :, 2] + w[:, :, 3]
+                ps.weight[:Cr, :, 2] = w[:, :, 4]
+                ps.weight[Cr:, :, 0] = w[:, :, 0]
+                ps.weight[Cr:, :, 1] = w[:, :, 1] + w[:, :, 2]
+                ps.weight[Cr:, :, 2] = w[:, :, 3] + w[:, :, 4]
+                check(lib.tq_pack_conv_weight(ps.weight.data_ptr(), ps.C_out, ps.C_in, 3, ps.pack_mode, ps.packed.data_ptr(), stream),
+                      "pack " + ps.name)
         with torch.no_grad():
             for rb in self.res_blocks:
                 if hasattr(rb, "emb_layers"):
