@@ -325,7 +325,7 @@ def main():
             "metric": "waveforms/sec (train step + 18-step EDM sample), 3ch x 4096",
             "value": value, "unit": "waveforms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (contractions on MFMA with fp32 accumulate: bf16x3, and fp16 + block-scaled-fp8 corrections on the non-fused 128/256-channel forward convs; sampler state f64)", "data": "synthetic",
+            "dtype": "f32 (contractions on MFMA with fp32 accumulate: bf16x3, and fp16 + block-scaled-fp8 corrections on the 128/256-channel forward convs; sampler state f64)", "data": "synthetic",
             "config": {"workload": f"{args.config} 1-D EDM UNet ({sum(p.numel() for p in edm.unet.parameters())} params), "
                                    f"B={B}/GPU, 3x{T}: 1 train step (dropout 0.1, Adam, cosine LR) + {args.sample_steps}-step "
                                    f"Heun sample ({nfe} NFE)", "global_batch": world * B, "parallelism": f"dp{world}",

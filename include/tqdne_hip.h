@@ -48,7 +48,8 @@ typedef struct ihipStream_t* hipStream_t;
  * BF16X3: both operands split into bf16 hi + lo, three bf16 MFMA products; fp32 range, ~2^-16 relative (pack modes 0 / 1).
  * F16_MX8: per 64 channels two fp16 MFMAs plus one block-scaled fp8 MFMA carrying both first-order corrections; ~2^-15 relative at
  * 2/3 of the MFMA cycles; the activation operand has fp16 RANGE (|x| > 65504 overflows to inf / NaN in the output, relative precision lost below 6e-5).  Built
- * for stride-1 forward launches with 128 | C_out and 64 | every source's channels (pack mode 2). */
+ * for stride-1 forward launches (tq_conv1d_fwd, tq_conv1d_fwd_skip, tq_conv1d_fwd_qkv) with 128 | C_out and 64 | every source's
+ * channels (pack mode 2). */
 #define TQ_WFMT_BF16X3 0
 #define TQ_WFMT_F16_MX8 1
 
