@@ -281,7 +281,7 @@ def main():
     if rank == 0:
         flops_fwd = conv_flops_per_sample(edm.unet, T)
         k_ms, k_flops, k_name, k_n = probe.result()
-        mx8 = os.environ.get("TQDNE_CONV_SCHEME", "f16mx8").lower() == "f16mx8" and "+skip" not in k_name
+        mx8 = os.environ.get("TQDNE_CONV_SCHEME", "f16mx8").lower() == "f16mx8"
         roofline = dict(bound="mfma", achieved=(k_flops / (k_ms * 1e-3) / 1e12) if k_ms else None,
                         peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
                         kernel=k_name, launches_timed=k_n, avg_launch_ms=k_ms, algorithmic_flop_per_launch=k_flops,
@@ -337,7 +337,7 @@ def main():
         }
         if args.no_train or args.no_sample:
             out["metric"] += " [DEBUG: partial workload, not the headline metric]"
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (a reported baseline of the same workload: rank 0 at N = 1 only)
             log("timing the CPU oracle (bounded sample, subprocess) ...")
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, T, args.sample_steps, 99)
         print(json.dumps(out), flush=True)
