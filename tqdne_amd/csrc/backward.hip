@@ -417,10 +417,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
     const int c4 = threadIdx.x % c4n, tr = threadIdx.x / c4n;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tr < nrow && threadIdx.x < nrow * c4n) {
-        for (int tl = tr; tl < STAT_SLOT; tl += nrow) {
-            const int t = slot * STAT_SLOT + tl;
-            if (t >= T) break;
-            const float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)b * T + t) * C + 4 * c4);
+        const int nvalid = min(STAT_SLOT, T - slot * STAT_SLOT);
+        const float* src = dy + ((size_t)b * T + slot * STAT_SLOT) * C + 4 * c4;
+        int tl = tr;
+        // 8 rows in flight per thread (a dependent load-add chain over up to 128 rows ran at 2 TB/s)
+        for (; tl + 7 * nrow < nvalid; tl += 8 * nrow) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(src + (size_t)(tl + q * nrow) * C);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+        }
+        for (; tl < nvalid; tl += nrow) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)tl * C);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         *reinterpret_cast<float4*>(red + (tr * c4n + c4) * 4) = a;
