@@ -405,6 +405,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
                               (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
             const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
+            // Issue order: the four short fp16 MFMAs first (dependent ones two apart), the two long block-scaled ones last.  With
+            // the scaled MFMA first, the second accumulator's fp16 MFMA had to wait for it (16 passes against 4 of cover).
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 0].u), b0v, acc[cbk][tb], 0, 0, 0);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 1].u), b1v, acc[cbk][tb], 0, 0, 0);
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk) {
                 const Frag& c0 = w[cbk * 4 + 2];
@@ -412,8 +420,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                 const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
                 // E8M0 scales: A 127 (2^0), B 115 (2^-12) on every lane: both correction products carry 2^-12
                 acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 0, 0, 0, 127, 0, 115);
-                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 0].u), b0v, acc[cbk][tb], 0, 0, 0);
-                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 1].u), b1v, acc[cbk][tb], 0, 0, 0);
             }
         }
     };
