@@ -264,7 +264,9 @@ class LightningEDM(LightningModule):
             run = self._heun_lane(eps, sigmas, cond_sample, cond, use_graph)
             for _ in run:
                 pass
-            return run.result.clone()
+            res = run.result.clone()
+            run.release()
+            return res
         dev = eps.device
         h = B // lanes
         cut = lambda t, i: None if t is None else t[i * h:(i + 1) * h].contiguous()
@@ -293,6 +295,8 @@ class LightningEDM(LightningModule):
                 out[i * h:(i + 1) * h].copy_(runs[i].result)
             main.wait_stream(st)
         out[:h].copy_(runs[0].result)
+        for r in runs:
+            r.release()
         return out
 
     def _side_stream(self, dev, i=1):
@@ -317,12 +321,14 @@ class LightningEDM(LightningModule):
         edm = self
 
         class _Run:
-            def __init__(r):
+            def __init__(r, start):
+                # (``start`` is an argument, not a closure variable: a class object sits in reference cycles of its own, and a
+                # cell holding a view of the caller's start state would keep that whole allocation alive until a cyclic GC pass)
                 r.x, r.xn, r.d, r.x32 = bufs["x"], bufs["xn"], bufs["d"], bufs["x32"]
-                r.x.copy_(eps)
-                r.x32.copy_(eps)  # fp64 -> fp32 rounding, as sample_curr.to(self.dtype)
+                r.x.copy_(start)
+                r.x32.copy_(start)  # fp64 -> fp32 rounding, as sample_curr.to(self.dtype)
                 r.i, r.nsteps = 0, sigmas.numel() - 1
-                r.keep = (sigmas, cond, cond_sample, eps)
+                r.keep = (sigmas, cond, cond_sample)
                 if use_graph:
                     r.denoise = edm._graph_denoiser(bufs, r.x32, cond, cond_sample)
                 else:
@@ -355,7 +361,14 @@ class LightningEDM(LightningModule):
                     r.advance()
                     yield r.i
 
-        return _Run()
+            def release(r):
+                """drop the references that tie this object into a cycle (closure <-> instance): the start state and the
+                conditioning tensors would otherwise stay allocated until Python's cyclic collector gets round to it"""
+                r.keep = r.denoise = None
+
+        run = _Run(eps)
+        del eps
+        return run
 
     def _graph_denoiser(self, bufs, x32, cond, cond_sample=None):
         """One preconditioned UNet evaluation (~160 launches) captured once in a HIP graph and replayed per NFE; sigma is fed
