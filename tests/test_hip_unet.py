@@ -570,9 +570,10 @@ def test_sampler_does_not_retain_start_state():
     import gc
     from tqdne_amd import LightningEDM, tiny_1d_unet_config
     torch.manual_seed(0)
-    edm = LightningEDM(tiny_1d_unet_config(), {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0}, num_sampling_steps=3)
+    cfg = tiny_1d_unet_config()
+    edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0}, num_sampling_steps=3)
     edm = edm.to(dev()).eval()
-    cond = torch.randn(32, 5, device=dev())
+    cond = torch.randn(32, cfg["cond_features"], device=dev()) if cfg["cond_features"] else None
     gc.collect()
     gc.disable()
     try:
@@ -582,6 +583,7 @@ def test_sampler_does_not_retain_start_state():
             torch.cuda.synchronize()
             used.append(torch.cuda.memory_allocated())
         assert torch.isfinite(x).all()
-        assert used[-1] == used[1], used
+        # (a 512-byte schedule tensor per call may wait for the collector; a start state is 786 KB)
+        assert used[-1] - used[1] < 100_000, used
     finally:
         gc.enable()
