@@ -88,9 +88,10 @@ def conv_flops_per_sample(unet, T):
     return total
 
 
-def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads):
+def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads, reps):
     """Runs in a child process: time the CPU oracle (oracle/ = our PyTorch-CPU restatement, a "port") on a bounded
-    sample of the same workload: one full train step (fwd + bwd + Adam) and one 18-step sample at batch B."""
+    sample of the same workload: full train steps (fwd + bwd + Adam) and 18-step samples at batch B; one untimed warm-up of
+    each half (a train step and a 2-step sample), then ``reps`` timed repetitions, printed one JSON line each."""
     import torch
     from oracle import edm as OE
     from tqdne_amd import UNetModel, paper_1d_unet_config, tiny_1d_unet_config
@@ -106,18 +107,28 @@ def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads):
     opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=1e-4)
     p = OE.EDMParams()
     net = OE.make_net(params, cfg)
-    t0 = time.perf_counter()
-    opt.zero_grad()
-    loss = OE.loss_step(p, net, sig, torch.randn(B, generator=g), torch.randn(B, 3, T, generator=g), cond=cond)
-    loss.backward()
-    opt.step()
-    t_train = time.perf_counter() - t0
-    print(json.dumps(dict(stage="train", t_train=t_train)), flush=True)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        OE.sample_deterministic(p, net, torch.randn(B, 3, T, generator=g, dtype=torch.float64), nsample_steps, cond=cond)
-    t_sample = time.perf_counter() - t0
-    print(json.dumps(dict(stage="done", t_train=t_train, t_sample=t_sample)), flush=True)
+
+    def train():
+        opt.zero_grad()
+        loss = OE.loss_step(p, net, sig, torch.randn(B, generator=g), torch.randn(B, 3, T, generator=g), cond=cond)
+        loss.backward()
+        opt.step()
+
+    def sample(n):
+        with torch.no_grad():
+            OE.sample_deterministic(p, net, torch.randn(B, 3, T, generator=g, dtype=torch.float64), n, cond=cond)
+
+    train()
+    sample(2)
+    print(json.dumps(dict(stage="warm")), flush=True)
+    for r in range(reps):
+        t0 = time.perf_counter()
+        train()
+        t_train = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sample(nsample_steps)
+        t_sample = time.perf_counter() - t0
+        print(json.dumps(dict(stage="rep", rep=r, t_train=t_train, t_sample=t_sample)), flush=True)
 
 
 def _cpu_model():
@@ -130,40 +141,121 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=240):
-    """Launch the worker with a hard timeout (a slow or oversubscribed host must not stall the bench)."""
+def _cpu_run(cfg_name, B, T, nsample_steps, seed, nthreads, reps, timeout_s):
     import subprocess
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
+            f"bench._cpu_baseline_worker({cfg_name!r}, {B}, {T}, {nsample_steps}, {seed}, {nthreads}, {reps})")
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(nthreads))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=timeout_s, env=env, cwd=ROOT)
+        out = r.stdout
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    reps_done = [json.loads(l) for l in out.splitlines() if l.startswith("{") and '"rep"' in l]
+    return reps_done
+
+
+def _median(v):
+    v = sorted(v)
+    n = len(v)
+    return None if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
+
+
+def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=150):
+    """The CPU oracle on the host cores of this box: all cores (<= 64 threads), warm-up + median of 3
+    repetitions of the same workload at batch B, and a 1-thread line at batch 1 (one repetition after the warm-up; a
+    1-thread step of the paper UNet takes ~10 s per waveform).  Each leg runs in a subprocess with a hard timeout."""
     try:
         ncores = len(os.sched_getaffinity(0))
     except Exception:
         ncores = os.cpu_count() or 1
     nthreads = max(1, min(ncores, 64))
-    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
-            f"bench._cpu_baseline_worker({cfg_name!r}, {B}, {T}, {nsample_steps}, {seed}, {nthreads})")
-    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(nthreads))
-    t_train = t_sample = None
-    try:
-        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                           timeout=timeout_s, env=env, cwd=ROOT)
-        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    except subprocess.TimeoutExpired as e:
-        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-        lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
-    for l in lines:
-        t_train = l.get("t_train", t_train)
-        t_sample = l.get("t_sample", t_sample)
-    res = dict(value=None, unit="waveforms/s", cores=nthreads, kind="port", train_s=t_train, sample_s=t_sample,
-               sample=f"{cfg_name} UNet, B={B}, 3x{T}: 1 train step + 1 x {nsample_steps}-step sample, torch {torch.__version__} CPU, "
-                      f"{nthreads} threads ({ncores} cores visible, {_cpu_model()})")
-    if t_train is not None and t_sample is not None:
+    reps = _cpu_run(cfg_name, B, T, nsample_steps, seed, nthreads, 3, timeout_s)
+    t_train, t_sample = _median([r["t_train"] for r in reps]), _median([r["t_sample"] for r in reps])
+    res = dict(value=None, unit="waveforms/s", cores=nthreads, kind="port", train_s=t_train, sample_s=t_sample, reps=len(reps),
+               sample=f"{cfg_name} UNet, B={B}, 3x{T}: warm-up, then median of {len(reps)} x (1 train step + 1 x {nsample_steps}-step "
+                      f"sample), torch {torch.__version__} CPU, {nthreads} threads ({ncores} cores visible, {_cpu_model()})")
+    if t_train is not None:
         res["value"] = B / (t_train + t_sample)
     else:
         res["sample"] += f" -- did not finish within {timeout_s} s"
+    one = _cpu_run(cfg_name, 1, T, nsample_steps, seed, 1, 1, timeout_s)
+    if one:
+        res["one_thread"] = dict(value=1.0 / (one[0]["t_train"] + one[0]["t_sample"]), unit="waveforms/s", cores=1,
+                                 train_s=one[0]["t_train"], sample_s=one[0]["t_sample"],
+                                 sample=f"same workload at B=1, 1 thread, 1 repetition after a warm-up")
+    else:
+        res["one_thread"] = dict(value=None, sample=f"B=1, 1 thread: did not finish within {timeout_s} s")
     return res
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` outside a launcher: start N ranks (one per GPU) as a child ``torch.distributed.run`` and exit
+    with its code.  Decided before anything in this process touches the GPU (nothing is exec'ed; this process only waits)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log("launching", n, "ranks:", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def op_class(name):
+    """kernel class of a plan launch, by its name (DESIGN.md section 5's table)"""
+    if name.startswith("conv:"):
+        if name.endswith("+skip"):
+            return "resblock k5 conv + fused 1x1 skip"
+        if ".qkv" in name or ".proj_out" in name:
+            return "attention qkv / proj 1x1 convs"
+        if name.endswith(".op") or name.endswith(".conv") or name.endswith("+polyphase"):
+            return "down / up-sampling convs"
+        return "resblock k5 convs"
+    if name.startswith("attention"):
+        return "attention core"
+    if name.startswith("gn_"):
+        return "GroupNorm finalise / backward"
+    if name in ("embed", "stem", "head"):
+        return "embedding + stem / head"
+    for pfx, cls in (("wgrad:", "conv weight gradients"), ("dgrad:", "conv data gradients"), ("colsum", "bias / embedding column sums")):
+        if name.startswith(pfx):
+            return cls
+    return "other (" + name.split(":")[0] + ")"
+
+
+def class_table(trace, peak_tflops, peak_gbs):
+    """per-class sums of a traced pass: time from HIP events around every launch on the launch stream"""
+    torch.cuda.synchronize()
+    rows = {}
+    for name, flops, nbytes, e0, e1 in trace:
+        r = rows.setdefault(op_class(name), dict(launches=0, ms=0.0, gflop=0.0, mbytes=0.0))
+        r["launches"] += 1
+        r["ms"] += e0.elapsed_time(e1)
+        r["gflop"] += flops / 1e9
+        r["mbytes"] += nbytes / 1e6
+    total = sum(r["ms"] for r in rows.values())
+    for r in rows.values():
+        r["share"] = r["ms"] / total if total else None
+        r["mfma_frac"] = (r["gflop"] / r["ms"] / peak_tflops) if r["ms"] and r["gflop"] else None   # GFLOP/ms = TFLOP/s
+        r["hbm_frac"] = (r["mbytes"] / r["ms"] / peak_gbs) if r["ms"] and r["mbytes"] else None      # MB/ms = GB/s
+        for k in ("ms", "gflop", "mbytes"):
+            r[k] = round(r[k], 4)
+    return dict(total_ms=total, classes=rows)
 
 
 def main():
@@ -175,44 +267,64 @@ def main():
     ap.add_argument("--length", type=int, default=4096)
     ap.add_argument("--sample-steps", type=int, default=18)
     ap.add_argument("--config", default="paper", choices=["paper", "tiny"])
-    ap.add_argument("--no-train", action="store_true", help="debug: time the sampler only (NOT the headline metric)")
-    ap.add_argument("--no-sample", action="store_true", help="debug: time the train step only (NOT the headline metric)")
+    ap.add_argument("--mode", default="step", choices=["step", "train", "sample", "consistency"],
+                    help="step (headline): 1 train step + one 18-step sample; train / sample: one half only (debug); "
+                         "consistency: BASELINE configs[4], 1-step consistency sampling, rank-sharded, no collective")
+    ap.add_argument("--no-train", action="store_true", help="= --mode sample")
+    ap.add_argument("--no-sample", action="store_true", help="= --mode train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tables", action="store_true", help="skip the per-class traced passes after the timed region")
+    ap.add_argument("--no-overlap", action="store_true", help="issue the gradient all-reduce after the backward instead of under it")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true", help="replay the UNet forward of the sampler from a HIP graph (neutral at B=64: GPU-bound)")
     args = ap.parse_args()
+    if args.no_train:
+        args.mode = "sample"
+    if args.no_sample:
+        args.mode = "train"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    import datetime
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(minutes=10))
 
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from tqdne_amd import LightningEDM, paper_1d_unet_config, tiny_1d_unet_config
+    from tqdne_amd import LightningEDM, paper_1d_unet_config, rng, tiny_1d_unet_config
     from tqdne_amd.trainer import DataParallelTrainer
     from tqdne_amd.edm import sampler_lanes
 
     cfg = paper_1d_unet_config() if args.config == "paper" else tiny_1d_unet_config()
     B, T = args.batch, args.length
-    torch.manual_seed(0)
+    do_train = args.mode in ("step", "train")
+    do_sample = args.mode in ("step", "sample")
+    torch.manual_seed(args.seed)  # identical initial weights on every rank (and a rank-0 broadcast in the trainer on top)
     edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 100000, "eta_min": 0.0}, num_sampling_steps=args.sample_steps)
     sd = perturbed_state(edm.unet, 17)
     edm.unet.load_state_dict(sd)
     edm = edm.to(dev)
+    cm = None
+    if args.mode == "consistency":
+        from tqdne_amd.consistency_model import LithningConsistencyModel
+        cm = LithningConsistencyModel(edm.unet).to(dev).eval()
 
+    # every rank: its own shard of synthetic data and its own random streams (noise levels, noise, dropout masks, sampler seeds)
+    rng.seed_rank(args.seed, rank)
     g = torch.Generator().manual_seed(1234 + rank)
     signal = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev)
     cond = torch.randn(B, 5, generator=g).to(dev) if cfg["cond_features"] else None
@@ -221,22 +333,32 @@ def main():
         batch["cond"] = cond
     start_noise = torch.randn(B, 3, T, generator=g, dtype=torch.float64).to(dev)
 
-    trainer = DataParallelTrainer(edm, world_size=world) if not args.no_train else None
+    trainer = DataParallelTrainer(edm, world_size=world, overlap=not args.no_overlap) if do_train else None
     sigmas = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
     eps0 = start_noise * sigmas[0]
+    eps32 = start_noise.float()
     use_graph = args.graph
 
     # HIP-event probe around the dominant kernel (the heaviest k=5 conv launch of the forward)
     eng = edm.unet._engine(B, T, dev)
     probe = eng.install_probe()
 
+    def train_half():
+        edm.train()
+        trainer.train_step(batch)
+
+    def sample_half():
+        edm.eval()
+        edm.sample_deterministically(eps0, sigmas, None, cond, use_graph=use_graph)
+
     def one_step():
-        if trainer is not None:
-            edm.train()
-            trainer.train_step(batch)
-        if not args.no_sample:
-            edm.eval()
-            edm.sample_deterministically(eps0, sigmas, None, cond, use_graph=use_graph)
+        if cm is not None:
+            cm.sample_from(eps32, [], [], None, cond)
+            return
+        if do_train:
+            train_half()
+        if do_sample:
+            sample_half()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -250,11 +372,15 @@ def main():
     sync()
     log("warmup done; timing", args.steps, "steps")
     probe.reset()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         one_step()
+        marks[k + 1].record()   # (on the main stream, which every sampler lane / the exchange joins at the end of a step)
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -263,20 +389,41 @@ def main():
     log(f"timed region done: {ms_per_step:.1f} ms/step")
     value = world * B / (dt / args.steps)
 
-    # separate timings of the two halves (reported, not the headline)
+    # separate timings of the two halves (reported, not the headline): median of 5 after one untimed call
     parts = {}
-    if rank == 0 or world > 1:
-        for name, fn in (("train", (lambda: (edm.train(), trainer.train_step(batch))) if trainer else None),
-                         ("sample", (lambda: (edm.eval(), edm.sample_deterministically(eps0, sigmas, None, cond, use_graph=use_graph)))
-                          if not args.no_sample else None)):
-            if fn is None:
-                continue
-            fn(); sync()
+    for name, fn in (("train", train_half if do_train else None), ("sample", sample_half if do_sample else None)):
+        if fn is None or cm is not None:
+            continue
+        fn(); sync()
+        ts = []
+        for _ in range(5):
             t1 = time.perf_counter()
-            for _ in range(2):
-                fn()
+            fn()
             sync()
-            parts[name + "_ms"] = 1e3 * (time.perf_counter() - t1) / 2
+            ts.append(1e3 * (time.perf_counter() - t1))
+        parts[name + "_ms"] = _median(ts)
+
+    tables = None
+    if rank == 0 and not args.no_tables and cm is None:
+        # per-class tables: one extra forward / train step with HIP events around EVERY launch (one lane, eager, outside the
+        # timed region; the sampler's lanes overlap each other, so the inference pass is traced on a single B-sample lane)
+        tables = {}
+        eng._trace = []
+        edm.eval()
+        with torch.no_grad():
+            edm(signal, torch.full((B,), 0.7, device=dev), None, cond)
+        tables["inference_forward_1lane"] = class_table(eng._trace, MFMA_BF16_DENSE_PEAK_TFLOPS, HBM_PEAK_GBS)
+        eng._trace = None
+        if do_train:
+            edm.train()
+            edm.step_and_backward(batch)   # makes sure the backward plan exists
+            eng._trace, eng._bwd._trace = [], []
+            edm.step_and_backward(batch)
+            tables["train_forward"] = class_table(eng._trace, MFMA_BF16_DENSE_PEAK_TFLOPS, HBM_PEAK_GBS)
+            tables["train_backward"] = class_table(eng._bwd._trace, MFMA_BF16_DENSE_PEAK_TFLOPS, HBM_PEAK_GBS)
+            eng._trace = eng._bwd._trace = None
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         flops_fwd = conv_flops_per_sample(edm.unet, T)
@@ -294,19 +441,27 @@ def main():
         if roofline["achieved"]:
             roofline["frac"] = roofline["achieved"] / roofline["peak"]
         # HBM traffic of the same launch from PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
-        # separate rocprofv3 --pmc passes by tools/pmc_dominant.sh; bench.py cannot read PMCs itself
+        # separate rocprofv3 --pmc passes by tools/pmc_dominant.sh; bench.py cannot read PMCs itself.  A PMC file recorded for
+        # an older build of the conv kernel is refused (the kernel source's hash is stored in the file).
         import glob
+        import hashlib
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_dominant_conv.json")))
+        src_hash = hashlib.sha256(open(os.path.join(ROOT, "tqdne_amd", "csrc", "conv1d_mfma.hip"), "rb").read()).hexdigest()[:16]
         if pmc and args.config == "paper" and B == 64 and T == 4096:
             try:
                 pj = json.load(open(pmc[-1]))
-                roofline["traffic"] = pj.get("hbm_traffic_bytes_per_launch")
-                roofline["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
-                roofline["algorithmic_bytes_per_launch"] = pj.get("algorithmic_bytes_per_launch")
+                if pj.get("conv1d_mfma_sha16") == src_hash:
+                    roofline["traffic"] = pj.get("hbm_traffic_bytes_per_launch")
+                    roofline["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
+                    roofline["algorithmic_bytes_per_launch"] = pj.get("algorithmic_bytes_per_launch")
+                else:
+                    roofline["traffic_source"] = (os.path.relpath(pmc[-1], ROOT) + " is stale (recorded for another build of "
+                                                  "conv1d_mfma.hip): traffic not reported")
             except Exception:
                 pass
         nfe = 2 * args.sample_steps - 1
-        work_flop = B * flops_fwd * ((3 if trainer else 0) + (nfe if not args.no_sample else 0))
+        n_fwd = (3 if do_train else 0) + (nfe if do_sample else 0) if cm is None else 1
+        work_flop = B * flops_fwd * n_fwd
         # the north star's second fraction: fused-minimum HBM bytes of the whole step over the 8 TB/s roof.
         # Per sample and forward every conv / attention core reads its input and writes its output once in fp32 (A), weights W
         # once per call: forward = B*A + W, sample = NFE * forward, train = 3*B*A + 3*W + 7*W (Adam).  A from hooks over the
@@ -315,33 +470,55 @@ def main():
         hbm_step = None
         if A_W and T == 4096:
             A_, W_ = A_W
-            algo_bytes = world * (((3 * B * A_ + 10 * W_) if trainer else 0) + ((nfe * (B * A_ + W_)) if not args.no_sample else 0))
+            if cm is not None:
+                algo_bytes = world * (B * A_ + W_)
+            else:
+                algo_bytes = world * (((3 * B * A_ + 10 * W_) if do_train else 0) + ((nfe * (B * A_ + W_)) if do_sample else 0))
             gbps = algo_bytes / (dt / args.steps) / 1e9
             hbm_step = dict(bound="hbm", achieved=gbps, peak=8000.0 * world, unit="GB/s", frac=gbps / (8000.0 * world),
                             algorithmic_bytes_per_step=algo_bytes,
                             note="whole step, fused-minimum byte model of SURVEY.md 8d; the step is MFMA-bound (see roofline), "
                                  "this is the fraction the north star asks to be reported")
+        if cm is not None:
+            metric = "waveforms/sec (consistency 1-step sample), 3ch x 4096"
+            workload = (f"{args.config} 1-D UNet under the consistency forward ({sum(p.numel() for p in edm.unet.parameters())} params), "
+                        f"B={B}/GPU, 3x{T}: sample(shape, sigmas=[]) = 1 NFE; ranks sample their own seeds, no collective")
+        else:
+            metric = "waveforms/sec (train step + 18-step EDM sample), 3ch x 4096"
+            workload = (f"{args.config} 1-D EDM UNet ({sum(p.numel() for p in edm.unet.parameters())} params), "
+                        f"B={B}/GPU, 3x{T}: " + " + ".join(
+                            (["1 train step (dropout 0.1, Adam, cosine LR"
+                              + (", gradient all-reduce " + ("under" if not args.no_overlap else "after") + " the backward" if world > 1 else "") + ")"]
+                             if do_train else [])
+                            + ([f"{args.sample_steps}-step Heun sample ({nfe} NFE)"] if do_sample else [])))
         out = {
-            "metric": "waveforms/sec (train step + 18-step EDM sample), 3ch x 4096",
+            "metric": metric,
             "value": value, "unit": "waveforms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_median": _median(per_step), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
             "dtype": "f32 (contractions on MFMA with fp32 accumulate: bf16x3, and fp16 + block-scaled-fp8 corrections on the 128/256-channel forward convs; sampler state f64)", "data": "synthetic",
-            "config": {"workload": f"{args.config} 1-D EDM UNet ({sum(p.numel() for p in edm.unet.parameters())} params), "
-                                   f"B={B}/GPU, 3x{T}: 1 train step (dropout 0.1, Adam, cosine LR) + {args.sample_steps}-step "
-                                   f"Heun sample ({nfe} NFE)", "global_batch": world * B, "parallelism": f"dp{world}",
-                       "hip_graph": use_graph, "sampler_lanes": 1 if use_graph else sampler_lanes(B)},
+            "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}",
+                       "hip_graph": use_graph, "sampler_lanes": 1 if use_graph else sampler_lanes(B), "mode": args.mode},
             "parts": parts,
             "whole_step_algorithmic_tflops": work_flop / (dt / args.steps) / 1e12,
+            "whole_step_mfma_frac": work_flop / (dt / args.steps) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
             "roofline": roofline,
             "hbm_roofline_whole_step": hbm_step,
         }
-        if args.no_train or args.no_sample:
+        if "sample_ms" in parts:
+            out["whole_forward_mfma_frac"] = B * flops_fwd * nfe / (parts["sample_ms"] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS
+        if "train_ms" in parts:
+            out["train_mfma_frac"] = B * flops_fwd * 3 / (parts["train_ms"] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS
+        if tables is not None:
+            out["kernel_classes"] = tables
+        if args.mode in ("train", "sample"):
             out["metric"] += " [DEBUG: partial workload, not the headline metric]"
-        if not args.no_cpu_baseline and world == 1:  # (a reported baseline of the same workload: rank 0 at N = 1 only)
+        if not args.no_cpu_baseline and world == 1 and cm is None:  # (a reported baseline of the same workload: rank 0 at N = 1 only)
             log("timing the CPU oracle (bounded sample, subprocess) ...")
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, T, args.sample_steps, 99)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -95,3 +95,21 @@ def test_hip_module_from_checkpoint_matches_reference_output():
         with torch.no_grad():
             y = m(e["x"].to(dev), e["sigma"].to(dev), cond=e["cond"].to(dev))
         assert rel_err(y.cpu(), e[key]) < 1e-3
+
+
+def test_checkpoint_with_a_foreign_global_is_refused(tmp_path):
+    """a .ckpt is a pickle: anything outside the allow-list (here os.system) must not be resolved, let alone called"""
+    import pickle
+
+    from tqdne_amd.checkpoint import load_checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+
+    path = tmp_path / "evil.ckpt"
+    torch.save({"state_dict": {}, "hyper_parameters": {"x": Evil()}}, path)
+    with pytest.raises(pickle.UnpicklingError, match="allow-list"):
+        load_checkpoint(path)
+    assert not (tmp_path / "pwned").exists()

@@ -1,0 +1,99 @@
+"""Data-parallel training on the real model and kernels (8e): N ranks on a fixed global batch
+give the one-rank full-batch gradients, with the exchange overlapped with the backward sweep or issued after it.
+Two ranks: RCCL ("nccl") when the box has >= 2 GPUs, otherwise both ranks share cuda:0 and exchange over gloo (host staged by
+the test worker).  Also: the backward plan's bucket callbacks tile the gradient buffer and fire only once a bucket is final."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, cfg_of, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gradients_equal_full_batch_gradients():
+    world = 2
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TQ_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=500)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-4000:]}"
+    line = [l for l in outs[0].splitlines() if l.startswith("DDP_RESULT ")][-1]
+    res = json.loads(line[len("DDP_RESULT "):])
+    print(backend, res)
+    for mode in ("overlap", "after"):
+        r = res[mode]
+        assert r["err_flat"] < 1e-5 and r["err_worst_tensor"] < 1e-4, (mode, r)
+        assert r["replicas_equal"], mode
+        assert abs(r["loss_mean"] - r["loss_full"]) < 1e-5 * abs(r["loss_full"]), (mode, r)
+    assert len(res["overlap"]["buckets"]) >= 3  # 64 KB buckets: the micro net's gradients leave in several pieces
+    assert len(res["after"]["buckets"]) >= 1
+
+
+def test_bucket_callbacks_tile_the_buffer_and_fire_when_final():
+    from tqdne_amd import LightningEDM, rng
+    sd, d = load_golden("micro_unet.npz")
+    cfg = cfg_of(d)
+    dev = torch.device("cuda:0")
+    edm = LightningEDM(cfg, {"learning_rate": 1e-3, "max_steps": 10, "eta_min": 0.0})
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev).train()
+    g = torch.Generator().manual_seed(2)
+    batch = {"signal": (0.5 * torch.randn(2, 3, 256, generator=g)).to(dev), "cond": torch.randn(2, 5, generator=g).to(dev)}
+    snaps = []
+
+    def hook(sl):
+        # a copy enqueued right behind the finalising launch: any later write to the slice would make it differ from the end state
+        snaps.append((sl.data_ptr(), sl.numel(), sl.clone()))
+
+    rng.seed_rank(5, 0)
+    loss, flat = edm.step_and_backward(batch, on_bucket=hook, bucket_elems=8192)
+    torch.cuda.synchronize()
+    bwd = edm.unet._engine(2, 256, dev)._bwd
+    assert len(snaps) >= 4
+    pos = flat.data_ptr()
+    for ptr, n, snap in snaps:  # contiguous, in order, covering [0, n_grad)
+        assert ptr == pos
+        off = (ptr - flat.data_ptr()) // 4
+        assert torch.equal(snap, flat[off:off + n]), "bucket was modified after its callback"
+        pos += 4 * n
+    assert (pos - flat.data_ptr()) // 4 == bwd.n_grad
+    # same gradients as the un-hooked run
+    ref = flat[:bwd.n_grad].clone()
+    rng.seed_rank(5, 0)
+    loss2, flat2 = edm.step_and_backward(batch)
+    torch.cuda.synchronize()
+    assert float(loss) == pytest.approx(float(loss2), rel=1e-6)
+    assert rel_err(flat2[:bwd.n_grad].cpu(), ref.cpu()) < 1e-5
+    # buckets of the output blocks' half leave before the sweep ends
+    fire, late = bwd._fire_points(8192)
+    assert len(fire) >= 3 and min(fire) < len(bwd.ops) // 2

@@ -61,3 +61,104 @@ def test_gloo_world2_gradient_allreduce_and_sharding():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DataParallelTrainer itself (not only its helpers), world size 2 over gloo: a stub module with the LightningEDM training surface
+# (configure_optimizers / optimizer_params / step_and_backward with the bucket hook) stands in for the HIP-backed module.
+
+
+class _StubEDM(torch.nn.Module):
+    """flat gradient buffer laid out in reverse parameter order; buckets released from inside the "backward" like BackwardPlan.run"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.SiLU(), torch.nn.Linear(32, 32), torch.nn.SiLU(),
+                                       torch.nn.Linear(32, 4))
+        self.optimizer_params = {"learning_rate": 1e-2, "max_steps": 20, "eta_min": 1e-4}
+        ps = list(self.parameters())[::-1]
+        self._offs, total = {}, 0
+        for p in ps:
+            self._offs[id(p)] = total
+            total += p.numel()
+        self.flat = torch.zeros(total)
+        self.release_order = None  # permutation of the bucket issue order (None: as completed)
+
+    def configure_optimizers(self):
+        opt = torch.optim.Adam(self.parameters(), lr=self.optimizer_params["learning_rate"])
+        sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=self.optimizer_params["max_steps"],
+                                                         eta_min=self.optimizer_params["eta_min"])
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sch, "interval": "step"}}
+
+    def step_and_backward(self, batch, on_bucket=None, bucket_elems=1 << 20):
+        loss = ((self.net(batch["signal"]) - batch["cond"]) ** 2).mean()
+        grads = torch.autograd.grad(loss, list(self.parameters()))
+        for p, g in zip(self.parameters(), grads):
+            o = self._offs[id(p)]
+            self.flat[o:o + p.numel()].copy_(g.reshape(-1))
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        if on_bucket is not None:
+            n = self.flat.numel()
+            cuts = [(i, min(i + bucket_elems, n)) for i in range(0, n, bucket_elems)]
+            for lo, hi in cuts:
+                on_bucket(self.flat[lo:hi])
+        return loss.detach(), self.flat
+
+
+def _trainer_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tqdne_amd.trainer import DataParallelTrainer, shard_batch
+
+    g = torch.Generator().manual_seed(3)
+    steps = [{"signal": torch.randn(8, 16, generator=g), "cond": torch.randn(8, 4, generator=g)} for _ in range(3)]
+
+    def run(world_size, **kw):
+        m = _StubEDM()
+        if world_size > 1 and rank != 0:  # replicas that start different must be overwritten by rank 0's broadcast
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(1.0)
+        tr = DataParallelTrainer(m, world_size=world_size, fused_optimizer=False, **kw)
+        sizes = []
+        for b in steps:
+            tr.train_step(shard_batch(b, rank, world_size) if world_size > 1 else b)
+            sizes.append(list(tr.last_bucket_sizes))
+        return torch.cat([p.detach().reshape(-1) for p in m.parameters()]), sizes
+
+    ref, _ = run(1)                                             # full batch, one rank, torch Adam + cosine LR
+    a, sizes_a = run(world, bucket_bytes=4 * 300, overlap=True)   # many small buckets, issued from inside the backward
+    b, sizes_b = run(world, bucket_bytes=4 * 300, overlap=False)  # same buckets, issued after the backward
+    c, sizes_c = run(world, bucket_bytes=1 << 20, overlap=True)   # one bucket
+    ok = (torch.allclose(a, ref, atol=1e-6) and torch.equal(a, b) and torch.allclose(c, ref, atol=1e-6)
+          and len(sizes_a[0]) > 3 and len(sizes_c[0]) == 1 and sum(sizes_a[0]) == sum(sizes_c[0]))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gloo_world2_trainer_matches_full_batch_training_for_any_bucketing():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_trainer_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))
+
+
+def test_rank_seeding_gives_distinct_reproducible_streams():
+    from tqdne_amd import rng
+    seeds = {}
+    for rank in (0, 1, 2):
+        rng.seed_rank(1234, rank)
+        draws = torch.randn(4)
+        s1, s2 = rng.next_dropout_seed(), rng.next_dropout_seed()
+        rng.seed_rank(1234, rank)
+        assert torch.equal(draws, torch.randn(4)) and (s1, s2) == (rng.next_dropout_seed(), rng.next_dropout_seed())
+        assert s1 != s2 and 0 <= s1 < 2 ** 64
+        seeds[rank] = (s1, s2, tuple(draws.tolist()))
+    assert len({v[0] for v in seeds.values()}) == 3 and len({v[2] for v in seeds.values()}) == 3
+    rng.seed_rank(0, 0)

@@ -1,0 +1,75 @@
+"""DataParallelTrainer on the GPU (one rank): the fused one-launch Adam must drive the SAME training trajectory as
+torch.optim.Adam (edm.py:240-251).  Guards the packed-weight cache: the fused launch writes parameters through raw pointers
+and has to invalidate the engines' packed MFMA fragments (engine.py repack / repack_transposed), else every step after the
+first runs on stale conv weights."""
+
+import pytest
+import torch
+
+from conftest import cfg_of, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fused, steps=4):
+    from tqdne_amd import LightningEDM, rng
+    from tqdne_amd.trainer import DataParallelTrainer
+    sd, d = load_golden("micro_unet.npz")
+    cfg = dict(cfg_of(d), dropout=0.1)
+    dev = torch.device("cuda:0")
+    edm = LightningEDM(cfg, {"learning_rate": 2e-3, "max_steps": 50, "eta_min": 0.0}, num_sampling_steps=4)
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev).train()
+    rng.seed_rank(123, 0)  # same eps / noise draws and the same dropout masks in both runs
+    tr = DataParallelTrainer(edm, world_size=1, fused_optimizer=fused)
+    g = torch.Generator().manual_seed(5)
+    batch = {"signal": (0.5 * torch.randn(4, 3, 256, generator=g)).to(dev), "cond": torch.randn(4, 5, generator=g).to(dev)}
+    losses = [float(tr.train_step(batch)) for _ in range(steps)]
+    edm.eval()
+    with torch.no_grad():
+        y = edm(batch["signal"], torch.full((4,), 0.7, device=dev), None, batch["cond"]).cpu()
+    w = {k: v.detach().cpu().clone() for k, v in edm.unet.state_dict().items()}
+    return losses, y, w
+
+
+def test_fused_and_torch_adam_train_the_same_trajectory():
+    l_f, y_f, w_f = _run(True)
+    l_t, y_t, w_t = _run(False)
+    print("losses fused", l_f, "torch", l_t)
+    assert l_f[0] == pytest.approx(l_t[0], rel=1e-6)  # same start
+    for a, b in zip(l_f, l_t):
+        assert a == pytest.approx(b, rel=2e-4)
+    # the learning rate is large enough that four steps move the conv weights visibly: a forward on stale packed weights
+    # would differ from the torch-Adam run by far more than the tolerance
+    moved = rel_err(w_f["input_blocks.1.0.in_layers.2.weight"], load_golden("micro_unet.npz")[0]["input_blocks.1.0.in_layers.2.weight"])
+    assert moved > 1e-2, moved
+    assert rel_err(y_f, y_t) < 1e-3
+    for k in w_f:
+        assert rel_err(w_f[k], w_t[k]) < 2e-3, k
+
+
+def test_packed_weights_follow_the_fused_optimizer():
+    """after each fused step the engine's packed conv weights equal a fresh pack of the updated parameters"""
+    from tqdne_amd import LightningEDM, rng
+    from tqdne_amd.trainer import DataParallelTrainer
+    sd, d = load_golden("micro_unet.npz")
+    cfg = cfg_of(d)
+    dev = torch.device("cuda:0")
+    edm = LightningEDM(cfg, {"learning_rate": 1e-2, "max_steps": 50, "eta_min": 0.0})
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev).train()
+    rng.seed_rank(1, 0)
+    tr = DataParallelTrainer(edm, world_size=1, fused_optimizer=True)
+    g = torch.Generator().manual_seed(6)
+    batch = {"signal": (0.5 * torch.randn(2, 3, 256, generator=g)).to(dev), "cond": torch.randn(2, 5, generator=g).to(dev)}
+    eng = edm.unet._engine(2, 256, dev)
+    for _ in range(2):
+        tr.train_step(batch)
+    tr.train_step(batch)  # this step's forward repacked from the parameters of step 2
+    torch.cuda.synchronize()
+    site = eng.conv_sites[0]
+    before = site.packed.clone()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    eng.repack(stream)  # parameters changed in step 3 -> must repack without force
+    torch.cuda.synchronize()
+    assert not torch.equal(before, site.packed), "packed weights did not follow the optimizer update"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment: does running co-resident workgroups OUT of phase pay?  One fused conv over B=64 as a single launch (all
 workgroups in lockstep) against the same work as 4 launches of B=16 alternating on two streams, the second stream started half
-a kernel later, so that each CU hosts workgroups of two launches in different phases.  usage: desync_test.py C0 Cout K T"""
+a kernel later, so that each CU hosts workgroups of two launches in different phases.  usage: desync_bench.py C0 Cout K T"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C

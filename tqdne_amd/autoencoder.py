@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch as th
 from torch import nn
 
-from . import engine
+from . import engine, rng
 from .lightning_compat import LightningModule
 from .unet import AttentionParams, DownsampleParams, ResBlockParams, UpsampleParams
 
@@ -110,7 +110,6 @@ def _seq_engine(mod, x):
     return eng
 
 
-_seed = [0]
 
 
 class _AELossFn(th.autograd.Function):
@@ -176,8 +175,7 @@ class LightningAutoencoder(LightningModule):
         engine.require_device(x)
         x = x.contiguous()
         train = self.training
-        _seed[0] += 1
-        seed = (int(th.initial_seed()) * 1000003 + _seed[0]) & 0xFFFFFFFFFFFFFFFF
+        seed = rng.next_dropout_seed()
         with th.no_grad():
             e_eng = _seq_engine(self.encoder, x)
             enc = e_eng.forward(x, train=train, dropout_seed=seed)

@@ -6,15 +6,12 @@ from __future__ import annotations
 
 import torch as th
 
-from . import _lib
+from . import _lib, rng
 from ._lib import check
 
 
 def _p(t):
     return None if t is None else t.data_ptr()
-
-
-_step_counter = [0]
 
 
 class _EDMLossFn(th.autograd.Function):
@@ -37,8 +34,7 @@ class _EDMLossFn(th.autograd.Function):
         check(lib.tq_edm_noise_inject(_p(sample), _p(unit_noise), _p(eps), float(e.P_mean), float(e.P_std), _p(bufs["sigma"]),
                                       _p(bufs["x"]), B, per, stream), "noise inject")
         train = module.training
-        _step_counter[0] += 1
-        seed = (int(th.initial_seed()) * 1000003 + _step_counter[0]) & 0xFFFFFFFFFFFFFFFF
+        seed = rng.next_dropout_seed()
         pred = module._denoise_static(bufs["x"], bufs["sigma"], 1, cond, train=train, dropout_seed=seed, cond_sample=cond_sample)
         sc = module._scalars(B, dev)
         need_grad = any(p.requires_grad for p in params)
@@ -59,7 +55,8 @@ class _EDMLossFn(th.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads)
 
 
-def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, lanes=None):
+def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, lanes=None, on_bucket=None,
+                       bucket_elems: int = 4 << 20):
     """Fused training step without the autograd round trip: runs the HIP forward and backward back to back and leaves the
     gradients in the backward plan's flat buffer; ``p.grad`` of every UNet parameter is (re)bound to its view of that buffer.
     Returns (loss, flat_gradient_buffer).  Used by DataParallelTrainer (one all-reduce over the flat buffer, no per-parameter
@@ -67,7 +64,11 @@ def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, 
 
     ``lanes`` > 1: the batch is split into sub-batches whose forward + backward run on separate HIP streams with their own plans
     (see LightningEDM.sample_deterministically); the loss is the mean of the sub-batch losses (``gloss = 1 / lanes`` scales each
-    backward) and the lanes' flat gradient buffers are summed into lane 0's.  Default ``train_lanes(B)``."""
+    backward) and the lanes' flat gradient buffers are summed into lane 0's.  Default ``train_lanes(B)``.
+
+    ``on_bucket(flat_slice)``: gradient-exchange hook of the data-parallel trainer, called from inside the backward sweep as
+    soon as a bucket of the flat buffer is final (BackwardPlan.run); with several lanes the buckets are only final after
+    the lanes' buffers have been summed, so the hook is then called for every bucket at the end."""
     params = list(module.unet.parameters())
     B = sample.shape[0]
     if lanes is None:
@@ -94,17 +95,21 @@ def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, 
                     Bl, _, T = _Ctx.shape
                     eng = module.unet._engine(Bl, T, dev, i)
                     scale = th.full((), 1.0 / lanes, device=dev)
-                    grads = eng.backward(bufs["dpred"], scale, clone=False)
+                    grads = eng.backward(bufs["dpred"], scale, clone=False, on_bucket=on_bucket if lanes == 1 else None,
+                                         bucket_elems=bucket_elems)
                     losses.append(loss)
                     flats.append(eng._bwd.flat)
                     if i == 0:
-                        grads0 = grads
+                        grads0, eng0_bwd = grads, eng._bwd
         finally:
             module._lane = 0
         for i, st in enumerate(streams[1:], 1):
             main.wait_stream(st)
         for f in flats[1:]:
             flats[0].add_(f)
+        if on_bucket is not None and lanes > 1:
+            for lo, hi, _ in eng0_bwd.plan_buckets(bucket_elems):
+                on_bucket(flats[0][lo:hi])
         for p, g in zip(params, grads0):
             if g is not None and (p.grad is None or p.grad.data_ptr() != g.data_ptr()):
                 p.grad = g

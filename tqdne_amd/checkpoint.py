@@ -33,13 +33,49 @@ _MODULE_MAP = {
 }
 
 
+# classes of the mapped modules a checkpoint may instantiate (hyper_parameters hold a pickled tqdne.edm.EDM; the reference
+# allow-lists exactly that class with add_safe_globals, experiments/generate.py:117-120)
+_MAPPED_CLASSES = {"EDM", "LightningEDM", "LithningConsistencyModel", "LightningAutoencoder", "UNetModel", "Encoder", "Decoder"}
+
+# everything else a Lightning checkpoint of the reference is made of: tensor / storage rebuild helpers, dtypes, containers,
+# numpy scalars.  A global outside this list is refused: unpickling never runs code a downloaded .ckpt chooses.
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._utils", "_rebuild_qtensor"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"), ("torch.storage", "_load_from_bytes"),
+    ("torch.serialization", "_get_layout"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+    ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"),
+}
+_SAFE_TORCH_NAMES = {n for n in dir(torch) if n.endswith("Storage")} | {
+    n for n in dir(torch) if isinstance(getattr(torch, n, None), torch.dtype)}
+_SAFE_BUILTINS = {"set", "frozenset", "tuple", "list", "dict", "int", "float", "bool", "str", "bytes", "complex", "slice", "range",
+                  "bytearray"}
+
+
 class _RemapUnpickler(pickle.Unpickler):
+    """Restricted unpickler (the allow-list idea of ``torch.load(weights_only=True)`` + ``add_safe_globals``, which is how the
+    reference loads, plus the tqdne.* -> tqdne_amd.* remapping).  ``extra`` = additional (module, name) pairs to accept."""
+
+    extra = frozenset()
+
     def find_class(self, module: str, name: str):
         target = _MODULE_MAP.get(module)
         if target is not None:
+            if name not in _MAPPED_CLASSES:
+                raise pickle.UnpicklingError(f"checkpoint references {module}.{name}: not a class a tqdne checkpoint may hold")
             return getattr(importlib.import_module(target), name)
         if module == "tqdne" or module.startswith("tqdne."):
             raise pickle.UnpicklingError(f"checkpoint references {module}.{name}, which has no tqdne_amd counterpart")
+        ok = ((module, name) in _SAFE_GLOBALS or (module, name) in self.extra
+              or (module == "torch" and name in _SAFE_TORCH_NAMES) or (module == "builtins" and name in _SAFE_BUILTINS))
+        if not ok:
+            raise pickle.UnpicklingError(
+                f"refusing to unpickle global {module}.{name} from a checkpoint (not on the allow-list; pass "
+                f"extra_safe_globals=[({module!r}, {name!r})] to load_checkpoint if the file is trusted)")
         return super().find_class(module, name)
 
 
@@ -91,9 +127,28 @@ class _RemapPickle:
         return bio.getvalue()
 
 
-def load_checkpoint(path, map_location="cpu") -> Dict[str, Any]:
-    """The raw checkpoint dict of a reference (or tqdne_amd) ``.ckpt`` file."""
-    return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_RemapPickle)
+def load_checkpoint(path, map_location="cpu", extra_safe_globals=()) -> Dict[str, Any]:
+    """The raw checkpoint dict of a reference (or tqdne_amd) ``.ckpt`` file.  Unpickling is restricted to an allow-list of
+    tensor / container globals and the remapped tqdne classes (see ``_RemapUnpickler``); ``extra_safe_globals``: further
+    (module, name) pairs to accept for a trusted file."""
+    if not extra_safe_globals:
+        return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_RemapPickle)
+
+    class _U(_RemapUnpickler):
+        extra = frozenset(tuple(x) for x in extra_safe_globals)
+
+    class _P(_RemapPickle):
+        Unpickler = _U
+
+        @staticmethod
+        def load(f, **kw):
+            return _U(f, **kw).load()
+
+        @staticmethod
+        def loads(b, **kw):
+            return _U(io.BytesIO(b), **kw).load()
+
+    return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_P)
 
 
 def save_checkpoint(module: torch.nn.Module, path, *, ema_state: Optional[Dict[str, torch.Tensor]] = None,

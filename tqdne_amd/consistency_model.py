@@ -1,7 +1,7 @@
-"""Consistency-model sampler: drop-in for the forward / sample part of ``tqdne.consistency_model``
-(reference tqdne/consistency_model.py:63-106).  The network is a ``tqdne_amd.UNetModel``; the consistency
-skip/out scalings are folded into the head-conv epilogue, and the raw sigma is the network's timestep (line 77).
-Training (``step``, iCT) is not part of BASELINE.json's configs and is not implemented."""
+"""Consistency model: drop-in for ``tqdne.consistency_model`` (reference tqdne/consistency_model.py:63-190): forward / sample
+(63-106) and the iCT training step (115-176: teacher at sigma_t without gradient, student at sigma_{t+1}, weighted pseudo-Huber
+distance).  The network is a ``tqdne_amd.UNetModel``; the consistency skip/out scalings are folded into the head-conv epilogue,
+and the raw sigma is the network's timestep (line 77).  Both UNet passes of the training step and its backward are HIP."""
 
 from __future__ import annotations
 
@@ -10,7 +10,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, engine
+from . import _lib, engine, rng
 from ._lib import check
 from .edm import sampler_lanes
 from .lightning_compat import LightningModule
@@ -20,7 +20,6 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-_seed = [0]
 
 
 class _ICTLossFn(torch.autograd.Function):
@@ -30,8 +29,7 @@ class _ICTLossFn(torch.autograd.Function):
     def forward(ctx, module, sample, sigmas, timesteps, epsilon, cond, *params):
         engine.require_device(sample)
         B, nd = sample.shape[0], sample.dim()
-        _seed[0] += 1
-        seed = (int(torch.initial_seed()) * 1000003 + _seed[0]) & 0xFFFFFFFFFFFFFFFF  # one seed: teacher = student masks
+        seed = rng.next_dropout_seed()  # one seed: teacher = student masks
         train = module.training
         t_sig, s_sig = sigmas[timesteps].float().contiguous(), sigmas[timesteps + 1].float().contiguous()
         exp = lambda v: v[(...,) + (None,) * (nd - 1)]

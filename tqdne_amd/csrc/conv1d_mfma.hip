@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include <atomic>
 #include "../../include/tqdne_hip.h"
 
 using namespace tq;
@@ -828,12 +829,17 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
     auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW>;
     constexpr int LDS_BYTES = PW ? 4 * C::BUF : C::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // The dynamic-LDS limit is a per-device property of the kernel: remember, per device ordinal, that it has been raised
+    // (idempotent call: two threads racing here both set the same value; the mask only saves the repeated runtime call).
+    static std::atomic<uint64_t> attr_done{0};
+    int dev_ord = 0;
+    (void)hipGetDevice(&dev_ord);
+    const uint64_t dev_bit = 1ull << (dev_ord & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_done.fetch_or(dev_bit, std::memory_order_release);
     }
     const int n_ttiles = (a.T_out + C::NT - 1) / C::NT;
     const int n_ctiles = (a.C_out + C::MT - 1) / C::MT;

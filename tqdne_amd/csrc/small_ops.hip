@@ -702,10 +702,11 @@ namespace {
 constexpr int ENV_TILE = 1024;
 
 __global__ __launch_bounds__(256) void envelope_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T,
-                                                           int W, double log_eps, double eps) {
+                                                           int W, double log_eps, double eps, int n_tiles) {
     extern __shared__ float env_lds[];
-    const int row = blockIdx.y, n = row / C, c = row % C;
-    const int t0 = blockIdx.x * ENV_TILE;
+    // (row, tile) folded into grid.x: grid.y would cap N * C at 65535 rows
+    const int row = blockIdx.x / n_tiles, n = row / C, c = row % C;
+    const int t0 = (blockIdx.x % n_tiles) * ENV_TILE;
     const int lo = W / 2, hi = (W - 1) / 2;
     const float* xr = x + (size_t)row * T;
     for (int i = threadIdx.x; i < ENV_TILE + W; i += 256) {
@@ -749,9 +750,11 @@ extern "C" int tq_envelope_fwd(const float* x, float* out, int N, int C, int T, 
                                hipStream_t stream) {
     if (!x || !out) return TQ_ERR_ARG;
     if (N <= 0 || C <= 0 || T <= 0 || window <= 0 || window > T || window > 4096 || !(log_eps > 0.0)) return TQ_ERR_SHAPE;
-    const dim3 grid((T + ENV_TILE - 1) / ENV_TILE, N * C);
+    const int n_tiles = (T + ENV_TILE - 1) / ENV_TILE;
+    if ((size_t)n_tiles * N * C > 0x7fffffffull) return TQ_ERR_SHAPE;
+    const dim3 grid((unsigned)((size_t)n_tiles * N * C));
     hipLaunchKernelGGL(envelope_fwd_kernel, grid, dim3(256), (ENV_TILE + window + 1) * sizeof(float), stream, x, out, C, T,
-                       window, log_eps, eps);
+                       window, log_eps, eps, n_tiles);
     TQ_CHECK_LAUNCH();
     return 0;
 }

@@ -185,8 +185,9 @@ class LightningEDM(LightningModule):
         return edm_loss(self, sample.contiguous(), eps.contiguous().float(), unit_noise.contiguous(), cond,
                         None if cond_sample is None else cond_sample.contiguous())
 
-    def step_and_backward(self, batch):
-        """``step`` + backward in one call, gradients left in ``p.grad`` (views of one flat buffer, returned as well)."""
+    def step_and_backward(self, batch, on_bucket=None, bucket_elems: int = 4 << 20):
+        """``step`` + backward in one call, gradients left in ``p.grad`` (views of one flat buffer, returned as well).
+        ``on_bucket``: gradient-exchange hook, called as buckets of the flat buffer become final (BackwardPlan.run)."""
         from .autograd import edm_loss_and_grads
         sample = batch["signal"]
         cond = batch["cond"] if "cond" in batch else None
@@ -199,7 +200,8 @@ class LightningEDM(LightningModule):
         eps = th.randn(sample.shape[0], device=sample.device)
         unit_noise = th.randn_like(sample)
         return edm_loss_and_grads(self, sample.contiguous(), eps, unit_noise, cond,
-                                  None if cond_sample is None else cond_sample.contiguous())
+                                  None if cond_sample is None else cond_sample.contiguous(), on_bucket=on_bucket,
+                                  bucket_elems=bucket_elems)
 
     def training_step(self, batch, batch_idx):
         loss = self.step(batch, batch_idx)
@@ -252,7 +254,7 @@ class LightningEDM(LightningModule):
         ``lanes``: samples are independent, so the batch can be integrated as ``lanes`` sub-batches on as many HIP streams, each
         with its own execution plan.  Workgroups of one launch run in lockstep (all in their load prologue, then all in their MFMA loop,
         then all in their store epilogue); streams drift out of phase, so one lane's prologue / epilogue bursts overlap another
-        lane's matrix work (measured on single layers: 1.0-1.17x, tools/desync_test.py; 18-step sample at B = 64: 2 lanes
+        lane's matrix work (measured on single layers: 1.0-1.17x, tools/desync_bench.py; 18-step sample at B = 64: 2 lanes
         -5.5 %, 4 lanes -9 %, 8 lanes +16 %: launches too small and too many).  Results are bit-identical to one lane.
         Default: ``sampler_lanes(B)``; 1 under graph replay."""
         if not eps.is_cuda:
@@ -260,6 +262,8 @@ class LightningEDM(LightningModule):
         B = eps.shape[0]
         if lanes is None:
             lanes = sampler_lanes(B)
+        if use_graph:
+            lanes = 1  # one captured denoiser per buffer set; replay is for launch-bound (small) batches, where lanes do not pay
         if lanes < 2 or B % lanes or B // lanes < 8:
             run = self._heun_lane(eps, sigmas, cond_sample, cond, use_graph)
             for _ in run:

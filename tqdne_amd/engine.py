@@ -87,6 +87,12 @@ class ConvSite:
         self.version = -1
 
 
+def _recorded_event():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
 class Probe:
     """HIP-event timings of one op of the plan (events are recorded on the stream the kernel is launched on)."""
 
@@ -113,6 +119,8 @@ class UNetEngine:
         self._keep = []          # ctypes structs / tensors referenced by raw pointers
         self.ops: List[Tuple] = []          # launches of a forward whose backward may follow
         self.ops_infer: List[Tuple] = []    # same order and length; inference-only variants where they exist
+        self.op_bytes: List[int] = []       # same order: algorithmic bytes per launch
+        self._trace = None                  # list: HIP-event pairs around EVERY launch of the next forwards (measurement only)
         self.conv_sites: List[ConvSite] = []
         self.poly_sites: List[Tuple[ConvSite, ConvSite]] = []   # (derived two-phase k = 3 site, the Upsample conv it restates)
         self.dropout_descs: List[TqConvDesc] = []
@@ -156,10 +164,12 @@ class UNetEngine:
         return s, t
 
     # ------------------------------------------------------------------ op builders
-    def _emit(self, op, infer_op=None):
-        """append a launch to the plan; ``infer_op`` replaces it in forwards that no backward will follow"""
+    def _emit(self, op, infer_op=None, nbytes=0):
+        """append a launch to the plan; ``infer_op`` replaces it in forwards that no backward will follow.
+        ``nbytes``: algorithmic HBM bytes of the launch (fp32 inputs read once + output written once), for the bench's tables"""
         self.ops.append(op)
         self.ops_infer.append(op if infer_op is None else infer_op)
+        self.op_bytes.append(nbytes)
 
     def _gn(self, srcs: Sequence[Act], norm: torch.nn.GroupNorm):
         C_ = sum(s.C for s in srcs)
@@ -169,7 +179,8 @@ class UNetEngine:
         s1 = srcs[1] if len(srcs) > 1 else None
         self._emit((self.lib.tq_gn_finalize, (
             _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
-            _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize", 0))
+            _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize", 0),
+            nbytes=4 * self.B * (2 * nslots(s0.T) * C_ + 2 * C_))
         return gscale, gshift, mean_rstd
 
     def _conv(self, srcs: Sequence[Act], site: ConvSite, *, gn=None, silu=False, emb_ptr=None, res: Optional[Act] = None,
@@ -223,6 +234,7 @@ class UNetEngine:
             self.dropout_descs.append(d)
         self._keep.append(d)
         flops = 2 * site.C_in * site.C_out * site.K * T_out * self.B
+        nbytes = 4 * self.B * (T_in * site.C_in + T_out * site.C_out + (T_out * site.C_out if res is not None else 0))
         if skip is not None:
             ksrcs, ksite = skip
             k0, k1 = ksrcs[0], (ksrcs[1] if len(ksrcs) > 1 else None)
@@ -232,7 +244,8 @@ class UNetEngine:
                 C.byref(d), _p(s0.buf), _p(s1.buf) if s1 else None, _p(gn[0]) if gn else None, _p(gn[1]) if gn else None,
                 _p(site.packed), _p(site.bias), emb_ptr, _p(k0.buf), _p(k1.buf) if k1 else None, _p(ksite.bias),
                 _p(out.buf), _p(out.stats)),
-                "conv:" + site.name + "+skip", flops + 2 * ksite.C_in * site.C_out * T_out * self.B))
+                "conv:" + site.name + "+skip", flops + 2 * ksite.C_in * site.C_out * T_out * self.B),
+                nbytes=nbytes + 4 * self.B * T_out * ksite.C_in)
         elif launch:
             op = (self.lib.tq_conv1d_fwd, (
                 C.byref(d), _p(s0.buf), _p(s1.buf) if s1 else None, _p(gn[0]) if gn else None, _p(gn[1]) if gn else None,
@@ -247,7 +260,7 @@ class UNetEngine:
                 infer_op = (self.lib.tq_conv1d_fwd_qkv, (
                     C.byref(d), _p(s0.buf), _p(gn[0]) if gn else None, _p(gn[1]) if gn else None, _p(site.packed), _p(site.bias),
                     _p(out.buf), _p(ws), H_, D_), "conv:" + site.name + "+split", flops)
-            self._emit(op, infer_op)
+            self._emit(op, infer_op, nbytes=nbytes)
         self.last_rec = ConvRec(site, d, list(srcs), gn, out, stride, upsample, silu, dropout_site is not None)
         return out
 
@@ -397,17 +410,18 @@ class UNetEngine:
         if split is not None:
             infer_op = (self.lib.tq_attention_fwd_presplit, (_p(qkv.buf), _p(ws), _p(att.buf), self.B, x.T, ab.num_heads, D),
                         "attention", flops)
-        self._emit(op, infer_op)
+        self._emit(op, infer_op, nbytes=4 * self.B * x.T * 4 * ab.channels)
         out = self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
         self.tape.append(("attn", dict(ab=ab, x=x, g=g, qkv=qkv, att=att, lse=lse, out=out, rec_qkv=rec_qkv,
                                        rec_proj=self.last_rec, D=D)))
         return out
 
     def _attn_workspace(self, nbytes: int):
-        """pre-split K/V scratch, shared by all attention blocks of the plan (they run back to back on one stream)"""
+        """pre-split K/V scratch, shared by the attention blocks of the plan that have one shape (they run back to back on one
+        stream); a block that needs more (a Decoder with attention at several resolutions: T grows along up_blocks) gets a
+        buffer of its own -- launches already emitted keep the pointer they were bound to"""
         ws = getattr(self, "_attn_ws", None)
-        if ws is None or ws.numel() < nbytes:
-            assert ws is None, "attention blocks of one plan share a shape"
+        if ws is None or ws.numel() != nbytes:
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)  # padding rows (t >= T) stay zero
             self._keep.append(ws)
             self._attn_ws = ws
@@ -496,6 +510,9 @@ class UNetEngine:
                 d.dropout_p, d.dropout_seed = p, dropout_seed
             else:
                 d.flags &= ~TQ_CONV_DROPOUT
+        trace = None if torch.cuda.is_current_stream_capturing() else self._trace
+        ev = (lambda: _recorded_event()) if trace is not None else None
+        e0 = ev() if ev else None
         tm, cm = m.time_mlp, (m.cond_mlp if m.cond_features is not None else None)
         check(lib.tq_embed_fwd(
             _p(timesteps), _p(cond), _p(m.time_embed.W), _p(tm[0].weight), _p(tm[0].bias), _p(tm[2].weight), _p(tm[2].bias),
@@ -508,13 +525,29 @@ class UNetEngine:
         else:
             check(lib.tq_linear_fwd(_p(self.silu_emb), _p(self.emb_w), _p(self.emb_b), _p(self.emb_all), B, self.E,
                                     self.emb_total, stream), "emb projections")
+        if ev:
+            e1 = ev()
+            trace.append(("embed", 2 * B * self.E * (self.emb_total + 2 * self.E), 4 * (self.emb_total * self.E + B * self.emb_total), e0, e1))
+            e0 = e1
         stem = m.input_blocks[0][0]
         check(lib.tq_stem_conv_fwd(_p(x), _p(in_scale), _p(stem.weight), _p(stem.bias), _p(self.stem_out.buf),
                                    _p(self.stem_out.stats), B, m.in_channels, T, stem.out_channels, stem.kernel_size[0],
                                    stream), "stem conv")
+        if ev:
+            e1 = ev()
+            trace.append(("stem", 2 * B * T * m.in_channels * stem.out_channels * stem.kernel_size[0],
+                          4 * B * T * (m.in_channels + stem.out_channels), e0, e1))
         probe = self._probe
         ops = self.ops_infer if (infer and not train) else self.ops
-        if probe is None or torch.cuda.is_current_stream_capturing():
+        if trace is not None:
+            for i, (fn, args, what, fl) in enumerate(ops):
+                a = ev()
+                rc = fn(*args, stream)
+                b = ev()
+                trace.append((what, fl, self.op_bytes[i], a, b))
+                if rc:
+                    check(rc, what)
+        elif probe is None or torch.cuda.is_current_stream_capturing():
             for fn, args, what, _ in ops:
                 rc = fn(*args, stream)
                 if rc:
@@ -534,18 +567,23 @@ class UNetEngine:
         self._last = dict(x=x, in_scale=in_scale, c_out=c_out, timesteps=timesteps, cond=cond, train=train,
                           dropout_p=p, dropout_seed=dropout_seed, infer=infer and not train)
         head = m.out[2]
+        e0 = ev() if ev else None
         check(lib.tq_head_conv_fwd(_p(self.final.buf), _p(self.head_gn[0]), _p(self.head_gn[1]), _p(head.weight),
                                    _p(head.bias), _p(c_out), _p(c_skip), _p(skip_src), _p(self.out_nct), B, T,
                                    self.final.C, m.out_channels, head.kernel_size[0], stream), "head conv")
+        if ev:
+            trace.append(("head", 2 * B * T * self.final.C * m.out_channels * head.kernel_size[0],
+                          4 * B * T * (self.final.C + 2 * m.out_channels), e0, ev()))
         return self.out_nct
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dpred: torch.Tensor, gloss: torch.Tensor, c_out=None, in_scale=None, clone: bool = True):
+    def backward(self, dpred: torch.Tensor, gloss: torch.Tensor, c_out=None, in_scale=None, clone: bool = True, on_bucket=None,
+                 bucket_elems: int = 4 << 20):
         """Gradients of every UNet parameter for d loss / d pred = gloss * dpred, for the last train-mode forward.
-        Returns a list aligned with ``model.parameters()`` (None for frozen parameters)."""
+        Returns a list aligned with ``model.parameters()`` (None for frozen parameters).  ``on_bucket``: see BackwardPlan.run."""
         if self._bwd is None:
             self._bwd = BackwardPlan(self)
-        return self._bwd.run(dpred, gloss, clone=clone)
+        return self._bwd.run(dpred, gloss, clone=clone, on_bucket=on_bucket, bucket_elems=bucket_elems)
 
 
 class SeqEngine(UNetEngine):

@@ -42,6 +42,8 @@ class BackwardPlan:
         self.ops: List = []
         self.bwd_dropout_descs: List[TqConvBwdDesc] = []
         self._scratch: Dict = {}
+        self.op_flops: Dict[int, int] = {}   # index into self.ops -> algorithmic FLOP of that launch (bench tables)
+        self._trace = None                   # list: HIP-event pairs around every launch of the next sweeps (measurement only)
         self._layout_gradients()
         self._build()
 
@@ -64,39 +66,121 @@ class BackwardPlan:
             act.grad = self._empty(self.B, act.T, act.C)
         return act.grad
 
+    def _readiness_keys(self):
+        """id(param) -> position of the reverse sweep at which its gradient becomes final: 0 = head / output layer, then the
+        tape entries from the last block back to the first, then the stem, and last whatever the sweep does not finalise
+        itself (the embedding MLPs and the ResBlocks' embedding projections: one GEMM chain after the sweep)."""
+        e, m = self.e, self.m
+        n = len(e.tape)
+        key = {}
+
+        def mark(ps, k):
+            for p in ps:
+                if p is not None:
+                    key.setdefault(id(p), k)
+
+        head = [m.out] if hasattr(m, "out") else [m.output_layer]
+        for mod in head:
+            mark(mod.parameters(), 0)
+        for k, (kind, t) in enumerate(e.tape):
+            pos = n - k
+            if kind == "res":
+                mark([p for name, p in t["rb"].named_parameters() if not name.startswith("emb_layers")], pos)
+            elif kind == "attn":
+                mark(t["ab"].parameters(), pos)
+            else:
+                mark([t["rec"].site.weight, t["rec"].site.bias], pos)
+        stem = m.input_blocks[0][0] if hasattr(m, "input_blocks") else m.input_layer
+        mark(stem.parameters(), n + 1)
+        return key, n + 2
+
     def _layout_gradients(self):
-        """One flat fp32 buffer: [emb_layers weights (contiguous, block order) | emb_layers biases | d emb_all | the rest]."""
+        """One flat fp32 buffer, laid out in the order the reverse sweep finalises the gradients (so that contiguous buckets
+        can be handed to the gradient exchange while the sweep is still running, DataParallelTrainer / SURVEY.md 8e):
+        [head | last block ... first block | stem | emb_layers weights (contiguous, block order) | emb_layers biases |
+         embedding MLPs | -- end of the parameter gradients, ``n_grad`` -- | d emb_all (scratch)]."""
         e, m = self.e, self.m
         named = list(m.named_parameters())
         self.param_order = [p for _, p in named]
-        first = []
+        emb_w, emb_b = [], []
         for rb in e.res_blocks:
             if hasattr(rb, "emb_layers"):
-                first.append(rb.emb_layers[1].weight)
-        for rb in e.res_blocks:
-            if hasattr(rb, "emb_layers"):
-                first.append(rb.emb_layers[1].bias)
-        ids = {id(p) for p in first}
-        rest = [p for _, p in named if id(p) not in ids]
+                emb_w.append(rb.emb_layers[1].weight)
+                emb_b.append(rb.emb_layers[1].bias)
+        emb_ids = {id(p) for p in emb_w + emb_b}
+        key, last = self._readiness_keys()
+        rest = [p for _, p in named if id(p) not in emb_ids]
+        order = sorted(range(len(rest)), key=lambda i: (key.get(id(rest[i]), last), i))
+        swept = [rest[i] for i in order if key.get(id(rest[i]), last) < last]
+        tail = [rest[i] for i in order if key.get(id(rest[i]), last) >= last]
         total, offs = 0, {}
-        for p in first:
-            offs[id(p)] = total
-            total += p.numel()
-        self.off_demb = total
-        total += self.B * e.emb_total
-        for p in rest:
+        for p in swept:
             total = (total + 63) // 64 * 64
             offs[id(p)] = total
             total += p.numel()
+        total = (total + 63) // 64 * 64
+        self.off_emb = total
+        for p in emb_w + emb_b:   # no padding in between: their gradient is ONE GEMM / one column sum over the block
+            offs[id(p)] = total
+            total += p.numel()
+        for p in tail:
+            total = (total + 63) // 64 * 64
+            offs[id(p)] = total
+            total += p.numel()
+        self.n_grad = total
+        total = (total + 63) // 64 * 64
+        self.off_demb = total
+        total += self.B * e.emb_total
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
-        self.gview = {pid: self.flat[o:o + p.numel()].view_as(p) for (pid, o), p in
-                      zip([(id(p), offs[id(p)]) for p in first + rest], first + rest)}
+        self.gview = {id(p): self.flat[offs[id(p)]:offs[id(p)] + p.numel()].view_as(p) for p in swept + emb_w + emb_b + tail}
         self.demb_all = self.flat[self.off_demb:self.off_demb + self.B * e.emb_total].view(self.B, e.emb_total)
-        self.g_emb_w = self.flat[0:e.emb_total * e.E].view(e.emb_total, e.E)
-        self.g_emb_b = self.flat[e.emb_total * e.E:e.emb_total * e.E + e.emb_total]
+        o = self.off_emb
+        self.g_emb_w = self.flat[o:o + e.emb_total * e.E].view(e.emb_total, e.E)
+        self.g_emb_b = self.flat[o + e.emb_total * e.E:o + e.emb_total * e.E + e.emb_total]
         self.offs = offs
+        self._ready = {}        # id(param) -> index of the op of self.ops that finalises its gradient (recorded by g())
+        self._swept_ids = {id(p) for p in swept}
+
+    # ------------------------------------------------------------------ gradient buckets (overlap with the exchange)
+    END = 1 << 30
+
+    def plan_buckets(self, bucket_elems: int):
+        """Cut [0, n_grad) of the flat buffer into contiguous buckets of >= ``bucket_elems`` floats and find, for each, the op
+        of the sweep after which all of it is final.  Returns [(lo, hi, op_index)]; op_index END = only after the sweep
+        (stem weight gradient, embedding backward)."""
+        spans = []
+        for p in self.param_order:
+            o = self.offs[id(p)]
+            r = self._ready.get(id(p), self.END) if id(p) in self._swept_ids else self.END
+            if r >= len(self.ops):
+                r = self.END
+            if not p.requires_grad:
+                r = -1
+            spans.append((o, o + p.numel(), r))
+        spans.sort()
+        buckets, lo, ready = [], 0, -1
+        for o, hi, r in spans:
+            ready = max(ready, r)
+            if hi - lo >= bucket_elems:
+                hi_al = min((hi + 63) // 64 * 64, self.n_grad)
+                buckets.append((lo, hi_al, ready))
+                lo = hi_al
+        if lo < self.n_grad:
+            buckets.append((lo, self.n_grad, max(ready, spans[-1][2]) if buckets else ready))
+        # a bucket can never be released before an earlier one (the exchange is issued in one order on every rank)
+        out, run_max = [], -1
+        for lo_, hi_, r in buckets:
+            run_max = max(run_max, r)
+            out.append((lo_, hi_, run_max))
+        return out
 
     def g(self, param):
+        """the gradient view of ``param``; called while an op is being assembled, so it also records that op (the next one
+        appended to self.ops) as the last writer of that gradient"""
+        self._ready[id(param)] = len(self.ops)
+        return self.gview[id(param)]
+
+    def gv(self, param):
         return self.gview[id(param)]
 
     # ------------------------------------------------------------------ emitters
@@ -107,6 +191,7 @@ class BackwardPlan:
         self._wgrad_ops.append(len(self.ops))
         s0 = rec.srcs[0]
         s1 = rec.srcs[1] if len(rec.srcs) > 1 else None
+        self.op_flops[len(self.ops)] = 2 * site.C_in * site.C_out * site.K * rec.desc.T_out * self.B
         self.ops.append([lib.tq_conv1d_bwd_weight, [C.byref(rec.desc), _p(dy), _p(s0.buf), _p(s1.buf) if s1 else None,
                                                     _p(rec.gn[0]) if rec.gn else None, _p(rec.gn[1]) if rec.gn else None,
                                                     _p(self.g(site.weight)), None, 0], "wgrad:" + site.name])
@@ -145,6 +230,7 @@ class BackwardPlan:
         d.flags = f
         d.dropout_site = rec.desc.dropout_site
         self._keep.append(d)
+        self.op_flops[len(self.ops)] = 2 * site.C_in * site.C_out * site.K * (rec.desc.T_out if rec.stride == 2 else T) * self.B
         self.ops.append([lib.tq_conv1d_bwd_data, [C.byref(d), _p(dy), _p(site.packed_t), _p(s0.buf) if chain else None,
                                                   _p(s1.buf) if (chain and s1) else None,
                                                   _p(rec.gn[0]) if (chain and rec.gn) else None,
@@ -192,6 +278,7 @@ class BackwardPlan:
         assert so.gw
         self.stem_op = [lib.tq_stem_conv_bwd_weight, [_p(so.grad), None, None, _p(self.g(stem.weight)), B, m.in_channels, so.T,
                                                       stem.out_channels, stem.kernel_size[0]], "stem wgrad"]
+        self._ready[id(stem.weight)] = self.END  # (run after the sweep, not from self.ops)
         # wide stems (the latent UNet's 16 input channels: 64 x 16 x 5 weights exceed the dedicated kernel's register budget)
         # are differentiated as a generic fused conv over a (B, T, 32) channels-last copy of the pre-scaled input
         self.stem_generic = stem.out_channels * m.in_channels * stem.kernel_size[0] > 2048
@@ -270,6 +357,7 @@ class BackwardPlan:
         self._dgrad(t["rec_proj"], dout, T, [datt], accumulate=False, chain=False)
         dqkv = self.grad(qkv)
         delta = self._empty(B, ab.num_heads, T)
+        self.op_flops[len(self.ops)] = 2 * 4 * ab.channels * T * T * B
         self.ops.append([self.lib.tq_attention_bwd, [_p(qkv.buf), _p(att.buf), _p(datt), _p(t["lse"]), _p(delta), _p(dqkv), B, T,
                                                      ab.num_heads, t["D"]], "attention bwd"])
         self._wgrad(t["rec_qkv"], dqkv)
@@ -299,7 +387,11 @@ class BackwardPlan:
         x.gw = True
 
     # ------------------------------------------------------------------ run
-    def run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True):
+    def run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True, on_bucket=None, bucket_elems: int = 4 << 20):
+        """``on_bucket(flat_slice)``: called from inside the sweep, right after the launch that finalises the last gradient of
+        each bucket of >= ``bucket_elems`` floats has been enqueued (buckets = contiguous slices of the flat buffer in the
+        order the sweep completes them; every rank cuts them identically).  The data-parallel trainer starts the slice's
+        all-reduce there, so the exchange runs under the rest of the backward."""
         e, m, lib = self.e, self.m, self.lib
         last = e._last
         if last.get("infer", False):
@@ -325,17 +417,39 @@ class BackwardPlan:
         if self.stem_generic:
             xs = last["x"] if last["in_scale"] is None else last["x"] * last["in_scale"][:, None, None]
             self.stem_x_btc[:, :, :cin].copy_(xs.permute(0, 2, 1))
-        for fn, args, what in self.ops:
-            rc = fn(*args, stream)
-            if rc:
-                check(rc, what)
+        if self._trace is not None:
+            from .engine import _recorded_event
+            late = ()
+            for i, (fn, args, what) in enumerate(self.ops):
+                a = _recorded_event()
+                rc = fn(*args, stream)
+                self._trace.append((what, self.op_flops.get(i, 0), 0, a, _recorded_event()))
+                if rc:
+                    check(rc, what)
+        elif on_bucket is None:
+            for fn, args, what in self.ops:
+                rc = fn(*args, stream)
+                if rc:
+                    check(rc, what)
+            late = ()
+        else:
+            fire, late = self._fire_points(bucket_elems)
+            for i, (fn, args, what) in enumerate(self.ops):
+                rc = fn(*args, stream)
+                if rc:
+                    check(rc, what)
+                if i in fire:
+                    for lo, hi in fire[i]:
+                        on_bucket(self.flat[lo:hi])
         if self.stem_generic:
-            self.g(m.input_blocks[0][0].weight).copy_(self.dw_stem32[:, :cin, :])
+            self.gv(m.input_blocks[0][0].weight).copy_(self.dw_stem32[:, :cin, :])
         else:
             fn, args, what = self.stem_op
             args[1], args[2] = last["x"].data_ptr(), _p(last["in_scale"])
             check(fn(*args, stream), what)
         self._embedding_backward(last)
+        for lo, hi in late:
+            on_bucket(self.flat[lo:hi])
         out = self.flat.clone() if clone else self.flat  # clone: autograd may keep the returned tensors alive
         res = []
         for p_ in self.param_order:
@@ -345,6 +459,20 @@ class BackwardPlan:
                 o = self.offs[id(p_)]
                 res.append(out[o:o + p_.numel()].view_as(p_))
         return res
+
+    def _fire_points(self, bucket_elems):
+        key = int(bucket_elems)
+        cached = getattr(self, "_fire_cache", None)
+        if cached is None or cached[0] != key:
+            fire, late = {}, []
+            for lo, hi, r in self.plan_buckets(key):
+                if r >= self.END:
+                    late.append((lo, hi))
+                else:
+                    fire.setdefault(max(r, 0), []).append((lo, hi))
+            cached = (key, fire, late)
+            self._fire_cache = cached
+        return cached[1], cached[2]
 
     def _embedding_backward(self, last):
         """Backward of Fourier -> time MLP (+ cond MLP) -> per-block Linear(SiLU(emb)) (unet.py:91-97, 210-227, 383-388).
@@ -361,22 +489,22 @@ class BackwardPlan:
         d_emb = torch.mm(demb_all, e.emb_w) * dsilu(e.emb)
         tm = m.time_mlp
         h0 = e.emb_hidden[:, 0]
-        torch.mm(d_emb.t(), torch.nn.functional.silu(h0), out=self.g(tm[2].weight))
-        torch.sum(d_emb, dim=0, out=self.g(tm[2].bias))
+        torch.mm(d_emb.t(), torch.nn.functional.silu(h0), out=self.gv(tm[2].weight))
+        torch.sum(d_emb, dim=0, out=self.gv(tm[2].bias))
         dh0 = torch.mm(d_emb, tm[2].weight) * dsilu(h0)
         t = last["timesteps"]
         arg = t[:, None] * m.time_embed.W[None, :] * 2 * torch.pi
         four = torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
-        torch.mm(dh0.t(), four, out=self.g(tm[0].weight))
-        torch.sum(dh0, dim=0, out=self.g(tm[0].bias))
+        torch.mm(dh0.t(), four, out=self.gv(tm[0].weight))
+        torch.sum(dh0, dim=0, out=self.gv(tm[0].bias))
         if m.cond_features is not None:
             cm = m.cond_mlp
             c0 = e.emb_hidden[:, 1]
-            torch.mm(d_emb.t(), torch.nn.functional.silu(c0), out=self.g(cm[2].weight))
-            torch.sum(d_emb, dim=0, out=self.g(cm[2].bias))
+            torch.mm(d_emb.t(), torch.nn.functional.silu(c0), out=self.gv(cm[2].weight))
+            torch.sum(d_emb, dim=0, out=self.gv(cm[2].bias))
             dc0 = torch.mm(d_emb, cm[2].weight) * dsilu(c0)
-            torch.mm(dc0.t(), last["cond"], out=self.g(cm[0].weight))
-            torch.sum(dc0, dim=0, out=self.g(cm[0].bias))
+            torch.mm(dc0.t(), last["cond"], out=self.gv(cm[0].weight))
+            torch.sum(dc0, dim=0, out=self.gv(cm[0].bias))
 
 
 class SeqBackwardPlan(BackwardPlan):
@@ -475,7 +603,7 @@ class SeqBackwardPlan(BackwardPlan):
             rc = fn(*args, stream)
             if rc:
                 check(rc, what)
-        self.g(stem.weight).copy_(self.dw_stem32[:, :cin, :])
+        self.gv(stem.weight).copy_(self.dw_stem32[:, :cin, :])
         dx = None
         if want_dx:
             fn, args, what = self.dx_op

@@ -50,9 +50,10 @@ class FusedAdamEMA(torch.optim.Optimizer):
             for p, o in zip(ps, offs):
                 self._ema[o:o + p.numel()].copy_(p.detach().reshape(-1))
         self._step = 0
+        self._step_t = torch.tensor(0.0)  # one shared CPU scalar: state[p]["step"] of every parameter (torch Adam's format)
         for p, o in zip(ps, offs):
             n = p.numel()
-            self.state[p] = dict(step=torch.tensor(0.0), exp_avg=self._m[o:o + n].view_as(p),
+            self.state[p] = dict(step=self._step_t, exp_avg=self._m[o:o + n].view_as(p),
                                  exp_avg_sq=self._v[o:o + n].view_as(p))
         self._table = None
         self._table_key = None
@@ -90,6 +91,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self._table = host.to(self._m.device)
         self._n_chunks = len(rows)
+        self._updated = [p for p in ps if p.grad is not None]
 
     def _key(self):
         ps = self.param_groups[0]["params"]
@@ -113,8 +115,10 @@ class FusedAdamEMA(torch.optim.Optimizer):
         stream = torch.cuda.current_stream(self._m.device).cuda_stream
         check(self._lib.tq_adam_ema_step(self._table.data_ptr(), self._n_chunks, step_size, b1, b2, g["eps"], ibc2, ema_w,
                                          grad_scale, 1.0 - g["lr"] * g["weight_decay"], stream), "adam")
-        for st in self.state.values():
-            st["step"] = torch.tensor(float(t))
+        # the kernel wrote the parameters through raw pointers: bump their autograd version counters so that everything keyed
+        # on ``p._version`` (the engines' packed MFMA weight fragments, engine.py repack / repack_transposed) sees the update
+        torch._C._increment_version(self._updated)
+        self._step_t.fill_(float(t))
         return loss
 
     # ------------------------------------------------------------------ (de)serialisation in torch Adam's format
@@ -130,8 +134,7 @@ class FusedAdamEMA(torch.optim.Optimizer):
         if len(steps) > 1:
             raise ValueError("per-parameter step counts differ; the fused update keeps one")
         self._step = steps.pop() if steps else 0
-        for st_p in self.state.values():
-            st_p["step"] = torch.tensor(float(self._step))
+        self._step_t.fill_(float(self._step))
         for k, v in state_dict["param_groups"][0].items():
             if k in ("lr", "betas", "eps", "initial_lr", "weight_decay"):
                 self.param_groups[0][k] = v

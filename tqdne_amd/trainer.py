@@ -1,9 +1,19 @@
 """Data-parallel training loop for the EDM module: stands where Lightning's fit loop + DDPStrategy stand in the
-reference (experiments/train_1d_edm.py:34-70; SURVEY.md 2.4): one process per GPU, identical replicas, the batch is
+reference (experiments/train_1d_edm.py:34-70; SURVEY.md 2.4, 8e): one process per GPU, identical replicas, the batch is
 sharded by rank, gradients are summed with RCCL all-reduce over xGMI (torch.distributed backend "nccl") and divided
-by the world size, then every rank applies the same Adam + per-step cosine LR update (edm.py:240-251)."""
+by the world size, then every rank applies the same Adam + per-step cosine LR update (edm.py:240-251).
+
+The exchange is overlapped with the backward, the way torch's DDP reducer does it for the reference: the backward plan lays
+the flat gradient buffer out in the order its reverse sweep finalises the gradients (head, output blocks, middle block,
+input blocks, stem, embedding MLPs) and calls back as each contiguous bucket becomes final; the bucket's all-reduce is
+issued right there (asynchronously: on RCCL's own stream, ordered behind the launches enqueued so far) and runs under the
+rest of the sweep.  Only the optimizer launch waits for the exchange.  Every rank cuts and issues the buckets identically
+(the cut depends on the model and ``bucket_bytes`` only), so the collectives match up by construction.
+"""
 
 from __future__ import annotations
+
+import inspect
 
 import torch
 import torch.distributed as dist
@@ -42,11 +52,17 @@ def shard_batch(batch: dict, rank: int, world_size: int) -> dict:
 
 
 class DataParallelTrainer:
-    def __init__(self, module, world_size: int = 1, bucket_bytes: int = 32 << 20, ema_decay=None, fused_optimizer=None):
+    def __init__(self, module, world_size: int = 1, bucket_bytes: int = 16 << 20, ema_decay=None, fused_optimizer=None,
+                 overlap: bool = True, process_group=None):
         """``ema_decay``: keep the EMA weights of the reference's EMA callback (tqdne/ema.py; 0.999 in the reference's runs).
-        ``fused_optimizer``: one-launch Adam (+ EMA) instead of torch.optim.Adam; default: on GPUs."""
+        ``fused_optimizer``: one-launch Adam (+ EMA) instead of torch.optim.Adam; default: on GPUs.
+        ``overlap``: issue each gradient bucket's all-reduce from inside the backward sweep (default) instead of after it.
+        ``bucket_bytes``: 16 MB = 4 buckets over the paper UNet's 62 MB of gradients (xGMI rings are per-link bound: few,
+        large messages; the first bucket leaves after the output blocks' half of the sweep)."""
         self.module = module
         self.world = world_size
+        self.group = process_group
+        self.overlap = overlap
         cfg = module.configure_optimizers()
         self.optimizer = cfg["optimizer"]
         self.scheduler = cfg["lr_scheduler"]["scheduler"]
@@ -66,19 +82,51 @@ class DataParallelTrainer:
         elif ema_decay is not None:
             self._ema = {n: p.detach().clone() for n, p in module.named_parameters() if p.requires_grad}
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self._hooked = "on_bucket" in inspect.signature(module.step_and_backward).parameters
+        self.last_bucket_sizes = []   # elements of each bucket exchanged by the last step, in issue order (diagnostics / tests)
         if world_size > 1:
-            for p in module.parameters():  # replicas start identical (DDP's initial broadcast)
-                dist.broadcast(p.data, src=0)
+            with torch.no_grad():  # replicas start identical (DDP's initial broadcast); in place on the parameter
+                for p in module.parameters():  # itself (not p.data) so that its version counter moves and packed weights follow
+                    dist.broadcast(p, src=0, group=self.group)
+                torch._C._increment_version(list(module.parameters()))
+
+    # ------------------------------------------------------------------ exchange
+    def _allreduce_async(self, t: torch.Tensor):
+        """start the sum all-reduce of ``t`` (in place); returns a handle with ``wait()``.  NCCL/RCCL: the collective is
+        enqueued on the process group's own stream behind everything the current stream holds so far."""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True, group=self.group)
 
     def train_step(self, batch):
-        """loss, backward (HIP), gradient mean over ranks (one flat buffer, bucketed all-reduce), Adam, cosine LR."""
-        loss, flat = self.module.step_and_backward(batch)
+        """loss, backward (HIP) with the gradient exchange riding under it, Adam, cosine LR.  Returns the local loss (a device
+        scalar; no host sync here -- the reference's ``loss.item()`` logging, edm.py:138, belongs to the caller)."""
+        works = []
+        self.last_bucket_sizes = []
+        hook = None
+        if self.world > 1 and self.overlap and self._hooked:
+            def hook(sl):
+                self.last_bucket_sizes.append(sl.numel())
+                works.append(self._allreduce_async(sl))
+        if self._hooked:
+            loss, flat = self.module.step_and_backward(batch, on_bucket=hook, bucket_elems=self.bucket_elems)
+        else:
+            loss, flat = self.module.step_and_backward(batch)
+        if self.world > 1 and hook is None:
+            flats = list(flat) if isinstance(flat, (list, tuple)) else [flat]
+            for f in flats:
+                f1 = f.view(-1)
+                for i in range(0, f1.numel(), self.bucket_elems):
+                    self.last_bucket_sizes.append(min(self.bucket_elems, f1.numel() - i))
+                    works.append(self._allreduce_async(f1[i:i + self.bucket_elems]))
+        for w in works:   # (NCCL: makes the current stream wait for the exchange; the host does not block)
+            w.wait()
         if self.fused:
             # the 1 / world_size of the gradient mean rides in the optimizer launch
-            allreduce_mean_(flat, self.world, self.bucket_elems, scale=False)
             self.optimizer.step(grad_scale=1.0 / self.world)
         else:
-            allreduce_mean_(flat, self.world, self.bucket_elems)
+            if self.world > 1:
+                flats = list(flat) if isinstance(flat, (list, tuple)) else [flat]
+                for f in flats:
+                    f.mul_(1.0 / self.world)
             self.optimizer.step()
             if self._ema is not None:
                 with torch.no_grad():
