@@ -302,7 +302,9 @@ def main():
 
     import __graft_entry__
     if rank == 0:
-        __graft_entry__.build()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):   # (stdout carries the one JSON line only)
+            __graft_entry__.build()
     if world > 1:
         dist.barrier()
     from tqdne_amd import LightningEDM, paper_1d_unet_config, rng, tiny_1d_unet_config

@@ -25,7 +25,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define TQ_ABI_VERSION 1
+#define TQ_ABI_VERSION 2
 
 #define TQ_ERR_ARG (-1)   /* null / inconsistent pointer arguments */
 #define TQ_ERR_SHAPE (-2) /* unsupported shape */
@@ -66,6 +66,12 @@ typedef struct TqConvDesc {
     uint64_t dropout_seed;
     int32_t C_skip0, C_skip1; /* tq_conv1d_fwd_skip only: channels of the fused 1x1 skip conv's (concatenated) input; else 0 */
     int32_t wfmt;             /* TQ_WFMT_*: format of packed_w = contraction scheme of this launch */
+    /* Range guard of the fp16-range scheme (optional, NULL = off): with TQ_CONV_STATS the epilogue sets *range_flag = 1 when a
+     * channel's sum of squares over one 128-position slot reaches (65504 / 2)^2, i.e. when max|y| of the written tensor MAY exceed
+     * half of the fp16 range (max|y| <= sqrt(sum y^2)), or is not finite.  The caller polls the flag and moves the launches that
+     * read such a tensor un-normalised (fused 1x1 skip convs, up-sampling convs) to TQ_WFMT_BF16X3.  Device pointer, never reset
+     * by the library. */
+    int32_t* range_flag;
 } TqConvDesc;
 
 /* flags of TqConvBwdDesc.flags: which stages the FORWARD conv applied to its input */

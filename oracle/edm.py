@@ -116,9 +116,12 @@ def sample_deterministic(
     cond_sample=None,
     net_dtype=torch.float32,
     trace: Optional[Dict[int, Tensor]] = None,
+    stop_after: Optional[int] = None,
 ) -> Tensor:
     """edm.py:159-196.  ``start_unit_noise`` is the fp64 N(0,1) draw of edm.py:160
-    (multiplied here by sigmas[0], an fp32 scalar, as the reference does)."""
+    (multiplied here by sigmas[0], an fp32 scalar, as the reference does).
+    ``trace[i]`` receives the state after step i; ``stop_after`` ends the loop after that many steps (tests of the early
+    steps at sizes where the full loop would take minutes on the CPU)."""
     dt = torch.float64
     sigmas = sampling_sigmas(p, num_steps)
     x_next = start_unit_noise.to(dt) * sigmas[0]
@@ -134,6 +137,8 @@ def sample_deterministic(
             x_next = x + (s_next - s) * (0.5 * d_cur + 0.5 * d_prime)
         if trace is not None:
             trace[i + 1] = x_next.clone()
+        if stop_after is not None and i + 1 >= stop_after:
+            break
     return x_next
 
 

@@ -102,13 +102,15 @@ def main():
         # the two plans (B = 8 and B = 4) lay their gradients out identically (the layout depends on the model only)
         assert [grabbed["offs"][id(p)] for p in m.unet.parameters()] == [offs_full[id(p)] for p in full.unet.parameters()]
         err = rel_err(grabbed["g"].cpu(), g_full.cpu())
-        worst = 0.0
+        # per tensor, relative to that tensor's own scale; tensors whose true gradient is zero (a conv bias in front of a
+        # one-channel-per-group GroupNorm: the micro net has 32 channels) hold rounding noise only, hence the floor
+        worst, floor = 0.0, 1e-4 * float(g_full.abs().max())
         for p_l, p_f in zip(m.unet.parameters(), full.unet.parameters()):
             if not p_l.requires_grad:
                 continue
             o = offs_full[id(p_f)]
             a, b = grabbed["g"][o:o + p_l.numel()], g_full[o:o + p_l.numel()]
-            worst = max(worst, rel_err(a.cpu(), b.cpu()))
+            worst = max(worst, float((a - b).abs().max()) / max(float(b.abs().max()), floor))
         # replicas identical after the update
         chk = torch.cat([p.detach().reshape(-1) for p in m.unet.parameters()]).double().cpu()
         sums = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]

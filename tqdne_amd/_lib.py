@@ -44,6 +44,7 @@ class TqConvDesc(C.Structure):
         ("upsample", C.c_int32), ("flags", C.c_int32), ("emb_stride", C.c_int32),
         ("dropout_site", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("C_skip0", C.c_int32), ("C_skip1", C.c_int32), ("wfmt", C.c_int32),
+        ("range_flag", C.c_void_p),
     ]
 
 
@@ -132,7 +133,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-    if lib.tq_abi_version() != 1:
+    if lib.tq_abi_version() != 2:
         raise RuntimeError("libtqdne_hip.so ABI version mismatch")
     _LIB = lib
     return lib

@@ -137,7 +137,37 @@ def edm_loss(module, sample, eps, unit_noise, cond, cond_sample=None):
     return _EDMLossFn.apply(module, sample, eps, unit_noise, cond, cond_sample, *params)
 
 
-def denoise_with_grad(module, sample, sigma, cond):
-    raise NotImplementedError(
-        "LightningEDM.forward under autograd is only differentiable through LightningEDM.step (fused loss + backward)"
-    )
+class _DenoiseFn(th.autograd.Function):
+    """D(x; sigma) = c_skip x + c_out F(c_in x; c_noise) (reference edm.py:105-113) as an ordinary differentiable call: the HIP
+    forward in training mode (dropout active), and in backward the hand-written HIP backward seeded with the incoming gradient.
+    Differentiable with respect to the UNet parameters (what training code needs); not with respect to the input."""
+
+    @staticmethod
+    def forward(ctx, module, sample, sigma, cond, cond_sample, *params):
+        seed = rng.next_dropout_seed()
+        out = module._denoise_static(sample, sigma, 1, cond, train=True, dropout_seed=seed, cond_sample=cond_sample)
+        ctx.module, ctx.shape, ctx.dev, ctx.lane = module, tuple(sample.shape), sample.device, module._lane
+        ctx.concat = cond_sample is not None
+        ctx.eng = module.unet._engine(sample.shape[0], sample.shape[2], sample.device, module._lane)
+        ctx.fwd_id = ctx.eng._fwd_count
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        module, eng = ctx.module, ctx.eng
+        if eng._fwd_count != ctx.fwd_id:
+            raise RuntimeError("another forward of the same shape ran between this forward and its backward: the execution plan's "
+                               "static buffers no longer hold its activations (call backward before the next forward)")
+        B, _, T = ctx.shape
+        sc = module._scalars(B, ctx.dev)
+        one = th.ones((), device=ctx.dev)
+        grads = eng.backward(gout.contiguous().float(), one, c_out=sc[1], in_scale=None if ctx.concat else sc[0])
+        return (None, None, None, None, None) + tuple(grads)
+
+
+def denoise_with_grad(module, sample, sigma, cond, cond_sample=None):
+    """``LightningEDM.forward`` under autograd (train mode, grad enabled): see _DenoiseFn."""
+    if sample.requires_grad:
+        raise NotImplementedError("the HIP backward produces parameter gradients only; detach the input sample")
+    params = list(module.unet.parameters())
+    return _DenoiseFn.apply(module, sample, sigma, cond, cond_sample, *params)

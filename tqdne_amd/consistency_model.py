@@ -92,7 +92,11 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         if lanes > 1 and (B % lanes or torch.is_grad_enabled()):
             lanes = 1
         if lanes < 2:
-            return self._forward_static(sample, sigma, cond, infer=not torch.is_grad_enabled()).clone()
+            infer = not torch.is_grad_enabled()
+            y = self._forward_static(sample, sigma, cond, infer=infer).clone()
+            if infer and self.net._engine(B, sample.shape[2], sample.device, 0).check_range():
+                y = self._forward_static(sample, sigma, cond, infer=infer).clone()  # (the plan is on bf16x3 now)
+            return y
         # independent samples: sub-batches on separate HIP streams run out of phase (see LightningEDM.sample_deterministically)
         dev = sample.device
         h = B // lanes

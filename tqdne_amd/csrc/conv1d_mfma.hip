@@ -91,6 +91,7 @@ struct ConvArgs {
     unsigned char* kv;
     int kvH, kvD, kvTp;
     float kvscale;
+    int* range_flag;  // see TqConvDesc.range_flag
 };
 
 #ifndef TQ_STAGE_PRE
@@ -420,7 +421,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                 const Frag& c1 = w[cbk * 4 + 3];
                 const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
                 // E8M0 scales: A 127 (2^0), B 115 (2^-12) on every lane: both correction products carry 2^-12
+#ifdef TQ_ABL_FP6TIME
+                // ablation (wrong numerics): the same stream with the block-scaled MFMA at its fp6 issue rate (4 passes instead of 8)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, 127, 0, 115);
+#else
                 acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 0, 0, 0, 127, 0, 115);
+#endif
             }
         }
     };
@@ -730,6 +736,9 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                 float* st = p.stats + (((size_t)b * p.nslots + slot) * Cr + co) * 2;
                 *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
                 *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
+                // range guard: max|y| <= sqrt(sum of squares); (65504 / 2)^2 = 1.0727e9.  NaN / inf fail the comparison too
+                const float q = fmaxf(fmaxf(s2[cbk][0], s2[cbk][1]), fmaxf(s2[cbk][2], s2[cbk][3]));
+                if (p.range_flag && !(q < 1.0727e9f)) *p.range_flag = 1;
             }
         }
     }
@@ -990,6 +999,7 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.sx0 = skip_x0; a.sx1 = skip_x1; a.sbias = skip_bias; a.sC0 = d->C_skip0; a.sC1 = d->C_skip1;
     a.wfmt = d->wfmt;
     a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale;
+    a.range_flag = d->range_flag;
 
     if (d->stride == 2 || d->upsample) {
         if (a.flags & (TQ_CONV_GN | TQ_CONV_SILU | TQ_CONV_DROPOUT)) return TQ_ERR_SHAPE;  // resampling convs take raw inputs
@@ -1044,6 +1054,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.sx0 = a.sx1 = a.sbias = nullptr; a.sC0 = a.sC1 = 0;
     a.wfmt = TQ_WFMT_BF16X3;  // gradients keep fp32 range
     a.kv = nullptr; a.kvH = a.kvD = a.kvTp = 0; a.kvscale = 1.f;
+    a.range_flag = nullptr;
     switch (d->ktaps) {
         case 1: return dispatch_tile<1, 1, 0, 1, 0>(a, stream);
         case 3: return dispatch_tile<3, 1, 0, 1, 0>(a, stream);

@@ -120,6 +120,14 @@ class UNetEngine:
         self.ops: List[Tuple] = []          # launches of a forward whose backward may follow
         self.ops_infer: List[Tuple] = []    # same order and length; inference-only variants where they exist
         self.op_bytes: List[int] = []       # same order: algorithmic bytes per launch
+        # contraction scheme of the forward convs: "auto" = the fp16-range scheme (TQ_WFMT_F16_MX8) wherever it is built, "bf16x3" =
+        # fp32 range everywhere (after the range guard fired, or on request: model._conv_scheme / TQDNE_CONV_SCHEME)
+        self.scheme = "auto"
+        self.plan_epoch = 0
+        self._wfmt_sites = []               # (descriptor, [conv sites packed for it], preferred wfmt)
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=device)   # set by the conv epilogues (TqConvDesc.range_flag)
+        self._range_host = torch.zeros(1, dtype=torch.int32).pin_memory() if device.type == "cuda" else torch.zeros(1, dtype=torch.int32)
+        self._range_evt = None
         self._trace = None                  # list: HIP-event pairs around EVERY launch of the next forwards (measurement only)
         self.conv_sites: List[ConvSite] = []
         self.poly_sites: List[Tuple[ConvSite, ConvSite]] = []   # (derived two-phase k = 3 site, the Upsample conv it restates)
@@ -133,6 +141,8 @@ class UNetEngine:
         self._wt_version = None
         self._build()
         self._w_version = None
+        if getattr(model, "_conv_scheme", "auto") == "bf16x3":
+            self._set_scheme_bf16x3()
 
     # ------------------------------------------------------------------ allocation helpers
     def _empty(self, *shape, dtype=torch.float32):
@@ -227,6 +237,9 @@ class UNetEngine:
             site.pack_mode = 2 if d.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
             if skip is not None:
                 skip[1].pack_mode = site.pack_mode
+            self._wfmt_sites.append((d, [site] + ([skip[1]] if skip is not None else []), d.wfmt))
+            if stats:
+                d.range_flag = self.range_flag.data_ptr()
         d.dropout_site = dropout_site or 0
         d.dropout_p = 0.0
         d.dropout_seed = 0
@@ -281,6 +294,9 @@ class UNetEngine:
         d2.emb_stride = 0
         d2.wfmt = _lib.forward_wfmt(2 * Cr, [d.C_in0, d.C_in1])
         ps.pack_mode = 2 if d2.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+        self._wfmt_sites.append((d2, [ps], d2.wfmt))
+        if d2.flags & TQ_CONV_STATS:
+            d2.range_flag = self.range_flag.data_ptr()
         self._keep.append(d2)
         return (self.lib.tq_conv1d_fwd, (
             C.byref(d2), _p(s0.buf), _p(s1.buf) if s1 else None, None, None, _p(ps.packed), _p(site.bias), None, None,
@@ -434,6 +450,58 @@ class UNetEngine:
         self._probe = Probe(idx, self.ops[idx][2], self.ops[idx][3])
         return self._probe
 
+    # ------------------------------------------------------------------ range guard of the fp16-range scheme
+    def _set_scheme_bf16x3(self):
+        """Move every forward launch of the plan to the fp32-range three-product scheme (descriptors are edited in place, the
+        weights are re-packed in that format on the next forward)."""
+        for d, sites, _pref in self._wfmt_sites:
+            d.wfmt = _lib.TQ_WFMT_BF16X3
+            for st in sites:
+                st.pack_mode = 0
+        if getattr(self, "emb_desc", None) is not None:
+            self.emb_desc.wfmt = _lib.TQ_WFMT_BF16X3
+            self.emb_pack_mode = 0
+        self.scheme = "bf16x3"
+        self._w_version = None   # forces the re-pack
+        self.plan_epoch += 1     # captured HIP graphs of this plan are stale
+
+    def _range_fallback(self):
+        import warnings
+        warnings.warn("tqdne_amd: activations approach the fp16 range (a tensor's 128-position sum of squares reached (65504/2)^2); "
+                      "the forward convolutions of this model now run in the fp32-range bf16x3 scheme", RuntimeWarning)
+        self.range_flag.zero_()
+        self.m._conv_scheme = "bf16x3"           # plans built later start there
+        for eng in getattr(self.m, "_engine_cache", {}).values():
+            if eng.scheme == "auto":
+                eng._set_scheme_bf16x3()
+        if self.scheme == "auto":
+            self._set_scheme_bf16x3()
+
+    def check_range(self) -> bool:
+        """Read the range-guard flag now (synchronises).  True: the flag was set -- the plan has been moved to bf16x3 and the
+        caller should repeat the computation whose launches raised it."""
+        if self.scheme != "auto":
+            return False
+        if int(self.range_flag.item()) != 0:
+            self._range_fallback()
+            return True
+        return False
+
+    def _range_poll(self, begin: bool):
+        """Deferred form for loops that must not synchronise (training steps): the flag is copied to pinned host memory after a
+        forward and looked at before a later one, once the copy has completed."""
+        if self.scheme != "auto" or torch.cuda.is_current_stream_capturing():
+            return
+        if begin:
+            if self._range_evt is not None and self._range_evt.query():
+                self._range_evt = None
+                if int(self._range_host[0]) != 0:
+                    self._range_fallback()
+        elif self._range_evt is None:
+            self._range_host.copy_(self.range_flag, non_blocking=True)
+            self._range_evt = torch.cuda.Event()
+            self._range_evt.record()
+
     # ------------------------------------------------------------------ weights
     def _weights_version(self):
         v = 0
@@ -502,6 +570,7 @@ class UNetEngine:
             cond = cond.contiguous().float()
             ncond = cond.shape[1]
         stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self._range_poll(True)
         self.repack(stream)
         p = float(m.dropout) if train else 0.0
         for d in self.dropout_descs:
@@ -564,6 +633,7 @@ class UNetEngine:
                     rc = fn(*args, stream)
                 if rc:
                     check(rc, what)
+        self._fwd_count = getattr(self, "_fwd_count", 0) + 1
         self._last = dict(x=x, in_scale=in_scale, c_out=c_out, timesteps=timesteps, cond=cond, train=train,
                           dropout_p=p, dropout_seed=dropout_seed, infer=infer and not train)
         head = m.out[2]
@@ -574,6 +644,8 @@ class UNetEngine:
         if ev:
             trace.append(("head", 2 * B * T * self.final.C * m.out_channels * head.kernel_size[0],
                           4 * B * T * (self.final.C + 2 * m.out_channels), e0, ev()))
+        if train:
+            self._range_poll(False)
         return self.out_nct
 
     # ------------------------------------------------------------------ backward

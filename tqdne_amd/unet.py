@@ -182,6 +182,7 @@ class UNetModel(nn.Module):
 
         self.out = nn.Sequential(_gn(ch), nn.SiLU(), _zero(nn.Conv1d(input_ch, out_channels, k, padding="same")))
         self._engine_cache = {}
+        self._conv_scheme = "auto"   # "bf16x3" once the range guard of the fp16-range scheme has fired (engine.py)
 
     # ------------------------------------------------------------------ execution
     def _engine(self, B: int, T: int, device: torch.device, lane: int = 0) -> "engine.UNetEngine":
@@ -200,8 +201,11 @@ class UNetModel(nn.Module):
         )
         engine.require_device(x)
         eng = self._engine(x.shape[0], x.shape[2], x.device)
-        y = eng.forward(x, timesteps, cond, train=self.training and torch.is_grad_enabled())
-        return y.clone()
+        train = self.training and torch.is_grad_enabled()
+        y = eng.forward(x, timesteps, cond, train=train).clone()
+        if not train and eng.check_range():   # activations near the fp16 range: the plan is on bf16x3 now, repeat
+            y = eng.forward(x, timesteps, cond, train=train).clone()
+        return y
 
     def _apply(self, fn, *a, **k):  # parameters moved (.to / .cuda): compiled plans hold stale pointers
         self._engine_cache = {}
