@@ -194,9 +194,14 @@ extern "C" int tq_stem_conv_fwd(const float* x, const float* in_scale, const flo
 }
 
 // =================================================================================================
-// Head: GroupNorm+SiLU (folded) -> conv k "same" to C_out<=4 -> NCW output with the EDM / consistency
-// skip connection folded in.  One workgroup per (b, 128 positions); the activated tile is transposed
-// into LDS as [ci][t] so that lanes (consecutive t) read consecutive words.
+// Head: GroupNorm+SiLU (folded) -> conv k "same" to C_out <= 16 -> NCW output with the EDM / consistency skip connection folded
+// in (unet.py:355-357,398; edm.py:111-113).  HBM-bound: the (B, T, C_in) input is read once.
+// One workgroup per (b, 128 output positions), "row stationary": four threads share one input row (position), each activates its
+// quarter of the channels (16-byte loads, a quad reads 64 contiguous bytes per instruction) and forms that row's KT x C_out
+// partial dot products against the weights (LDS, broadcast reads); the quad sums them with two cross-lane steps and parks the
+// row's KT x C_out sums in LDS; after one barrier output (t, co) adds the KT entries of rows t .. t + KT - 1.
+// (The first version staged a transposed [ci][t] tile; its output was found corrupted when an attention kernel ran on the same CU
+// from another stream -- every launch of the plan is now also checked under that kind of concurrency, tests/test_concurrency.py.)
 // =================================================================================================
 namespace {
 template <int KT, int MAXCO>
@@ -205,14 +210,14 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ bias, const float* __restrict__ c_out,
                                                         const float* __restrict__ c_skip, const float* __restrict__ skip_src,
                                                         float* __restrict__ y, int T, int C_in, int C_out, int ntiles) {
-    extern __shared__ float shm[];
+    extern __shared__ __attribute__((aligned(16))) float shm[];
     constexpr int PAD = KT / 2;
     constexpr int TW = 128 + KT - 1;
-    constexpr int LD = TW + 1;  // odd leading dimension: conflict-free transposed writes
-    float* xs = shm;             // [C_in][LD]
-    float* part = xs + C_in * LD;  // [128][MAXCO]
-    float* wl = part + 128 * MAXCO;  // [C_in][KT][MAXCO] weights, co fastest (broadcast reads)
-    for (int i = threadIdx.x; i < C_in * KT * MAXCO; i += 256) {
+    constexpr int NP = KT * MAXCO;     // partial sums per input row
+    constexpr int MAXV = 8;            // float4 per thread and row: C_in <= 128
+    float* wl = shm;                   // [C_in][KT][MAXCO] weights, co fastest (16-byte broadcast reads)
+    float* part = wl + C_in * NP;      // [TW][NP]
+    for (int i = threadIdx.x; i < C_in * NP; i += 256) {
         const int co = i % MAXCO, r = i / MAXCO;
         const int k = r % KT, ci = r / KT;
         wl[i] = (co < C_out) ? w[((size_t)co * C_in + ci) * KT + k] : 0.f;
@@ -220,55 +225,78 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     const int tile = blockIdx.x % ntiles;
     const int b = blockIdx.x / ntiles;
     const int t0 = tile * 128;
-    const int nc4 = C_in >> 2;
-    for (int i = threadIdx.x; i < TW * nc4; i += 256) {
-        const int c4 = i % nc4, j = i / nc4;
-        const int t = t0 - PAD + j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < T) {
-            v = *reinterpret_cast<const float4*>(x + ((size_t)b * T + t) * C_in + 4 * c4);
-            if (gscale) {
-                const float4 a = *reinterpret_cast<const float4*>(gscale + (size_t)b * C_in + 4 * c4);
-                const float4 s = *reinterpret_cast<const float4*>(gshift + (size_t)b * C_in + 4 * c4);
-                v.x = silu_f(a.x * v.x + s.x); v.y = silu_f(a.y * v.y + s.y);
-                v.z = silu_f(a.z * v.z + s.z); v.w = silu_f(a.w * v.w + s.w);
+    const int q = threadIdx.x & 3;
+    const int nv = C_in >> 4;          // float4 per thread and row (the quad covers C_in channels: 4 threads x nv x 4)
+    // folded GroupNorm coefficients of this thread's channels: float4 number q + 4 j
+    float4 ga[MAXV], gs[MAXV];
+#pragma unroll
+    for (int jv = 0; jv < MAXV; ++jv) {
+        ga[jv] = make_float4(1.f, 1.f, 1.f, 1.f); gs[jv] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gscale && jv < nv) {
+            ga[jv] = *reinterpret_cast<const float4*>(gscale + (size_t)b * C_in + 4 * (q + 4 * jv));
+            gs[jv] = *reinterpret_cast<const float4*>(gshift + (size_t)b * C_in + 4 * (q + 4 * jv));
+        }
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < TW; r0 += 64) {
+        const int r = r0 + (threadIdx.x >> 2);
+        if (r < TW) {  // (a quad is active or idle as a whole: the cross-lane sums below stay inside it)
+            const int t = t0 - PAD + r;
+            float acc[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc[i] = 0.f;
+            if (t >= 0 && t < T) {
+                const float* xr = x + ((size_t)b * T + t) * C_in;
+#pragma unroll
+                for (int jv = 0; jv < MAXV; ++jv) {
+                    if (jv < nv) {
+                        const int c4 = q + 4 * jv;
+                        const float4 v4 = *reinterpret_cast<const float4*>(xr + 4 * c4);
+                        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                        if (gscale) {
+                            const float a[4] = {ga[jv].x, ga[jv].y, ga[jv].z, ga[jv].w};
+                            const float sh[4] = {gs[jv].x, gs[jv].y, gs[jv].z, gs[jv].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = silu_f(fmaf(a[e], v[e], sh[e]));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float4* wr = reinterpret_cast<const float4*>(wl + (size_t)(4 * c4 + e) * NP);
+#pragma unroll
+                            for (int i4 = 0; i4 < NP / 4; ++i4) {
+                                const float4 ww = wr[i4];
+                                acc[4 * i4 + 0] = fmaf(ww.x, v[e], acc[4 * i4 + 0]);
+                                acc[4 * i4 + 1] = fmaf(ww.y, v[e], acc[4 * i4 + 1]);
+                                acc[4 * i4 + 2] = fmaf(ww.z, v[e], acc[4 * i4 + 2]);
+                                acc[4 * i4 + 3] = fmaf(ww.w, v[e], acc[4 * i4 + 3]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                acc[i] += __shfl_xor(acc[i], 1);
+                acc[i] += __shfl_xor(acc[i], 2);
+            }
+            if (q == 0) {
+                float4* pr = reinterpret_cast<float4*>(part + (size_t)r * NP);
+#pragma unroll
+                for (int i4 = 0; i4 < NP / 4; ++i4) pr[i4] = make_float4(acc[4 * i4], acc[4 * i4 + 1], acc[4 * i4 + 2], acc[4 * i4 + 3]);
             }
         }
-        xs[(4 * c4 + 0) * LD + j] = v.x; xs[(4 * c4 + 1) * LD + j] = v.y;
-        xs[(4 * c4 + 2) * LD + j] = v.z; xs[(4 * c4 + 3) * LD + j] = v.w;
     }
     __syncthreads();
-    const int tl = threadIdx.x & 127;
-    const int half = threadIdx.x >> 7;
-    const int c_lo = half * (C_in >> 1), c_hi = c_lo + (C_in >> 1);
-    float acc[MAXCO];
-#pragma unroll
-    for (int co = 0; co < MAXCO; ++co) acc[co] = 0.f;
-    for (int ci = c_lo; ci < c_hi; ++ci) {
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            const float xv = xs[ci * LD + tl + k];
-            const float* wr = wl + (ci * KT + k) * MAXCO;
-#pragma unroll
-            for (int co = 0; co < MAXCO; ++co) acc[co] = fmaf(wr[co], xv, acc[co]);
-        }
-    }
-    if (half == 1) {
-#pragma unroll
-        for (int co = 0; co < MAXCO; ++co) part[tl * MAXCO + co] = acc[co];
-    }
-    __syncthreads();
-    if (half == 0) {
+    for (int o = threadIdx.x; o < 128 * C_out; o += 256) {
+        const int co = o >> 7, tl = o & 127;
         const int t = t0 + tl;
         if (t < T) {
+            float v = bias ? bias[co] : 0.f;
 #pragma unroll
-            for (int co = 0; co < MAXCO; ++co) {
-                if (co >= C_out) break;
-                float v = acc[co] + part[tl * MAXCO + co] + (bias ? bias[co] : 0.f);
-                const size_t o = ((size_t)b * C_out + co) * T + t;
-                if (c_out) v = v * c_out[b] + c_skip[b] * skip_src[o];
-                y[o] = v;
-            }
+            for (int k = 0; k < KT; ++k) v += part[(size_t)(tl + k) * NP + k * MAXCO + co];
+            const size_t oo = ((size_t)b * C_out + co) * T + t;
+            if (c_out) v = v * c_out[b] + c_skip[b] * skip_src[oo];
+            y[oo] = v;
         }
     }
 }
@@ -280,15 +308,14 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
     if (!x || !w || !y) return TQ_ERR_ARG;
     if ((gscale == nullptr) != (gshift == nullptr)) return TQ_ERR_ARG;
     if (c_out && (!c_skip || !skip_src)) return TQ_ERR_ARG;
-    if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || C_out < 1 || C_out > 16) return TQ_ERR_SHAPE;
+    if (B <= 0 || T <= 0 || C_in < 16 || C_in % 16 || C_in > 128 || C_out < 1 || C_out > 16) return TQ_ERR_SHAPE;
     const int ntiles = (T + 127) / 128;
     const int maxco = C_out <= 4 ? 4 : 16;
-    const size_t sh = ((size_t)C_in * (128 + ktaps) + 128 * maxco + (size_t)C_in * ktaps * maxco) * sizeof(float);
-    if (sh > 160 * 1024) return TQ_ERR_SHAPE;
+    const size_t sh = ((size_t)C_in * ktaps * maxco + (size_t)(128 + ktaps - 1) * ktaps * maxco) * sizeof(float);
+    if (sh > 64 * 1024) return TQ_ERR_SHAPE;
 #define TQ_HEAD(K)                                                                                          \
     {                                                                                                       \
         auto kern = (maxco == 4) ? head_conv_kernel<K, 4> : head_conv_kernel<K, 16>;                        \
-        if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL(kern, dim3(B * ntiles), dim3(256), sh, stream, x, gscale, gshift, w, bias, c_out, c_skip, skip_src, y, T, C_in, C_out, ntiles); \
     }
     if (ktaps == 5) TQ_HEAD(5)
