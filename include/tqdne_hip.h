@@ -230,6 +230,35 @@ int tq_heun_correct(const double* x, const double* x_next, const float* denoised
 /* x64 = unit_noise64 * sigma0; x32 = (float)x64   (edm.py:160) */
 int tq_sampler_init(const double* unit_noise, const float* sigma0, double* x, float* x32, size_t n, hipStream_t stream);
 
+/* Stochastic (churned) sampler, edm.py:198-230: the temporary noise increase x_hat = x + (n * S_noise) * c (lines 205-208), c =
+ * sqrt(sigma_hat^2 - sigma^2) formed by the caller in fp32 as the reference does (device scalar).  The Euler / correction steps are
+ * tq_heun_euler / tq_heun_correct with sigma_hat in place of sigma (lines 217-228). */
+int tq_heun_churn(const double* x, const double* unit_noise, const float* coef, double s_noise, double* x_hat, float* x32,
+                  size_t n, hipStream_t stream);
+
+/* out[b] = x[b] + noise[b] * sigma[b]: the two noised copies of the iCT training step (consistency_model.py:150-160). */
+int tq_axpy_sigma(const float* x, const float* noise, const float* sigma, float* out, int B, int n_per_sample,
+                  hipStream_t stream);
+
+/* Weighted pseudo-Huber distance of improved consistency training (consistency_model.py:163-173):
+ * loss = mean(w_b (sqrt((pred - target)^2 + c^2) - c)); dpred (nullable) = d loss / d pred.  loss_out is overwritten. */
+int tq_pseudo_huber_loss(const float* pred, const float* target, const float* weight, float c, float* loss_out, float* dpred,
+                         int B, int n_per_sample, hipStream_t stream);
+
+/* Mean squared error (autoencoder.py:61-63): loss_out = mean((a - b)^2) (overwritten), d (nullable) = 2 (a - b) / n. */
+int tq_mse_loss(const float* a, const float* b, float* loss_out, float* d, size_t n, hipStream_t stream);
+
+/* VAE bottleneck (autoencoder.py:37-43,64-66).  enc (B, 2L, T) = [mean | log_std]; eps, z, dz (B, L, T).
+ * fwd: z = mean + eps exp(log_std); kl_out (nullable, overwritten) = mean over (b, t) of 0.5 sum_c (mean^2 + std^2 - 2 log_std - 1).
+ * bwd: denc (B, 2L, T) = [dz + kw mean | dz eps std + kw (std^2 - 1)], kw = kl_weight / (B T). */
+int tq_vae_reparam_fwd(const float* enc, const float* eps, float* z, float* kl_out, int B, int L, int T, hipStream_t stream);
+int tq_vae_reparam_bwd(const float* enc, const float* eps, const float* dz, float* denc, float kl_weight, int B, int L, int T,
+                       hipStream_t stream);
+
+/* Stem input of a signal-conditioned model (edm.py:108-109): out (B, C0 + C1, T) = [x * scale[b] | cond_signal]; scale nullable. */
+int tq_concat_scale(const float* x, const float* scale, const float* cond_signal, float* out, int B, int C0, int C1, int T,
+                    hipStream_t stream);
+
 /* ---- optimizer (edm.py:240-251, ema.py:24-28) ------------------------------------------------------------- */
 /* One launch for the whole model: torch.optim.Adam's update (no weight decay, no amsgrad) on every chunk of the table,
  *   g' = g * grad_scale;  m += (1 - beta1) (g' - m);  v = beta2 v + (1 - beta2) g'^2;

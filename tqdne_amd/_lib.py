@@ -88,6 +88,13 @@ _PROTOS = {
     "tq_heun_euler": (I, [VP] * 7 + [SZ, VP]),
     "tq_heun_correct": (I, [VP] * 8 + [SZ, VP]),
     "tq_sampler_init": (I, [VP] * 4 + [SZ, VP]),
+    "tq_heun_churn": (I, [VP, VP, VP, C.c_double, VP, VP, SZ, VP]),
+    "tq_axpy_sigma": (I, [VP, VP, VP, VP, I, I, VP]),
+    "tq_pseudo_huber_loss": (I, [VP, VP, VP, F, VP, VP, I, I, VP]),
+    "tq_mse_loss": (I, [VP, VP, VP, VP, SZ, VP]),
+    "tq_vae_reparam_fwd": (I, [VP, VP, VP, VP, I, I, I, VP]),
+    "tq_vae_reparam_bwd": (I, [VP, VP, VP, VP, F, I, I, I, VP]),
+    "tq_concat_scale": (I, [VP, VP, VP, VP, I, I, I, I, VP]),
     "tq_envelope_fwd": (I, [VP, VP, I, I, I, I, C.c_double, C.c_double, VP]),
     "tq_envelope_inv": (I, [VP, VP, I, I, I, C.c_double, C.c_double, VP]),
     "tq_adam_ema_step": (I, [VP, I] + [C.c_double] * 8 + [VP]),

@@ -155,9 +155,14 @@ class LightningAutoencoder(LightningModule):
 
     def _encode(self, x, unit_noise=None):
         """autoencoder.py:37-40.  ``unit_noise`` (optional) injects the N(0,1) draw of ``randn_like(mean)``."""
-        mean, log_std = th.chunk(self.encoder(x), 2, dim=1)
-        eps = th.randn_like(mean) if unit_noise is None else unit_noise
-        latent = mean + eps * th.exp(log_std)  # (B, latent, T/ds) elementwise: 1/100 of an encoder conv
+        from . import _lib
+        enc = self.encoder(x)
+        mean, log_std = th.chunk(enc, 2, dim=1)
+        eps = (th.randn_like(mean) if unit_noise is None else unit_noise).contiguous().float()
+        latent = th.empty_like(eps)
+        B, L, Tl = eps.shape
+        _lib.check(_lib.load().tq_vae_reparam_fwd(enc.data_ptr(), eps.data_ptr(), latent.data_ptr(), None, B, L, Tl,
+                                                  th.cuda.current_stream(x.device).cuda_stream), "vae reparam")
         return latent, mean, log_std
 
     def encode(self, x):
@@ -184,25 +189,37 @@ class LightningAutoencoder(LightningModule):
         x = x.contiguous()
         train = self.training
         seed = rng.next_dropout_seed()
+        from . import _lib
+        from ._lib import check
+        lib = _lib.load()
+        _p = lambda t: None if t is None else t.data_ptr()
         with th.no_grad():
+            stream = th.cuda.current_stream(x.device).cuda_stream
             e_eng = _seq_engine(self.encoder, x)
-            enc = e_eng.forward(x, train=train, dropout_seed=seed)
-            mean, log_std = th.chunk(enc, 2, dim=1)
-            eps = th.randn_like(mean) if unit_noise is None else unit_noise
-            std = th.exp(log_std)
-            z = (mean + eps * std).contiguous()
-            d_eng = _seq_engine(self.decoder, z)
-            recon = d_eng.forward(z, train=train, dropout_seed=seed ^ 0x9E3779B97F4A7C15)
-            diff = recon - x
-            recon_loss = th.mean(diff * diff)
-            kl = th.mean(0.5 * th.sum(mean * mean + std * std - 2 * log_std - 1, dim=1))
+            enc = e_eng.forward(x, train=train, dropout_seed=seed)            # (B, 2L, T') = [mean | log_std], static buffer
+            B, L2, Tl = enc.shape
+            L = L2 // 2
+            key = ("ae", tuple(enc.shape), str(x.device))
+            bufs = getattr(self, "_ae_bufs", {}).get(key)
+            if bufs is None:
+                f = lambda *sh: th.empty(*sh, device=x.device)
+                bufs = dict(z=f(B, L, Tl), kl=f(1), rl=f(1), drecon=th.empty_like(x), denc=f(B, L2, Tl))
+                self.__dict__.setdefault("_ae_bufs", {})[key] = bufs
+            eps = (th.randn(B, L, Tl, device=x.device) if unit_noise is None else unit_noise).contiguous()
+            # z = mean + eps * exp(log_std) and the KL term in one launch (autoencoder.py:37-43, 64-66)
+            check(lib.tq_vae_reparam_fwd(_p(enc), _p(eps), _p(bufs["z"]), _p(bufs["kl"]), B, L, Tl, stream), "vae reparam")
+            d_eng = _seq_engine(self.decoder, bufs["z"])
+            recon = d_eng.forward(bufs["z"], train=train, dropout_seed=seed ^ 0x9E3779B97F4A7C15)
+            check(lib.tq_mse_loss(_p(recon), _p(x), _p(bufs["rl"]), _p(bufs["drecon"]) if want_grads else None, x.numel(), stream),
+                  "mse loss")
+            recon_loss, kl = bufs["rl"][0].clone(), bufs["kl"][0].clone()
             if not want_grads:
                 return recon_loss, kl, None
-            g_dec, dz = d_eng.backward(diff * (2.0 / diff.numel()), want_dx=True, clone=True)
-            n_kl = mean.shape[0] * mean.shape[2]  # kl is a mean over (batch, time) of a sum over channels
-            d_mean = dz + mean * (self.kl_weight / n_kl)
-            d_ls = dz * eps * std + (std * std - 1.0) * (self.kl_weight / n_kl)
-            g_enc, _ = e_eng.backward(th.cat((d_mean, d_ls), dim=1), want_dx=False, clone=True)
+            g_dec, dz = d_eng.backward(bufs["drecon"], want_dx=True, clone=True)
+            # d loss / d [mean | log_std] from d z and the KL term (kl is a mean over (batch, time) of a sum over channels)
+            check(lib.tq_vae_reparam_bwd(_p(enc), _p(eps), _p(dz.contiguous()), _p(bufs["denc"]), float(self.kl_weight), B, L, Tl, stream),
+                  "vae reparam bwd")
+            g_enc, _ = e_eng.backward(bufs["denc"], want_dx=False, clone=True)
         return recon_loss, kl, list(g_enc) + list(g_dec)
 
     def step(self, batch, stage="training"):

@@ -31,19 +31,30 @@ class _ICTLossFn(torch.autograd.Function):
         B, nd = sample.shape[0], sample.dim()
         seed = rng.next_dropout_seed()  # one seed: teacher = student masks
         train = module.training
+        lib = _lib.load()
+        dev = sample.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
         t_sig, s_sig = sigmas[timesteps].float().contiguous(), sigmas[timesteps + 1].float().contiguous()
-        exp = lambda v: v[(...,) + (None,) * (nd - 1)]
-        target = module._forward_static((sample + epsilon * exp(t_sig)).contiguous(), t_sig, cond, train=train,
-                                        dropout_seed=seed).clone()
-        pred = module._forward_static((sample + epsilon * exp(s_sig)).contiguous(), s_sig, cond, train=train, dropout_seed=seed)
+        per = sample[0].numel()
+        key = ("ict", tuple(sample.shape), str(dev))
+        bufs = module._scal.get(key)
+        if bufs is None:
+            bufs = dict(xt=torch.empty_like(sample), xs=torch.empty_like(sample), target=torch.empty_like(sample),
+                        dpred=torch.empty_like(sample), loss=torch.empty(1, device=dev))
+            module._scal[key] = bufs
+        epsilon = epsilon.contiguous()
+        # the two noised copies (consistency_model.py:150-160), teacher first (no gradient, same dropout masks as the student)
+        check(lib.tq_axpy_sigma(_p(sample), _p(epsilon), _p(t_sig), _p(bufs["xt"]), B, per, stream), "noise (teacher)")
+        check(lib.tq_axpy_sigma(_p(sample), _p(epsilon), _p(s_sig), _p(bufs["xs"]), B, per, stream), "noise (student)")
+        bufs["target"].copy_(module._forward_static(bufs["xt"], t_sig, cond, train=train, dropout_seed=seed))
+        pred = module._forward_static(bufs["xs"], s_sig, cond, train=train, dropout_seed=seed)
         c = 0.00054 * float(np.sqrt(np.prod(sample.shape[2:])))
-        diff = pred - target
-        root = torch.sqrt(diff * diff + c * c)
-        w = exp((1 / (sigmas[1:] - sigmas[:-1]))[timesteps].float())
-        loss = ((root - c) * w).mean()
+        w = (1 / (sigmas[1:] - sigmas[:-1]))[timesteps].float().contiguous()   # (B,) weights: indexing glue, as the schedule
+        check(lib.tq_pseudo_huber_loss(_p(pred), _p(bufs["target"]), _p(w), c, _p(bufs["loss"]), _p(bufs["dpred"]), B, per, stream),
+              "pseudo-Huber loss")
         ctx.module, ctx.shape = module, tuple(sample.shape)
-        ctx.dpred = (diff / root * w / diff.numel()).contiguous()  # d loss / d prediction
-        return loss
+        ctx.dpred = bufs["dpred"]
+        return bufs["loss"][0].clone()
 
     @staticmethod
     def backward(ctx, gloss):

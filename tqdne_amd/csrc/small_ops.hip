@@ -586,6 +586,117 @@ __global__ void sampler_init_kernel(const double* __restrict__ z, const float* _
     }
 }
 
+// Stochastic ("churned") sampler, the temporary noise increase of edm.py:205-208:  x_hat = x + (n * S_noise) * c, with the fp64
+// state x, the fp64 unit draw n and c = sqrt(sigma_hat^2 - sigma^2) formed by the caller in fp32 exactly as the reference does
+// with its 0-dim fp32 tensors (a device scalar, promoted to fp64 here like torch's type promotion does).
+__global__ void heun_churn_kernel(const double* __restrict__ x, const double* __restrict__ unit, const float* __restrict__ coef,
+                                  double s_noise, double* __restrict__ xh, float* __restrict__ x32, size_t n) {
+    const double c = (double)*coef;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double r = x[i] + (unit[i] * s_noise) * c;
+        xh[i] = r;
+        x32[i] = (float)r;
+    }
+}
+
+// out[b, :] = x[b, :] + noise[b, :] * sigma[b]   (consistency_model.py:150-160: the two noised copies of the iCT step; also
+// edm.py:128-129 with a given sigma)
+__global__ void axpy_sigma_kernel(const float* __restrict__ x, const float* __restrict__ nz, const float* __restrict__ sigma,
+                                  float* __restrict__ out, int per) {
+    const int b = blockIdx.y;
+    const float s = sigma[b];
+    const size_t base = (size_t)b * per;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x)
+        out[base + i] = x[base + i] + nz[base + i] * s;
+}
+
+// Weighted pseudo-Huber distance of the improved consistency training step (consistency_model.py:163-173):
+//   loss = mean_{b,i} w_b * (sqrt((pred - target)^2 + c^2) - c);   dpred = w_b * (pred - target) / sqrt(.) / n
+__global__ __launch_bounds__(256) void pseudo_huber_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           const float* __restrict__ wgt, float c, float* __restrict__ loss,
+                                                           float* __restrict__ dpred, int per, float inv_n) {
+    const int b = blockIdx.y;
+    const float w = wgt[b];
+    const size_t base = (size_t)b * per;
+    const float c2 = c * c;
+    float a = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+        const float d = pred[base + i] - target[base + i];
+        const float root = sqrtf(d * d + c2);
+        a += w * (root - c);
+        if (dpred) dpred[base + i] = d / root * w * inv_n;
+    }
+    a = wave_sum(a);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (ws[0] + ws[1] + ws[2] + ws[3]) * inv_n);
+}
+
+// Mean squared error and its gradient (autoencoder.py:61-63): loss += sum (a - b)^2 / n, d = 2 (a - b) / n
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ loss,
+                                                  float* __restrict__ d, size_t n, float inv_n) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float df = a[i] - b[i];
+        acc += df * df;
+        if (d) d[i] = 2.0f * df * inv_n;
+    }
+    acc = wave_sum(acc);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (ws[0] + ws[1] + ws[2] + ws[3]) * inv_n);
+}
+
+// VAE bottleneck (autoencoder.py:37-43, 64-66; blocks.py:233-260): enc (B, 2L, T) = [mean | log_std] on the channel axis.
+//   forward : z = mean + eps * exp(log_std);  kl += mean_{b,t} 0.5 * sum_c (mean^2 + exp(2 log_std) - 2 log_std - 1)
+//   backward: d mean = dz + kw * mean,  d log_std = dz * eps * std + kw * (std^2 - 1),  kw = kl_weight / (B * T)
+__global__ __launch_bounds__(256) void vae_reparam_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ eps,
+                                                              float* __restrict__ z, float* __restrict__ kl, int L, int T,
+                                                              size_t n, float inv_bt) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t lt = (size_t)L * T;
+        const size_t b = i / lt, r = i - b * lt;
+        const float m = enc[b * 2 * lt + r], ls = enc[b * 2 * lt + lt + r];
+        const float sd = expf(ls);
+        z[i] = m + eps[i] * sd;
+        acc += 0.5f * (m * m + sd * sd - 2.0f * ls - 1.0f);
+    }
+    if (kl) {
+        acc = wave_sum(acc);
+        __shared__ float ws[4];
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(kl, (ws[0] + ws[1] + ws[2] + ws[3]) * inv_bt);
+    }
+}
+
+__global__ void vae_reparam_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ eps, const float* __restrict__ dz,
+                                       float* __restrict__ denc, int L, int T, size_t n, float kw) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t lt = (size_t)L * T;
+        const size_t b = i / lt, r = i - b * lt;
+        const float m = enc[b * 2 * lt + r], ls = enc[b * 2 * lt + lt + r];
+        const float sd = expf(ls);
+        const float g = dz[i];
+        denc[b * 2 * lt + r] = g + kw * m;
+        denc[b * 2 * lt + lt + r] = g * eps[i] * sd + kw * (sd * sd - 1.0f);
+    }
+}
+
+// The stem input of a model conditioned on a signal (edm.py:108-109): out (B, C0 + C1, T) = [x * scale_b | cond_signal]
+__global__ void concat_scale_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ cs,
+                                    float* __restrict__ out, int C0, int C1, int T, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t ct = (size_t)(C0 + C1) * T;
+        const size_t b = i / ct, r = i - b * ct;
+        const size_t c = r / T, t = r - c * T;
+        out[i] = (c < (size_t)C0) ? x[(b * C0 + c) * T + t] * (scale ? scale[b] : 1.0f) : cs[(b * C1 + (c - C0)) * T + t];
+    }
+}
+
 inline unsigned ew_grid(size_t n) {
     size_t g = (n + 255) / 256;
     return (unsigned)(g > 2048 ? 2048 : (g ? g : 1));
@@ -656,6 +767,77 @@ extern "C" int tq_sampler_init(const double* unit_noise, const float* sigma0, do
                                hipStream_t stream) {
     if (!unit_noise || !sigma0 || !x || !x32 || n == 0) return TQ_ERR_ARG;
     hipLaunchKernelGGL(sampler_init_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, unit_noise, sigma0, x, x32, n);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_heun_churn(const double* x, const double* unit_noise, const float* coef, double s_noise, double* x_hat,
+                             float* x32, size_t n, hipStream_t stream) {
+    if (!x || !unit_noise || !coef || !x_hat || !x32 || n == 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(heun_churn_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, unit_noise, coef, s_noise, x_hat, x32, n);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_axpy_sigma(const float* x, const float* noise, const float* sigma, float* out, int B, int n_per_sample,
+                             hipStream_t stream) {
+    if (!x || !noise || !sigma || !out || B <= 0 || n_per_sample <= 0) return TQ_ERR_ARG;
+    const int gx = (n_per_sample + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(axpy_sigma_kernel, dim3(gx, B), dim3(256), 0, stream, x, noise, sigma, out, n_per_sample);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_pseudo_huber_loss(const float* pred, const float* target, const float* weight, float c, float* loss_out,
+                                    float* dpred, int B, int n_per_sample, hipStream_t stream) {
+    if (!pred || !target || !weight || !loss_out || B <= 0 || n_per_sample <= 0) return TQ_ERR_ARG;
+    hipError_t e = hipMemsetAsync(loss_out, 0, sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    const int gx = (n_per_sample + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(pseudo_huber_kernel, dim3(gx, B), dim3(256), 0, stream, pred, target, weight, c, loss_out, dpred,
+                       n_per_sample, 1.0f / ((float)B * (float)n_per_sample));
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_mse_loss(const float* a, const float* b, float* loss_out, float* d, size_t n, hipStream_t stream) {
+    if (!a || !b || !loss_out || n == 0) return TQ_ERR_ARG;
+    hipError_t e = hipMemsetAsync(loss_out, 0, sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mse_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, a, b, loss_out, d, n, 1.0f / (float)n);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_vae_reparam_fwd(const float* enc, const float* eps, float* z, float* kl_out, int B, int L, int T,
+                                  hipStream_t stream) {
+    if (!enc || !eps || !z || B <= 0 || L <= 0 || T <= 0) return TQ_ERR_ARG;
+    if (kl_out) {
+        hipError_t e = hipMemsetAsync(kl_out, 0, sizeof(float), stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t n = (size_t)B * L * T;
+    hipLaunchKernelGGL(vae_reparam_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, enc, eps, z, kl_out, L, T, n,
+                       1.0f / ((float)B * (float)T));
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_vae_reparam_bwd(const float* enc, const float* eps, const float* dz, float* denc, float kl_weight, int B, int L,
+                                  int T, hipStream_t stream) {
+    if (!enc || !eps || !dz || !denc || B <= 0 || L <= 0 || T <= 0) return TQ_ERR_ARG;
+    const size_t n = (size_t)B * L * T;
+    hipLaunchKernelGGL(vae_reparam_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, enc, eps, dz, denc, L, T, n,
+                       kl_weight / ((float)B * (float)T));
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_concat_scale(const float* x, const float* scale, const float* cond_signal, float* out, int B, int C0, int C1,
+                               int T, hipStream_t stream) {
+    if (!x || !cond_signal || !out || B <= 0 || C0 <= 0 || C1 <= 0 || T <= 0) return TQ_ERR_ARG;
+    const size_t n = (size_t)B * (C0 + C1) * T;
+    hipLaunchKernelGGL(concat_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, x, scale, cond_signal, out, C0, C1, T, n);
     TQ_CHECK_LAUNCH();
     return 0;
 }

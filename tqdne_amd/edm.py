@@ -130,7 +130,7 @@ class LightningEDM(LightningModule):
         """Fused preconditioned forward (edm.py:105-113); returns the engine's static output buffer.
         ``sigma``: device tensor; ``sigma_stride`` 1 (per-sample) or 0 (one value shared by the batch).
         ``cond_sample``: conditioning signal concatenated on the channel axis behind the scaled sample (edm.py:108-109); the
-        pre-scale then cannot ride in the stem load (only the first channels are scaled): one elementwise + cat glue op."""
+        pre-scale then cannot ride in the stem load (only the first channels are scaled): one fused concat + scale launch."""
         lib = _lib.load()
         B, _, T = sample.shape
         dev = sample.device
@@ -139,7 +139,14 @@ class LightningEDM(LightningModule):
         check(lib.tq_edm_scalars(_p(sigma), sigma_stride, float(self.edm.sigma_data), _p(sc[0]), _p(sc[1]), _p(sc[2]),
                                  _p(sc[3]), _p(sc[4]), B, stream), "edm scalars")
         if cond_sample is not None:
-            x_in = th.cat((sample * sc[0][:, None, None], cond_sample.to(sample.dtype)), dim=1).contiguous()
+            C1 = cond_sample.shape[1]
+            key = ("cat", B, sample.shape[1], C1, T, str(dev), self._lane)
+            x_in = self._scal.get(key)
+            if x_in is None:
+                x_in = th.empty(B, sample.shape[1] + C1, T, dtype=th.float32, device=dev)
+                self._scal[key] = x_in
+            check(lib.tq_concat_scale(_p(sample), _p(sc[0]), _p(cond_sample.contiguous().float()), _p(x_in), B, sample.shape[1], C1, T,
+                                      stream), "concat + scale")
             eng = self.unet._engine(B, T, dev, self._lane)
             return eng.forward(x_in, sc[3], cond, in_scale=None, c_out=sc[1], c_skip=sc[2], skip_src=sample, train=train,
                                dropout_seed=dropout_seed, infer=infer)
@@ -390,7 +397,7 @@ class LightningEDM(LightningModule):
         eng = self.unet._engine(x32.shape[0], x32.shape[2], x32.device, self._lane)
         key = (None if cond is None else cond.data_ptr(), None if cond_sample is None else cond_sample.data_ptr(), eng.plan_epoch)
         if g is None or bufs.get("graph_cond") != key:
-            slot = th.zeros(1, device=x32.device)
+            slot = th.ones(1, device=x32.device)  # (a valid sigma for the warm-up: sigma = 0 gives c_noise = -inf, NaN activations)
             self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample, infer=True)  # warm-up outside capture (plan build, packing)
             th.cuda.synchronize(x32.device)
             graph = th.cuda.CUDAGraph()
@@ -411,30 +418,49 @@ class LightningEDM(LightningModule):
 
     @th.no_grad()
     def sample_stochastically(self, eps, sigmas, cond_sample=None, cond=None, churn_noises=None):
-        """Stochastic (churned) sampler (edm.py:198-230).  The churn bookkeeping is a handful of fp64 elementwise torch
-        ops per step around the fused HIP denoiser; sigma_hat is resolved on the host exactly as the reference does."""
-        return self._sample_generic(eps, sigmas, cond_sample, cond, stochastic=True, churn_noises=churn_noises)
-
-    def _sample_generic(self, eps, sigmas, cond_sample, cond, stochastic, churn_noises=None):
-        dtype = th.float64
-        sample_next = eps
-        for i, (sigma, sigma_next) in enumerate(zip(sigmas[:-1], sigmas[1:])):
-            sample_curr = sample_next
-            if stochastic:
-                sigma_hat = self.edm.sigma_hat(sigma, self.num_sampling_steps)
-                unit = th.randn_like(sample_curr) if churn_noises is None else churn_noises[i]  # edm.py:207 draw
-                noise = unit * self.edm.S_noise
-                sample_hat = sample_curr + noise * (sigma_hat**2 - sigma**2) ** 0.5
+        """Stochastic (churned) sampler (edm.py:198-230) on the HIP kernels: per step the noise increase ``tq_heun_churn`` (lines
+        205-208), the fused denoiser at sigma_hat, ``tq_heun_euler`` and -- except on the last step -- the denoiser at sigma_next
+        and ``tq_heun_correct`` (lines 210-228), fp64 state, fp32 network.  sigma_hat and sqrt(sigma_hat^2 - sigma^2) are formed once
+        on the host from the reference's own fp32 0-dim-tensor expressions (edm.py:48-52, 208) and live on the device; the only torch
+        op in the loop is the ``randn_like`` draw of line 207 (``churn_noises[i]``, fp64 unit draws, replace it in tests)."""
+        if not eps.is_cuda:
+            raise RuntimeError("tqdne_amd samples on MI355X HIP kernels only; got a CPU start state")
+        lib = _lib.load()
+        dev = eps.device
+        N = self.num_sampling_steps
+        sig_cpu = sigmas.detach().to("cpu", th.float32)
+        shat_cpu = th.stack([self.edm.sigma_hat(sg, N) for sg in sig_cpu[:-1]]).to(th.float32)
+        coef_cpu = th.stack([(sh ** 2 - sg ** 2) ** 0.5 for sh, sg in zip(shat_cpu, sig_cpu[:-1])]).to(th.float32)
+        sig = sig_cpu.to(dev).contiguous()
+        shat, coef = shat_cpu.to(dev).contiguous(), coef_cpu.to(dev).contiguous()
+        if cond is not None:
+            cond = cond.contiguous().float()
+        if cond_sample is not None:
+            cond_sample = cond_sample.contiguous().float()
+        bufs = self._sampler_buffers(eps)
+        if "xh" not in bufs:
+            bufs["xh"] = th.empty_like(bufs["x"])
+        x, xh, xn, d, x32 = bufs["x"], bufs["xh"], bufs["xn"], bufs["d"], bufs["x32"]
+        x.copy_(eps)
+        n = x.numel()
+        stream = th.cuda.current_stream(dev).cuda_stream
+        nsteps = sig.numel() - 1
+        for i in range(nsteps):
+            unit = th.randn_like(x) if churn_noises is None else churn_noises[i].to(device=dev, dtype=th.float64).contiguous()
+            s_hat, s_next = shat.data_ptr() + 4 * i, sig.data_ptr() + 4 * (i + 1)
+            check(lib.tq_heun_churn(_p(x), _p(unit), coef.data_ptr() + 4 * i, float(self.edm.S_noise), _p(xh), _p(x32), n, stream),
+                  "heun churn")
+            den = self._denoise_static(x32, _RawPtr(s_hat), 0, cond, cond_sample=cond_sample, infer=True)
+            check(lib.tq_heun_euler(_p(xh), _p(den), s_hat, s_next, _p(d), _p(xn), _p(x32), n, stream), "heun euler")
+            if i < N - 1:
+                den = self._denoise_static(x32, _RawPtr(s_next), 0, cond, cond_sample=cond_sample, infer=True)
+                check(lib.tq_heun_correct(_p(xh), _p(xn), _p(den), _p(d), s_hat, s_next, _p(x), _p(x32), n, stream), "heun correct")
             else:
-                sigma_hat, sample_hat = sigma, sample_curr
-            pred_hat = self(sample_hat.to(th.float32), sigma_hat.to(th.float32).repeat(len(sample_hat)), cond_sample, cond).to(dtype)
-            d_cur = (sample_hat - pred_hat) / sigma_hat
-            sample_next = sample_hat + d_cur * (sigma_next - sigma_hat)
-            if i < self.num_sampling_steps - 1:
-                pred_next = self(sample_next.to(th.float32), sigma_next.to(th.float32).repeat(len(sample_hat)), cond_sample, cond).to(dtype)
-                d_prime = (sample_next - pred_next) / sigma_next
-                sample_next = sample_hat + (sigma_next - sigma_hat) * (0.5 * d_cur + 0.5 * d_prime)
-        return sample_next
+                x, xn = xn, x
+        out = x.clone()
+        if self.unet._engine(eps.shape[0], eps.shape[2], dev, self._lane).check_range():
+            return self.sample_stochastically(eps, sigmas, cond_sample, cond, churn_noises)  # (the plan is on bf16x3 now)
+        return out
 
     @th.no_grad()
     def evaluate(self, batch):
