@@ -205,7 +205,7 @@ class LightningAutoencoder(LightningModule):
                 f = lambda *sh: th.empty(*sh, device=x.device)
                 bufs = dict(z=f(B, L, Tl), kl=f(1), rl=f(1), drecon=th.empty_like(x), denc=f(B, L2, Tl))
                 self.__dict__.setdefault("_ae_bufs", {})[key] = bufs
-            eps = (th.randn(B, L, Tl, device=x.device) if unit_noise is None else unit_noise).contiguous()
+            eps = (th.randn_like(enc[:, :L]) if unit_noise is None else unit_noise).contiguous()  # (the draw of autoencoder.py:39)
             # z = mean + eps * exp(log_std) and the KL term in one launch (autoencoder.py:37-43, 64-66)
             check(lib.tq_vae_reparam_fwd(_p(enc), _p(eps), _p(bufs["z"]), _p(bufs["kl"]), B, L, Tl, stream), "vae reparam")
             d_eng = _seq_engine(self.decoder, bufs["z"])
