@@ -78,3 +78,43 @@ def test_packed_weights_follow_the_fused_optimizer():
     eng.repack(stream)  # parameters changed in step 3 -> must repack without force
     torch.cuda.synchronize()
     assert not torch.equal(before, site.packed), "packed weights did not follow the optimizer update"
+
+
+def test_plans_share_one_packed_weight_store():
+    """every plan of a model (any batch, length, lane) reads the same packed fragments; a weight update is re-packed once, by the
+    first plan that runs after it, and seen by all of them -- also across streams"""
+    from tqdne_amd import UNetModel
+    sd, d = load_golden("micro_unet.npz")
+    dev = torch.device("cuda:0")
+    m = UNetModel(**cfg_of(d))
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    e_a, e_b, e_c = m._engine(2, 256, dev), m._engine(4, 248, dev), m._engine(2, 256, dev, lane=1)
+    assert e_a.store is e_b.store is e_c.store
+    for sa, sb, sc in zip(e_a.conv_sites, e_b.conv_sites, e_c.conv_sites):
+        assert sa.packed.data_ptr() == sb.packed.data_ptr() == sc.packed.data_ptr(), sa.name
+    g = torch.Generator().manual_seed(3)
+    x, t, c = torch.randn(2, 3, 256, generator=g).to(dev), torch.rand(2, generator=g).to(dev), torch.randn(2, 5, generator=g).to(dev)
+    x4 = torch.randn(4, 3, 248, generator=g).to(dev)
+    t4, c4 = torch.rand(4, generator=g).to(dev), torch.randn(4, 5, generator=g).to(dev)
+    with torch.no_grad():
+        y0 = m(x, t, c)
+        gen0 = e_a.store.gen
+        m(x4, t4, c4)
+        assert e_a.store.gen == gen0, "a second plan must not re-pack unchanged weights"
+        for p in m.parameters():
+            p.mul_(1.25)   # in-place: bumps the version counters
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            y4 = e_b.forward(x4, t4, c4, infer=True).clone()          # packs on the side stream
+        y1 = e_a.forward(x, t, c, infer=True).clone()                # main stream: must wait for that pack
+        torch.cuda.synchronize()
+        assert e_a.store.gen == gen0 + 1
+    m2 = UNetModel(**cfg_of(d))
+    m2.load_state_dict({k: v * 1.25 if v.is_floating_point() else v for k, v in sd.items()})
+    m2 = m2.to(dev).eval()
+    with torch.no_grad():
+        r1, r4 = m2(x, t, c), m2(x4, t4, c4)
+    assert torch.equal(y1, r1) and torch.equal(y4, r4)
+    assert not torch.equal(y0, y1)

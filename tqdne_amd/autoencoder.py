@@ -64,6 +64,7 @@ class Encoder(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._engine_cache = {}
+        self.__dict__.pop("_packed_stores", None)
         return super()._apply(fn, *a, **k)
 
 
@@ -106,6 +107,7 @@ class Decoder(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._engine_cache = {}
+        self.__dict__.pop("_packed_stores", None)
         return super()._apply(fn, *a, **k)
 
 

@@ -70,18 +70,60 @@ class ConvRec:
         self.stride, self.upsample, self.silu, self.dropout = stride, upsample, silu, dropout
 
 
+class PackedStore:
+    """The packed MFMA weight fragments (and the derived weight tensors) of ONE model on one device, shared by every execution
+    plan of that model: the fragments depend on the weights only, not on the batch, the length or the sampler lane.  One copy
+    instead of one per plan (the 4-lane sampler + the training plan held five 62 MB copies and re-packed each of them after every
+    optimizer step), and one copy for the XCD L2s / the Infinity Cache to keep.
+
+    Plans on different HIP streams use the store: a plan that finds stale fragments re-packs them on ITS stream after waiting for
+    the last use recorded by every other stream; a plan on another stream than the packing one waits for the pack's event."""
+
+    def __init__(self, device):
+        self.dev = device
+        self.entries = {}       # key -> {"buf": tensor, "ver": version tag of the weights the buffer was built from}
+        self.event = None       # recorded behind the most recent pack
+        self.gen = 0            # pack generation
+        self.pack_stream = None
+        self.users = {}         # stream handle -> event recorded behind that stream's most recent forward
+
+    def entry(self, key, shape, dtype=torch.uint8):
+        e = self.entries.get(key)
+        if e is None:
+            e = {"buf": torch.empty(shape, dtype=dtype, device=self.dev), "ver": None}
+            self.entries[key] = e
+        assert tuple(e["buf"].shape) == (tuple(shape) if isinstance(shape, (tuple, list)) else (shape,)), key
+        return e
+
+
+def get_store(model, device) -> PackedStore:
+    stores = model.__dict__.setdefault("_packed_stores", {})
+    st = stores.get(str(device))
+    if st is None:
+        st = stores[str(device)] = PackedStore(device)
+    return st
+
+
 class ConvSite:
-    """One convolution's weights: torch parameter + packed bf16 hi/lo MFMA fragments."""
+    """One convolution's weights: torch parameter + packed bf16 hi/lo MFMA fragments (a buffer of the model's PackedStore)."""
 
-    __slots__ = ("weight", "bias", "packed", "packed_t", "C_out", "C_in", "K", "version", "name", "pack_mode")
+    __slots__ = ("weight", "bias", "packed", "packed_t", "C_out", "C_in", "K", "version", "name", "pack_mode", "entry", "tail")
 
-    def __init__(self, name, weight, bias, device, lib, packed=None, tail_bytes=0):
+    def __init__(self, name, weight, bias, device, lib, packed=None, tail_bytes=0, store=None):
         self.name = name
         self.weight, self.bias = weight, bias
         self.C_out, self.C_in, self.K = weight.shape
         nbytes = lib.tq_conv_weight_pack_bytes(self.C_out, self.C_in, self.K, 0)
         # tail_bytes: room for a second conv's fragments right behind this one's (fused skip conv, tq_conv1d_fwd_skip)
-        self.packed = packed if packed is not None else torch.empty(nbytes + tail_bytes, dtype=torch.uint8, device=device)
+        self.entry = None      # store entry owning `packed` (None: a tail view of another site's buffer, or a private buffer)
+        self.tail = None       # the site whose fragments follow in the same buffer
+        if packed is not None:
+            self.packed = packed
+        elif store is not None:
+            self.entry = store.entry("conv:" + name, nbytes + tail_bytes)
+            self.packed = self.entry["buf"]
+        else:
+            self.packed = torch.empty(nbytes + tail_bytes, dtype=torch.uint8, device=device)
         self.pack_mode = 0     # tq_pack_conv_weight mode of `packed` (2: TQ_WFMT_F16_MX8), set by the plan builder
         self.packed_t = None  # transposed / tap-flipped fragments for the data gradient (training only)
         self.version = -1
@@ -115,6 +157,9 @@ class UNetEngine:
         self.lib = _lib.load()
         self.m = model
         self.B, self.T, self.dev = B, T, device
+        self.store = get_store(model, device)
+        self._seen_pack = {}
+        self._clean_tag = None
         self.E = 4 * getattr(model, "model_channels", 0)
         self._keep = []          # ctypes structs / tensors referenced by raw pointers
         self.ops: List[Tuple] = []          # launches of a forward whose backward may follow
@@ -140,7 +185,6 @@ class UNetEngine:
         self.dgrad_sites = []
         self._wt_version = None
         self._build()
-        self._w_version = None
         if getattr(model, "_conv_scheme", "auto") == "bf16x3":
             self._set_scheme_bf16x3()
 
@@ -156,7 +200,7 @@ class UNetEngine:
         return a
 
     def _site(self, name: str, conv: torch.nn.Module) -> ConvSite:
-        s = ConvSite(name, conv.weight, conv.bias, self.dev, self.lib)
+        s = ConvSite(name, conv.weight, conv.bias, self.dev, self.lib, store=self.store)
         self.conv_sites.append(s)
         return s
 
@@ -168,8 +212,9 @@ class UNetEngine:
         assert tk == 1 and tco == co
         main_bytes = lib.tq_conv_weight_pack_bytes(co, ci, k, 0)
         tail_bytes = lib.tq_conv_weight_pack_bytes(tco, tci, 1, 0)
-        s = ConvSite(name, conv.weight, conv.bias, self.dev, lib, tail_bytes=tail_bytes)
+        s = ConvSite(name, conv.weight, conv.bias, self.dev, lib, tail_bytes=tail_bytes, store=self.store)
         t = ConvSite(tail_name, tail_conv.weight, tail_conv.bias, self.dev, lib, packed=s.packed[main_bytes:])
+        s.tail = t
         self.conv_sites += [s, t]
         return s, t
 
@@ -283,8 +328,8 @@ class UNetEngine:
         w3+w4): 3/5 of the multiply-adds, same result up to the fp32 rounding of the tap sums.  The training forward keeps the k = 5
         launch its gradients are written for.  The two-phase weights are rebuilt by repack() with the packed fragments."""
         Cr = site.C_out
-        w2 = torch.empty(2 * Cr, site.C_in, 3, device=self.dev)
-        ps = ConvSite(site.name + ":polyphase", w2, site.bias, self.dev, self.lib)
+        w2 = self.store.entry("w:" + site.name + ":polyphase", (2 * Cr, site.C_in, 3), torch.float32)["buf"]
+        ps = ConvSite(site.name + ":polyphase", w2, site.bias, self.dev, self.lib, store=self.store)
         self.poly_sites.append((ps, site))
         d2 = TqConvDesc()
         d2.B, d2.T_in, d2.T_out = d.B, d.T_in, d.T_in
@@ -321,8 +366,9 @@ class UNetEngine:
         self.emb = self._empty(B, self.E)
         self.silu_emb = self._empty(B, self.E)
         self.emb_hidden = self._empty(B, 2, self.E)
-        self.emb_w = self._empty(self.emb_total, self.E)
-        self.emb_b = self._empty(self.emb_total)
+        self.emb_w = self.store.entry("emb_w", (self.emb_total, self.E), torch.float32)["buf"]
+        self.emb_b = self.store.entry("emb_b", (self.emb_total,), torch.float32)["buf"]
+        self.emb_entry = None
         # all 22 per-block Linear(SiLU(emb)) projections (unet.py:91-97) as ONE pointwise "conv" on the MFMA path: the B samples
         # are the positions of a single (1, B, E) channels-last sequence, the concatenated weight a (emb_total, E, 1) kernel
         self.emb_desc = None
@@ -332,8 +378,8 @@ class UNetEngine:
             d.ktaps, d.stride, d.pad, d.upsample, d.flags = 1, 1, 0, 0, 0
             d.wfmt = _lib.forward_wfmt(self.emb_total, [self.E])
             self.emb_pack_mode = 2 if d.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
-            self.emb_packed = torch.empty(lib.tq_conv_weight_pack_bytes(self.emb_total, self.E, 1, self.emb_pack_mode),
-                                          dtype=torch.uint8, device=self.dev)
+            self.emb_entry = self.store.entry("emb_packed", lib.tq_conv_weight_pack_bytes(self.emb_total, self.E, 1, self.emb_pack_mode))
+            self.emb_packed = self.emb_entry["buf"]
             self._keep.append(d)
             self.emb_desc = d
         self.emb_all = self._empty(B, self.emb_total)
@@ -461,8 +507,7 @@ class UNetEngine:
         if getattr(self, "emb_desc", None) is not None:
             self.emb_desc.wfmt = _lib.TQ_WFMT_BF16X3
             self.emb_pack_mode = 0
-        self.scheme = "bf16x3"
-        self._w_version = None   # forces the re-pack
+        self.scheme = "bf16x3"            # (the pack mode is part of every store entry's version tag: the next forward re-packs)
         self.plan_epoch += 1     # captured HIP graphs of this plan are stale
 
     def _range_fallback(self):
@@ -503,45 +548,101 @@ class UNetEngine:
             self._range_evt.record()
 
     # ------------------------------------------------------------------ weights
-    def _weights_version(self):
+    def _stale(self):
+        """(conv sites, polyphase sites, emb?) whose store buffers were not built from the current weights / pack mode"""
+        sites = []
+        for st in self.conv_sites:
+            if st.entry is None:
+                continue  # tail of a pair: packed with its head
+            ver = (id(st.weight), st.weight._version, st.pack_mode) + ((id(st.tail.weight), st.tail.weight._version) if st.tail else ())
+            if st.entry["ver"] != ver:
+                sites.append((st, ver))
+        polys = []
+        for ps, src in self.poly_sites:
+            ver = (id(src.weight), src.weight._version, ps.pack_mode)
+            if ps.entry["ver"] != ver:
+                polys.append((ps, src, ver))
+        emb = None
+        if self.emb_total > 0:
+            ver = tuple((id(rb.emb_layers[1].weight), rb.emb_layers[1].weight._version, rb.emb_layers[1].bias._version)
+                        for rb in self.res_blocks if hasattr(rb, "emb_layers")) + (getattr(self, "emb_pack_mode", 0),)
+            e = self.store.entries["emb_w"]
+            if e["ver"] != ver:
+                emb = ver
+        return sites, polys, emb
+
+    def repack(self, stream: int, force: bool = False):
+        """(Re)build the packed conv weights and the concatenated emb projection in the model's PackedStore where the parameters
+        (or the contraction scheme) changed since they were built -- by whichever plan runs first after the change."""
+        store, lib = self.store, self.lib
+        capturing = torch.cuda.is_current_stream_capturing()
+        # cheap test first: nothing moved since this plan last found every buffer current (sum of the version counters, the
+        # store's pack generation, this plan's scheme)
         v = 0
-        for s in self.conv_sites:
-            v += s.weight._version
+        for st in self.conv_sites:
+            v += st.weight._version
         for rb in self.res_blocks:
             if hasattr(rb, "emb_layers"):
                 v += rb.emb_layers[1].weight._version + rb.emb_layers[1].bias._version
-        return v
-
-    def repack(self, stream: int, force: bool = False):
-        """(Re)build packed conv weights and the concatenated emb projection when parameters changed."""
-        v = self._weights_version()
-        if not force and v == self._w_version:
+        tag = (v, store.gen, self.plan_epoch, stream)
+        if not force and tag == self._clean_tag:
             return
-        lib = self.lib
-        for s in self.conv_sites:
-            check(lib.tq_pack_conv_weight(s.weight.data_ptr(), s.C_out, s.C_in, s.K, s.pack_mode, s.packed.data_ptr(), stream),
-                  "pack " + s.name)
-        with torch.no_grad():
-            for ps, src in self.poly_sites:  # two-phase k = 3 restatement of the upsampling convs (see _polyphase_op)
-                w, Cr = src.weight, src.C_out
-                ps.weight[:Cr, :, 0] = w[:, :, 0] + w[:, :, 1]
-                ps.weight[:Cr, :, 1] = w[:, :, 2] + w[:, :, 3]
-                ps.weight[:Cr, :, 2] = w[:, :, 4]
-                ps.weight[Cr:, :, 0] = w[:, :, 0]
-                ps.weight[Cr:, :, 1] = w[:, :, 1] + w[:, :, 2]
-                ps.weight[Cr:, :, 2] = w[:, :, 3] + w[:, :, 4]
-                check(lib.tq_pack_conv_weight(ps.weight.data_ptr(), ps.C_out, ps.C_in, 3, ps.pack_mode, ps.packed.data_ptr(), stream),
-                      "pack " + ps.name)
-        with torch.no_grad():
-            for rb in self.res_blocks:
-                if hasattr(rb, "emb_layers"):
-                    o = self.emb_offsets[id(rb)]
-                    self.emb_w[o:o + rb.out_channels].copy_(rb.emb_layers[1].weight)
-                    self.emb_b[o:o + rb.out_channels].copy_(rb.emb_layers[1].bias)
-            if getattr(self, "emb_desc", None) is not None:
-                check(lib.tq_pack_conv_weight(self.emb_w.data_ptr(), self.emb_total, self.E, 1, self.emb_pack_mode,
-                                              self.emb_packed.data_ptr(), stream), "pack emb projections")
-        self._w_version = v
+        sites, polys, emb = self._stale()
+        if sites or polys or emb is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            if not capturing:
+                for sid, ev in store.users.items():   # nobody may still be reading the fragments about to be overwritten
+                    if sid != stream:
+                        cur.wait_event(ev)
+            for st, ver in sites:
+                check(lib.tq_pack_conv_weight(st.weight.data_ptr(), st.C_out, st.C_in, st.K, st.pack_mode, st.packed.data_ptr(), stream),
+                      "pack " + st.name)
+                if st.tail is not None:
+                    t = st.tail
+                    check(lib.tq_pack_conv_weight(t.weight.data_ptr(), t.C_out, t.C_in, t.K, t.pack_mode, t.packed.data_ptr(), stream),
+                          "pack " + t.name)
+                st.entry["ver"] = ver
+            with torch.no_grad():
+                for ps, src, ver in polys:  # two-phase k = 3 restatement of the upsampling convs (see _polyphase_op)
+                    w, Cr = src.weight, src.C_out
+                    ps.weight[:Cr, :, 0] = w[:, :, 0] + w[:, :, 1]
+                    ps.weight[:Cr, :, 1] = w[:, :, 2] + w[:, :, 3]
+                    ps.weight[:Cr, :, 2] = w[:, :, 4]
+                    ps.weight[Cr:, :, 0] = w[:, :, 0]
+                    ps.weight[Cr:, :, 1] = w[:, :, 1] + w[:, :, 2]
+                    ps.weight[Cr:, :, 2] = w[:, :, 3] + w[:, :, 4]
+                    check(lib.tq_pack_conv_weight(ps.weight.data_ptr(), ps.C_out, ps.C_in, 3, ps.pack_mode, ps.packed.data_ptr(), stream),
+                          "pack " + ps.name)
+                    ps.entry["ver"] = ver
+                if emb is not None:
+                    for rb in self.res_blocks:
+                        if hasattr(rb, "emb_layers"):
+                            o = self.emb_offsets[id(rb)]
+                            self.emb_w[o:o + rb.out_channels].copy_(rb.emb_layers[1].weight)
+                            self.emb_b[o:o + rb.out_channels].copy_(rb.emb_layers[1].bias)
+                    if getattr(self, "emb_desc", None) is not None:
+                        check(lib.tq_pack_conv_weight(self.emb_w.data_ptr(), self.emb_total, self.E, 1, self.emb_pack_mode,
+                                                      self.emb_packed.data_ptr(), stream), "pack emb projections")
+                    store.entries["emb_w"]["ver"] = emb
+            store.gen += 1
+            if not capturing:
+                store.event = torch.cuda.Event()
+                store.event.record(cur)
+                store.pack_stream = stream
+        elif (not capturing and store.event is not None and store.pack_stream != stream
+              and self._seen_pack.get(stream) is not store.event):
+            torch.cuda.current_stream(self.dev).wait_event(store.event)   # packed on another stream: order this one behind it
+            self._seen_pack[stream] = store.event
+        self._clean_tag = (v, store.gen, self.plan_epoch, stream)
+
+    def _mark_use(self, stream: int):
+        """record, behind the launches of this forward, that ``stream`` has read the store (see repack)"""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        ev = self.store.users.get(stream)
+        if ev is None:
+            ev = self.store.users[stream] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
 
     def repack_transposed(self, stream: int):
         """Transposed / tap-flipped fragments for the data-gradient launches (training only)."""
@@ -646,6 +747,7 @@ class UNetEngine:
                           4 * B * T * (self.final.C + 2 * m.out_channels), e0, ev()))
         if train:
             self._range_poll(False)
+        self._mark_use(stream)
         return self.out_nct
 
     # ------------------------------------------------------------------ backward
@@ -728,6 +830,7 @@ class SeqEngine(UNetEngine):
                                        stream), "output layer")
         else:
             self.out_nct.copy_(self.out_btc.buf.permute(0, 2, 1))  # (B,T,C) -> (B,C,T): 1/60 of the encoder's traffic
+        self._mark_use(stream)
         return self.out_nct
 
     def backward(self, dout: torch.Tensor, want_dx: bool = False, clone: bool = True):

@@ -209,4 +209,5 @@ class UNetModel(nn.Module):
 
     def _apply(self, fn, *a, **k):  # parameters moved (.to / .cuda): compiled plans hold stale pointers
         self._engine_cache = {}
+        self.__dict__.pop("_packed_stores", None)
         return super()._apply(fn, *a, **k)
