@@ -97,6 +97,8 @@ class PackedStore:
 
 
 def get_store(model, device) -> PackedStore:
+    if os.environ.get("TQDNE_SHARED_STORE", "1") == "0":   # A/B switch: a private store per plan (the round-1 behaviour)
+        return PackedStore(device)
     stores = model.__dict__.setdefault("_packed_stores", {})
     st = stores.get(str(device))
     if st is None:
@@ -588,6 +590,10 @@ class UNetEngine:
         if not force and tag == self._clean_tag:
             return
         sites, polys, emb = self._stale()
+        if (not capturing and store.event is not None and store.pack_stream != stream
+                and self._seen_pack.get(stream) is not store.event):
+            torch.cuda.current_stream(self.dev).wait_event(store.event)   # packed on another stream: order this one behind it
+            self._seen_pack[stream] = store.event
         if sites or polys or emb is not None:
             cur = torch.cuda.current_stream(self.dev)
             if not capturing:
@@ -629,10 +635,6 @@ class UNetEngine:
                 store.event = torch.cuda.Event()
                 store.event.record(cur)
                 store.pack_stream = stream
-        elif (not capturing and store.event is not None and store.pack_stream != stream
-              and self._seen_pack.get(stream) is not store.event):
-            torch.cuda.current_stream(self.dev).wait_event(store.event)   # packed on another stream: order this one behind it
-            self._seen_pack[stream] = store.event
         self._clean_tag = (v, store.gen, self.plan_epoch, stream)
 
     def _mark_use(self, stream: int):
