@@ -30,8 +30,12 @@ def test_oracle_ae_step_matches_reference():
     loss = l0 + l1
     assert rel_err(loss.detach(), s["loss"]) < 1e-6
     loss.backward()
+    gmax = max(float(np.abs(s["g:" + k]).max()) for k in params)
     for k, v in params.items():
-        assert rel_err(v.grad, s["g:" + k]) < 2e-5, k  # fp32 autograd on both sides, different summation order
+        # fp32 autograd on both sides, different summation order; gradients that are zero in exact arithmetic (a conv bias in
+        # front of a GroupNorm with one channel per group) are rounding noise of ~1e-10 and differ between hosts: hence the floor
+        ref = torch.from_numpy(s["g:" + k])
+        assert float((v.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-6 * gmax) < 2e-5, k
 
 
 @pytest.mark.gpu

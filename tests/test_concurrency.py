@@ -73,9 +73,11 @@ def test_four_plans_on_four_streams_match_a_plan_alone():
             edm._lane = 0
 
     def tensors(eng):
+        # (inference plans write only the q third of a qkv buffer: K and V go straight to the attention kernel's bf16 planes)
+        qkv = {id(t["qkv"]) for kind, t in eng.tape if kind == "attn"}
         out = [("out", eng.out_nct)]
         for i, a in enumerate(eng.acts):
-            out.append((f"act{i}", a.buf))
+            out.append((f"act{i}", a.buf[:, :, : a.C // 3] if id(a) in qkv else a.buf))
             if a.stats is not None:
                 out.append((f"act{i}.stats", a.stats))
         return out

@@ -4,6 +4,7 @@
 //   * GroupNorm32 backward (finalise group sums -> per-(b,c) coefficients; elementwise apply)
 //   * column sums (bias / time-embedding gradients), zero-stuffing and pair-sum (strided / upsampled convs)
 //   * stem weight gradient and head (last conv) backward
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/tqdne_hip.h"
 
@@ -48,13 +49,17 @@ struct WgArgs {
 
 constexpr int WG_TT = 64;        // reduction positions per staged tile
 constexpr int WG_DY_STRIDE = 272;  // bytes per dy image row (128 co * 2 B + 16 pad)
-constexpr int WG_X_STRIDE = 64;    // bytes per xhat image row (32 ci * 2 B)
 
-template <int KT, int STRIDE, int UPS>
+// NCI: input-channel chunk of a workgroup in units of 32.  The dy tile (128 co) is staged, split and read once per workgroup and
+// unit whatever the chunk width, so the 64-channel chunk (NCI = 2) halves the number of times dy is re-read from L2 / HBM and
+// re-split (measured traffic-bound with 32: every conv's dy was read C_in / 32 times); 160 accumulator registers at k = 5.
+template <int KT, int STRIDE, int UPS, int NCI>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
     constexpr int PAD = (STRIDE == 1) ? KT / 2 : 1;
     constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
-    constexpr int XIT = (XR * 8 + 255) / 256;
+    constexpr int WG_X_STRIDE = 64 * NCI;    // bytes per xhat image row (32 NCI ci * 2 B)
+    constexpr int XC4 = 8 * NCI;             // float4 columns of the xhat tile
+    constexpr int XIT = (XR * XC4 + 255) / 256;
     constexpr int DY_PLANE = WG_TT * WG_DY_STRIDE;
     constexpr int X_PLANE = XR * WG_X_STRIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
     const int cc = bid % p.n_cichunks;
     const int sp = bid / p.n_cichunks;
     const int co0 = ct * 128;
-    const int cb = cc * 32;
+    const int cb = cc * 32 * NCI;
     const int Cin = p.C0 + p.C1;
     const int T_src = UPS ? 2 * p.T_in : p.T_in;
     const int U = p.B * p.n_ttiles;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
     // xhat source (one concat source per 32-channel chunk)
     const float* xsrc; int xcs, xoff;
     if (cb < p.C0) { xsrc = p.x0; xcs = p.C0; xoff = cb; } else { xsrc = p.x1; xcs = p.C1; xoff = cb - p.C0; }
-    const int m = tid & 7;  // float4 column of the xhat tile owned by this thread
+    const int m = tid & (XC4 - 1);  // float4 column of the xhat tile owned by this thread
 
     float4 dyr[8];
     float4 xr[XIT];
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         const float* xb = xsrc + (size_t)b * p.T_in * xcs + xoff + 4 * m;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            const int i = (tid + it * 256) >> 3;
+            const int i = (tid + it * 256) / XC4;
             const int pos = xpos(t0, i);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < XR && pos >= 0 && pos < T_src) v = *reinterpret_cast<const float4*>(xb + (size_t)(UPS ? (pos >> 1) : pos) * xcs);
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            const int i = (tid + it * 256) >> 3;
+            const int i = (tid + it * 256) / XC4;
             if (i >= XR) continue;
             const int pos = xpos(t0, i);
             float v[4] = {xr[it].x, xr[it].y, xr[it].z, xr[it].w};
@@ -168,18 +173,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         }
     };
 
-    f32x4 acc[2][2][KT];
+    f32x4 acc[2][2 * NCI][KT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2 * NCI; ++j)
 #pragma unroll
             for (int k = 0; k < KT; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 
     auto compute = [&]() __attribute__((always_inline)) {
-#pragma unroll
+#pragma unroll (NCI == 2 && KT == 5 ? 1 : 2)
         for (int ks = 0; ks < WG_TT / 32; ++ks) {
             const int r0 = ks * 32 + 8 * g + q;  // reduction row supplied by this lane (first read; +4 second)
             Frag ah[2], al[2];
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
             for (int k = 0; k < KT; ++k) {
                 const int xrow = (STRIDE == 1) ? (r0 + k) : ((k & 1) * (WG_TT + 1) + r0 + (k >> 1));
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
+                for (int nb = 0; nb < 2 * NCI; ++nb) {
                     const int off = xrow * WG_X_STRIDE + (nb * 16 + 4 * pp) * 2;
                     Frag bh, bl;
                     bh.h[0] = lds_tr_read(x_hi + off);
@@ -210,12 +215,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         }
     };
 
-    if (u_begin < u_end) load_unit(u_begin);
+    // The next unit's loads are normally in flight under this unit's MFMAs.  With 160 accumulator registers (k = 5, 64-channel
+    // chunk) there is no room for the 52 staging registers across the MFMA phase: that variant loads right before it converts and
+    // leaves the latency to the co-resident workgroup.
+    constexpr bool PREFETCH = !(NCI == 2 && KT == 5);
+    if (PREFETCH && u_begin < u_end) load_unit(u_begin);
     for (int u = u_begin; u < u_end; ++u) {
+        if (!PREFETCH) load_unit(u);
         __syncthreads();
         write_unit(u);
         __syncthreads();
-        if (u + 1 < u_end) load_unit(u + 1);
+        if (PREFETCH && u + 1 < u_end) load_unit(u + 1);
         if (wave_active) compute();
     }
 
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < 2 * NCI; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + wave * 32 + mb * 16 + 4 * (lane >> 4) + r;
@@ -256,9 +266,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (threadIdx.y == 0 && i < n) dw[i * KT + k] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+int wgrad_nci(const TqConvDesc* d) {
+    // 64-channel chunks where both concat sources are made of whole chunks (every 1-D config: 64 | C); TQDNE_WGRAD_NCI=1 forces 32
+    static const int forced = [] { const char* e = getenv("TQDNE_WGRAD_NCI"); return e ? atoi(e) : 0; }();
+    if (forced == 1) return 1;
+    // Measured (B = 64, paper UNet): the ResBlocks' 1x1 skip convs gain 15-29 % from the 64-channel chunk (their MFMA phase is a
+    // fifth of a k = 5 one, so the dy staging dominates); k = 5 loses 35-50 % (160 accumulator registers: 17 spills and no room
+    // for the staging prefetch), k = 3 loses 16-34 %, the attention projections are neutral -> 64 only for k = 1
+    if (d->ktaps != 1 && forced != 2) return 1;
+    return (d->C_in0 % 64 == 0 && d->C_in1 % 64 == 0) ? 2 : 1;
+}
+
 void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_ttiles, int& nsplit, int& ups) {
     n_cotiles = (d->C_out + 127) / 128;
-    n_cichunks = (d->C_in0 + d->C_in1) / 32;
+    n_cichunks = (d->C_in0 + d->C_in1) / (32 * wgrad_nci(d));
     n_ttiles = (d->T_out + WG_TT - 1) / WG_TT;
     const int U = d->B * n_ttiles;
     const int ntiles = n_cotiles * n_cichunks;
@@ -270,11 +291,15 @@ void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_tti
 }
 
 template <int KT, int STRIDE, int UPS>
-int launch_wgrad(const WgArgs& a, hipStream_t stream) {
+int launch_wgrad(const WgArgs& a, int nci, hipStream_t stream) {
     constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
-    const size_t sh = 2 * WG_TT * WG_DY_STRIDE + 2 * XR * WG_X_STRIDE;
+    const size_t sh = 2 * WG_TT * WG_DY_STRIDE + 2 * XR * 64 * nci;
     const unsigned grid = (unsigned)(a.n_cotiles * a.n_cichunks * a.nsplit);
-    hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS>), dim3(grid), dim3(256), sh, stream, a);
+    if (nci == 2) {
+        hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 2>), dim3(grid), dim3(256), sh, stream, a);
+    } else {
+        hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 1>), dim3(grid), dim3(256), sh, stream, a);
+    }
     TQ_CHECK_LAUNCH();
     return 0;
 }
@@ -306,17 +331,18 @@ extern "C" int tq_conv1d_bwd_weight(const TqConvDesc* d, const float* dy, const 
     a.drop_thresh = (uint32_t)((double)pdrop * 4294967296.0);
     a.drop_scale = 1.0f / (1.0f - pdrop);
     int rc;
+    const int nci = wgrad_nci(d);
     if (d->stride == 2) {
         if (d->ktaps != 3) return TQ_ERR_SHAPE;
-        rc = launch_wgrad<3, 2, 0>(a, stream);
+        rc = launch_wgrad<3, 2, 0>(a, nci, stream);
     } else if (d->upsample) {
-        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 1>(a, stream);
-        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 1>(a, stream);
+        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 1>(a, nci, stream);
+        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 1>(a, nci, stream);
         else return TQ_ERR_SHAPE;
     } else {
-        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 0>(a, stream);
-        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 0>(a, stream);
-        else if (d->ktaps == 1) rc = launch_wgrad<1, 1, 0>(a, stream);
+        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 0>(a, nci, stream);
+        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 0>(a, nci, stream);
+        else if (d->ktaps == 1) rc = launch_wgrad<1, 1, 0>(a, nci, stream);
         else return TQ_ERR_SHAPE;
     }
     if (rc) return rc;
