@@ -234,10 +234,11 @@ class UNetEngine:
         mean_rstd = self._empty(self.B, 32, 2)
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) > 1 else None
-        self._emit((self.lib.tq_gn_finalize, (
-            _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
-            _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize", 0),
-            nbytes=4 * self.B * (2 * nslots(s0.T) * C_ + 2 * C_))
+        for _ in range(2 if os.environ.get("TQDNE_DUP_GN") == "1" else 1):   # (measurement switch: what do these launches cost?)
+            self._emit((self.lib.tq_gn_finalize, (
+                _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
+                _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize", 0),
+                nbytes=4 * self.B * (2 * nslots(s0.T) * C_ + 2 * C_))
         return gscale, gshift, mean_rstd
 
     def _conv(self, srcs: Sequence[Act], site: ConvSite, *, gn=None, silu=False, emb_ptr=None, res: Optional[Act] = None,
