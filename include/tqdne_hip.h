@@ -167,6 +167,25 @@ int tq_gn_bwd_apply(const float* g, const float* x, const float* r, const float*
                     hipStream_t stream);
 /* out_bc[b*bc_stride + c] += bscale[b] * sum_t dy[b,t,c];  out_c[c], out_c2[c] += sum_{b,t} (...)  (each optional; bias and
  * embedding gradients: two biases fed by the same tensor are served by one pass) */
+/* Small fp32 GEMMs of the embedding-MLP backward (unet.py:91-97,210-227,383-388; the autograd of blocks.py:15-26): one launch runs
+ * a list of independent products  C (M x N) = A (M x K) * f(B) (K x N) [* silu'(U)]  with strided operands
+ * A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn] (a stride of 1 marks the contiguous direction), f = SiLU when pre_b,
+ * U (M x N, row stride ldu) optional.  The job table lives in device memory; tile_begin = running sum of tq_gemm_tiles(M, N). */
+typedef struct TqGemmJob {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* U;
+    int32_t M, N, K;
+    int32_t sam, sak, sbk, sbn, ldc, ldu;
+    int32_t pre_b;
+    int32_t tile_begin;
+} TqGemmJob;
+int tq_gemm_tiles(int M, int N);
+int tq_gemm_f32_jobs(const TqGemmJob* jobs_device, int njobs, int total_tiles, hipStream_t stream);
+/* GaussianFourierProjection features (blocks.py:15-26): out (B, 2 half) = [sin(2 pi t W) | cos(2 pi t W)] */
+int tq_fourier_features(const float* t, const float* W, float* out, int B, int half, hipStream_t stream);
+
 int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, float* out_c2,
               const float* bscale, hipStream_t stream);
 /* gradient plumbing of the strided / upsampled convs: out[b,u,:] = (u even) ? dy[b,u/2,:] : 0 for u < T_in;

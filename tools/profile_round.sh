@@ -15,3 +15,5 @@ for d in full_step sample_only_1lane train_only; do
   f=$(find gpurun_out/${tag}_$d -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f gpurun_out/${tag}_${d}_kernel_stats.csv
 done
+# only the summaries travel back (gpurun merges at most 64 MiB): drop the raw traces
+rm -rf gpurun_out/${tag}_full_step gpurun_out/${tag}_sample_only_1lane gpurun_out/${tag}_train_only gpurun_out/pmc_${tag}

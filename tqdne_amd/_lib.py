@@ -56,6 +56,13 @@ class TqAdamChunk(C.Structure):
 TQ_ADAM_CHUNK = 4096
 
 
+class TqGemmJob(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("U", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("sam", C.c_int32), ("sak", C.c_int32), ("sbk", C.c_int32), ("sbn", C.c_int32), ("ldc", C.c_int32), ("ldu", C.c_int32),
+                ("pre_b", C.c_int32), ("tile_begin", C.c_int32)]
+
+
 class TqConvBwdDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T", C.c_int32), ("C_dy", C.c_int32), ("C_dx0", C.c_int32), ("C_dx1", C.c_int32),
@@ -103,6 +110,9 @@ _PROTOS = {
     "tq_conv1d_bwd_weight": (I, [VP] * 8 + [SZ, VP]),
     "tq_gn_bwd_finalize": (I, [VP, VP, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
     "tq_gn_bwd_apply": (I, [VP] * 7 + [I] * 6 + [VP]),
+    "tq_gemm_tiles": (I, [I, I]),
+    "tq_gemm_f32_jobs": (I, [VP, I, I, VP]),
+    "tq_fourier_features": (I, [VP, VP, VP, I, I, VP]),
     "tq_colsum": (I, [VP, I, I, I, VP, I, VP, VP, VP, VP]),
     "tq_zero_stuff": (I, [VP, VP, I, I, I, I, VP]),
     "tq_pair_sum": (I, [VP, VP, I, I, I, I, VP]),

@@ -768,3 +768,94 @@ extern "C" int tq_head_conv_bwd(const float* dpred_nct, const float* c_out, cons
     TQ_CHECK_LAUNCH();
     return 0;
 }
+
+
+// =================================================================================================
+// Small fp32 GEMMs of the embedding-MLP backward (unet.py:91-97, 210-227, 383-388): (B x 4mc)-sized matrices, a few hundred
+// MFLOP in all, exact fp32 FMA on the vector units.  One launch runs a LIST of independent GEMMs (the weight gradient, the bias
+// gradient as a product with a row of ones, and the data gradient of one MLP level), so the whole backward of the embedding path
+// is three dependent launches instead of ~25 library calls.
+//   C (M x N) = A (M x K) * f(B) (K x N)  [* dsilu(U)],  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+// =================================================================================================
+namespace {
+constexpr int GJ_T = 32;  // tile edge
+
+__global__ __launch_bounds__(256) void gemm_jobs_kernel(const TqGemmJob* __restrict__ jobs, int njobs) {
+    __shared__ float As[GJ_T][GJ_T + 1];
+    __shared__ float Bs[GJ_T][GJ_T + 1];
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile_begin) ++j;
+    const TqGemmJob jb = jobs[j];
+    const int tile = blockIdx.x - jb.tile_begin;
+    const int ntn = (jb.N + GJ_T - 1) / GJ_T;
+    const int m0 = (tile / ntn) * GJ_T, n0 = (tile % ntn) * GJ_T;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // thread -> outputs (m0 + ty + 16 i, n0 + tx + 16 jx)
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < jb.K; k0 += GJ_T) {
+        for (int i = threadIdx.x; i < GJ_T * GJ_T; i += 256) {
+            const int r = i / GJ_T, c = i % GJ_T;
+            // A tile: rows m, cols k.  Read along the operand's contiguous direction
+            {
+                const int mm = jb.sak == 1 ? r : c, kk = jb.sak == 1 ? c : r;
+                const int m = m0 + mm, k = k0 + kk;
+                As[mm][kk] = (m < jb.M && k < jb.K) ? jb.A[(size_t)m * jb.sam + (size_t)k * jb.sak] : 0.f;
+            }
+            {
+                const int kk = jb.sbn == 1 ? r : c, nn = jb.sbn == 1 ? c : r;
+                const int k = k0 + kk, n = n0 + nn;
+                float v = (k < jb.K && n < jb.N) ? jb.B[(size_t)k * jb.sbk + (size_t)n * jb.sbn] : 0.f;
+                if (jb.pre_b) v = silu_f(v);
+                Bs[kk][nn] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < GJ_T; ++k) {
+            const float a0 = As[ty][k], a1 = As[ty + 16][k];
+            const float b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) {
+            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * jx;
+            if (m < jb.M && n < jb.N) {
+                float v = acc[i][jx];
+                if (jb.U) v *= dsilu_f(jb.U[(size_t)m * jb.ldu + n]);
+                jb.C[(size_t)m * jb.ldc + n] = v;
+            }
+        }
+}
+
+__global__ void fourier_features_kernel(const float* __restrict__ t, const float* __restrict__ W, float* __restrict__ out, int B,
+                                        int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half;
+    float a = t[b] * W[j];      // blocks.py:24: x[:, None] * W[None, :] * 2 * pi, evaluated left to right in fp32
+    a = a * 2.0f;
+    a = a * 3.14159265358979323846f;
+    out[(size_t)b * 2 * half + j] = sinf(a);
+    out[(size_t)b * 2 * half + half + j] = cosf(a);
+}
+}  // namespace
+
+extern "C" int tq_gemm_tiles(int M, int N) { return ((M + GJ_T - 1) / GJ_T) * ((N + GJ_T - 1) / GJ_T); }
+
+extern "C" int tq_gemm_f32_jobs(const TqGemmJob* jobs_device, int njobs, int total_tiles, hipStream_t stream) {
+    if (!jobs_device || njobs <= 0 || total_tiles <= 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(gemm_jobs_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, jobs_device, njobs);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_fourier_features(const float* t, const float* W, float* out, int B, int half, hipStream_t stream) {
+    if (!t || !W || !out || B <= 0 || half <= 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(fourier_features_kernel, dim3((unsigned)((B * half + 255) / 256)), dim3(256), 0, stream, t, W, out, B, half);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}

@@ -20,11 +20,20 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ gscale, float* __restrict__ gshift,
                                                           float* __restrict__ mean_rstd) {
+    // Latency-bound (a few KB per sample): the kernel is three dependent steps, so every global load is issued as early as
+    // possible -- gamma / beta before anything else, a thread's slot loads all together before the first add.
     extern __shared__ double sh[];  // [C][2] channel sums, then [32][2] group mean/rstd
     const int C = C0 + C1;
     const int b = blockIdx.x;
     double* csum = sh;
     double* gstat = sh + 2 * C;
+    // folded-affine inputs of the last step (<= 2 channels per thread for C <= 512)
+    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = threadIdx.x + k * 256;
+        if (c < C) { gam[k] = gamma[c]; bet[k] = beta[c]; }
+    }
     // thread = (channel, slot part): PARTS threads share one channel's slots so the dependent-load chain is short
     const int PARTS = (C <= 64) ? 4 : ((C <= 128) ? 2 : 1);
     for (int idx = threadIdx.x; idx < C * PARTS; idx += blockDim.x) {
@@ -33,20 +42,26 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         int cs, cc;
         if (c < C0) { st = st0; cs = C0; cc = c; } else { st = st1; cs = C1; cc = c - C0; }
         const float* pp = st + ((size_t)b * nslots * cs + cc) * 2;
-        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
         double s1 = 0.0, s2 = 0.0;
         int s = part;
-        for (; s + PARTS < nslots; s += 2 * PARTS) {
-            const float2 v = *reinterpret_cast<const float2*>(pp + (size_t)s * cs * 2);
-            const float2 v2 = *reinterpret_cast<const float2*>(pp + (size_t)(s + PARTS) * cs * 2);
-            s1 += (double)v.x + (double)v2.x;
-            s2 += (double)v.y + (double)v2.y;
+        for (; s + 7 * PARTS < nslots; s += 8 * PARTS) {   // 8 loads in flight
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(pp + (size_t)(s + u * PARTS) * cs * 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
         }
-        for (; s < nslots; s += PARTS) {
-            const float2 v = *reinterpret_cast<const float2*>(pp + (size_t)s * cs * 2);
-            s1 += (double)v.x; s2 += (double)v.y;
+        {   // up to 7 left: again all loads first (clamped index, masked add)
+            float2 v[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int su = s + u * PARTS;
+                v[u] = *reinterpret_cast<const float2*>(pp + (size_t)(su < nslots ? su : (nslots - 1)) * cs * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (s + u * PARTS < nslots) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
         }
-        (void)s1a; (void)s2a; (void)s1b; (void)s2b;
         if (PARTS == 1) { csum[2 * c] = s1; csum[2 * c + 1] = s2; }
         else {
             // combine the parts of one channel (adjacent lanes)
@@ -73,12 +88,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / G;
-        const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
-        const float a = gamma[c] * rstd;
-        gscale[(size_t)b * C + c] = a;
-        gshift[(size_t)b * C + c] = beta[c] - mean * a;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = threadIdx.x + k * 256;
+        if (c < C) {
+            const int g = c / G;
+            const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
+            const float a = gam[k] * rstd;
+            gscale[(size_t)b * C + c] = a;
+            gshift[(size_t)b * C + c] = bet[k] - mean * a;
+        }
     }
 }
 }  // namespace
@@ -87,7 +106,7 @@ extern "C" int tq_gn_finalize(const float* stats0, int C0, const float* stats1, 
                               const float* beta, float* gscale, float* gshift, float* mean_rstd, hipStream_t stream) {
     if (!stats0 || !gamma || !beta || !gscale || !gshift || (C1 > 0 && !stats1)) return TQ_ERR_ARG;
     const int C = C0 + C1;
-    if (B <= 0 || T <= 0 || C <= 0 || C % GN_GROUPS) return TQ_ERR_SHAPE;
+    if (B <= 0 || T <= 0 || C <= 0 || C % GN_GROUPS || C > 512) return TQ_ERR_SHAPE;  // (two channels per thread in the last step)
     const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
     const size_t shbytes = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(double);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), shbytes, stream, stats0, C0, stats1, C1, T, nslots, gamma,

@@ -474,37 +474,75 @@ class BackwardPlan:
             self._fire_cache = cached
         return cached[1], cached[2]
 
-    def _embedding_backward(self, last):
-        """Backward of Fourier -> time MLP (+ cond MLP) -> per-block Linear(SiLU(emb)) (unet.py:91-97, 210-227, 383-388).
-        (B x 4mc) matrices: plain library GEMMs."""
-        e, m = self.e, self.m
-
-        def dsilu(u):
-            s = torch.sigmoid(u)
-            return s * (1 + u * (1 - s))
-
-        demb_all = self.demb_all
-        torch.mm(demb_all.t(), e.silu_emb, out=self.g_emb_w)
-        torch.sum(demb_all, dim=0, out=self.g_emb_b)
-        d_emb = torch.mm(demb_all, e.emb_w) * dsilu(e.emb)
+    def _embedding_jobs(self):
+        """The job tables of the embedding backward (built once: every operand is a static buffer of the plan or a parameter).
+        Three dependent levels, each ONE tq_gemm_f32_jobs launch:
+          1  d W_proj = d emb_all^T . SiLU(emb);  d b_proj = 1^T . d emb_all;  d emb = (d emb_all . W_proj) * SiLU'(emb)
+          2  per MLP (time, cond): d W_2 = d emb^T . SiLU(h);  d b_2 = 1^T . d emb;  d h = (d emb . W_2) * SiLU'(h)
+          3  per MLP: d W_0 = d h^T . input;  d b_0 = 1^T . d h      (input = Fourier features / cond)"""
+        from ._lib import TqGemmJob
+        e, m, B, dev = self.e, self.m, self.B, self.dev
+        E, Et, mc = e.E, e.emb_total, m.model_channels
+        self.ones = torch.ones(B, device=dev)
+        self.d_emb = self._empty(B, E)
+        self.dh0 = self._empty(B, E)
+        self.four = self._empty(B, mc)
         tm = m.time_mlp
-        h0 = e.emb_hidden[:, 0]
-        torch.mm(d_emb.t(), torch.nn.functional.silu(h0), out=self.gv(tm[2].weight))
-        torch.sum(d_emb, dim=0, out=self.gv(tm[2].bias))
-        dh0 = torch.mm(d_emb, tm[2].weight) * dsilu(h0)
-        t = last["timesteps"]
-        arg = t[:, None] * m.time_embed.W[None, :] * 2 * torch.pi
-        four = torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
-        torch.mm(dh0.t(), four, out=self.gv(tm[0].weight))
-        torch.sum(dh0, dim=0, out=self.gv(tm[0].bias))
-        if m.cond_features is not None:
-            cm = m.cond_mlp
+        h0 = e.emb_hidden[:, 0]       # (B, E) view, row stride 2E
+        cm = m.cond_mlp if m.cond_features is not None else None
+        if cm is not None:
+            self.dc0 = self._empty(B, E)
             c0 = e.emb_hidden[:, 1]
-            torch.mm(d_emb.t(), torch.nn.functional.silu(c0), out=self.gv(cm[2].weight))
-            torch.sum(d_emb, dim=0, out=self.gv(cm[2].bias))
-            dc0 = torch.mm(d_emb, cm[2].weight) * dsilu(c0)
-            torch.mm(dc0.t(), last["cond"], out=self.gv(cm[0].weight))
-            torch.sum(dc0, dim=0, out=self.gv(cm[0].bias))
+            self.cond_buf = self._empty(B, m.cond_features)
+
+        def job(A, sam, sak, Bm, sbk, sbn, Cm, ldc, M, N, K, U=None, ldu=0, pre_b=0):
+            jb = TqGemmJob()
+            jb.A, jb.B, jb.C, jb.U = A, Bm, Cm, U
+            jb.M, jb.N, jb.K = M, N, K
+            jb.sam, jb.sak, jb.sbk, jb.sbn, jb.ldc, jb.ldu, jb.pre_b = sam, sak, sbk, sbn, ldc, ldu, pre_b
+            return jb
+
+        demb, ones = self.demb_all, self.ones
+        hid = e.emb_hidden.stride(0)
+        lv1 = [job(_p(demb), 1, Et, _p(e.silu_emb), E, 1, _p(self.g_emb_w), E, Et, E, B),          # d W_proj
+               job(_p(ones), 0, 1, _p(demb), Et, 1, _p(self.g_emb_b), Et, 1, Et, B),                # d b_proj
+               job(_p(demb), Et, 1, _p(e.emb_w), E, 1, _p(self.d_emb), E, B, E, Et, U=_p(e.emb), ldu=E)]
+        lv2 = [job(_p(self.d_emb), 1, E, _p(h0), hid, 1, _p(self.gv(tm[2].weight)), E, E, E, B, pre_b=1),
+               job(_p(ones), 0, 1, _p(self.d_emb), E, 1, _p(self.gv(tm[2].bias)), E, 1, E, B),
+               job(_p(self.d_emb), E, 1, _p(tm[2].weight), E, 1, _p(self.dh0), E, B, E, E, U=_p(h0), ldu=hid)]
+        lv3 = [job(_p(self.dh0), 1, E, _p(self.four), mc, 1, _p(self.gv(tm[0].weight)), mc, E, mc, B),
+               job(_p(ones), 0, 1, _p(self.dh0), E, 1, _p(self.gv(tm[0].bias)), E, 1, E, B)]
+        if cm is not None:
+            nc = m.cond_features
+            lv2 += [job(_p(self.d_emb), 1, E, _p(c0), hid, 1, _p(self.gv(cm[2].weight)), E, E, E, B, pre_b=1),
+                    job(_p(ones), 0, 1, _p(self.d_emb), E, 1, _p(self.gv(cm[2].bias)), E, 1, E, B),
+                    job(_p(self.d_emb), E, 1, _p(cm[2].weight), E, 1, _p(self.dc0), E, B, E, E, U=_p(c0), ldu=hid)]
+            lv3 += [job(_p(self.dc0), 1, E, _p(self.cond_buf), nc, 1, _p(self.gv(cm[0].weight)), nc, E, nc, B),
+                    job(_p(ones), 0, 1, _p(self.dc0), E, 1, _p(self.gv(cm[0].bias)), E, 1, E, B)]
+        self._gemm_levels = []
+        for jobs in (lv1, lv2, lv3):
+            total = 0
+            for jb in jobs:
+                jb.tile_begin = total
+                total += self.lib.tq_gemm_tiles(jb.M, jb.N)
+            arr = (TqGemmJob * len(jobs))(*jobs)
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self._keep.append(table)
+            self._gemm_levels.append((table, len(jobs), total))
+
+    def _embedding_backward(self, last):
+        """Backward of Fourier -> time MLP (+ cond MLP) -> per-block Linear(SiLU(emb)) (unet.py:91-97, 210-227, 383-388): the
+        Fourier features and three tq_gemm_f32_jobs launches (see _embedding_jobs)."""
+        e, m, lib = self.e, self.m, self.lib
+        if getattr(self, "_gemm_levels", None) is None:
+            self._embedding_jobs()
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        check(lib.tq_fourier_features(_p(last["timesteps"]), _p(m.time_embed.W), _p(self.four), self.B, m.model_channels // 2, stream),
+              "fourier features")
+        if m.cond_features is not None:
+            self.cond_buf.copy_(last["cond"])
+        for table, n, total in self._gemm_levels:
+            check(lib.tq_gemm_f32_jobs(table.data_ptr(), n, total, stream), "embedding backward GEMMs")
 
 
 class SeqBackwardPlan(BackwardPlan):
