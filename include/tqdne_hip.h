@@ -137,6 +137,12 @@ int tq_conv1d_bwd_data(const TqConvBwdDesc* desc, const float* dy, const void* p
 size_t tq_conv1d_bwd_weight_workspace(const TqConvDesc* desc);
 int tq_conv1d_bwd_weight(const TqConvDesc* desc, const float* dy, const float* x0, const float* x1, const float* gscale,
                          const float* gshift, float* dw, void* workspace, size_t ws_bytes, hipStream_t stream);
+/* Same, with the column sums of dy fused in (the bias gradient and, per sample, the gradient of the broadcast time embedding,
+ * unet.py:141): colsum_bc[b * bc_stride + co] += sum_t dy[b, t, co], colsum_c[co] (and colsum_c2[co]) += sum_{b,t} dy -- each
+ * nullable, accumulated with atomics into buffers the caller has zeroed.  Saves the separate pass of tq_colsum over dy. */
+int tq_conv1d_bwd_weight_colsum(const TqConvDesc* desc, const float* dy, const float* x0, const float* x1, const float* gscale,
+                                const float* gshift, float* dw, void* workspace, size_t ws_bytes, float* colsum_bc, int bc_stride,
+                                float* colsum_c, float* colsum_c2, hipStream_t stream);
 
 /* First conv of the network: (B, C_in<=16, T) fp32 input, scaled per sample by in_scale[b] (EDM c_in, edm.py:107;
  * NULL = 1), k taps "same" -> (B, T, C_out) channels-last + bias (+ partial statistics).  unet.py:233. */

@@ -108,6 +108,7 @@ _PROTOS = {
     "tq_conv1d_bwd_data": (I, [VP] * 11),
     "tq_conv1d_bwd_weight_workspace": (SZ, [VP]),
     "tq_conv1d_bwd_weight": (I, [VP] * 8 + [SZ, VP]),
+    "tq_conv1d_bwd_weight_colsum": (I, [VP] * 8 + [SZ, VP, I, VP, VP, VP]),
     "tq_gn_bwd_finalize": (I, [VP, VP, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
     "tq_gn_bwd_apply": (I, [VP] * 7 + [I] * 6 + [VP]),
     "tq_gemm_tiles": (I, [I, I]),

@@ -45,6 +45,11 @@ struct WgArgs {
     uint32_t drop_site, drop_thresh;
     float drop_scale;
     uint64_t drop_seed;
+    // fused column sums of dy (bias / time-embedding gradients): accumulated by the workgroups of the first input-channel chunk
+    float* cs_bc;   // [b * cs_stride + co] += sum_t dy[b, t, co]   (nullable)
+    int cs_stride;
+    float* cs_c;    // [co] += sum_{b,t} dy                          (nullable)
+    float* cs_c2;   // second destination of the same sums           (nullable)
 };
 
 constexpr int WG_TT = 64;        // reduction positions per staged tile
@@ -127,9 +132,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         }
     };
 
+    // column sums of dy, fused (the stand-alone pass re-read every dy once more): accumulated in LDS (registers are what this
+    // kernel does not have: a float4 of running sums per thread tipped the k = 5 instantiation into 29 spills), flushed with
+    // global atomics when the sample changes and at the end.  All conditions are workgroup-uniform.
+    const bool do_cs = (cc == 0) && (p.cs_bc || p.cs_c);
+    float* cs_lds = reinterpret_cast<float*>(x_lo + X_PLANE);   // [128]
+    int cs_b = -1;
+    if (do_cs && tid < 128) cs_lds[tid] = 0.f;
+    auto cs_flush = [&]() __attribute__((always_inline)) {
+        if (tid < 128) {
+            const int c = co0 + tid;
+            const float v = cs_lds[tid];
+            if (cs_b >= 0 && c < p.C_out) {
+                if (p.cs_bc) atomicAdd(p.cs_bc + (size_t)cs_b * p.cs_stride + c, v);
+                if (p.cs_c) atomicAdd(p.cs_c + c, v);
+                if (p.cs_c2) atomicAdd(p.cs_c2 + c, v);
+            }
+            cs_lds[tid] = 0.f;
+        }
+    };
+
     auto write_unit = [&](int u) __attribute__((always_inline)) {
         const int b = u / p.n_ttiles;
         const int t0 = (u % p.n_ttiles) * WG_TT;
+        if (do_cs) {
+            if (b != cs_b) {   // (the previous unit's LDS adds are complete: a barrier separates the units)
+                cs_flush();
+                cs_b = b;
+                __syncthreads();
+            }
+            float4 a4 = dyr[0];
+#pragma unroll
+            for (int it = 1; it < 8; ++it) { a4.x += dyr[it].x; a4.y += dyr[it].y; a4.z += dyr[it].z; a4.w += dyr[it].w; }
+            float* dst = cs_lds + 4 * (tid & 31);
+            atomicAdd(dst, a4.x); atomicAdd(dst + 1, a4.y); atomicAdd(dst + 2, a4.z); atomicAdd(dst + 3, a4.w);
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int task = tid + it * 256;
@@ -229,6 +266,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         if (wave_active) compute();
     }
 
+    if (do_cs) {
+        __syncthreads();
+        cs_flush();
+    }
     // ---- partial result -> slab[sp][k][co][ci]
     if (!wave_active) return;
 #pragma unroll
@@ -293,7 +334,7 @@ void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_tti
 template <int KT, int STRIDE, int UPS>
 int launch_wgrad(const WgArgs& a, int nci, hipStream_t stream) {
     constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
-    const size_t sh = 2 * WG_TT * WG_DY_STRIDE + 2 * XR * 64 * nci;
+    const size_t sh = 2 * WG_TT * WG_DY_STRIDE + 2 * XR * 64 * nci + 128 * sizeof(float);   // (+ the fused column sums)
     const unsigned grid = (unsigned)(a.n_cotiles * a.n_cichunks * a.nsplit);
     if (nci == 2) {
         hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 2>), dim3(grid), dim3(256), sh, stream, a);
@@ -315,7 +356,15 @@ extern "C" size_t tq_conv1d_bwd_weight_workspace(const TqConvDesc* d) {
 extern "C" int tq_conv1d_bwd_weight(const TqConvDesc* d, const float* dy, const float* x0, const float* x1,
                                     const float* gscale, const float* gshift, float* dw, void* workspace, size_t ws_bytes,
                                     hipStream_t stream) {
+    return tq_conv1d_bwd_weight_colsum(d, dy, x0, x1, gscale, gshift, dw, workspace, ws_bytes, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int tq_conv1d_bwd_weight_colsum(const TqConvDesc* d, const float* dy, const float* x0, const float* x1,
+                                           const float* gscale, const float* gshift, float* dw, void* workspace, size_t ws_bytes,
+                                           float* colsum_bc, int bc_stride, float* colsum_c, float* colsum_c2,
+                                           hipStream_t stream) {
     if (!d || !dy || !x0 || !dw || !workspace) return TQ_ERR_ARG;
+    if (colsum_c2 && !colsum_c) return TQ_ERR_ARG;
     if (d->C_in0 <= 0 || d->C_in0 % 32 || d->C_in1 < 0 || d->C_in1 % 32 || d->C_out <= 0 || d->C_out % 32) return TQ_ERR_SHAPE;
     if (d->C_in1 > 0 && !x1) return TQ_ERR_ARG;
     if ((d->flags & TQ_CONV_GN) && (!gscale || !gshift)) return TQ_ERR_ARG;
@@ -324,6 +373,7 @@ extern "C" int tq_conv1d_bwd_weight(const TqConvDesc* d, const float* dy, const 
     a.dy = dy; a.x0 = x0; a.x1 = x1; a.gscale = gscale; a.gshift = gshift; a.slab = reinterpret_cast<float*>(workspace);
     a.B = d->B; a.T_in = d->T_in; a.T_out = d->T_out; a.C0 = d->C_in0; a.C1 = d->C_in1; a.C_out = d->C_out;
     a.flags = d->flags;
+    a.cs_bc = colsum_bc; a.cs_stride = bc_stride; a.cs_c = colsum_c; a.cs_c2 = colsum_c2;
     wgrad_plan(d, a.n_cotiles, a.n_cichunks, a.n_ttiles, a.nsplit, a.units_per_split);
     a.drop_site = d->dropout_site; a.drop_seed = d->dropout_seed;
     float pdrop = d->dropout_p;

@@ -28,6 +28,12 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# Column sums of dy (bias / time-embedding gradients) inside the weight-gradient launch (tq_conv1d_bwd_weight_colsum) instead of a pass
+# of their own: built and parity-tested, but measured SLOWER on the paper UNet (train step 32.1 vs 31.0 ms, same box): the LDS
+# adds and the extra barrier cost the k = 5 kernel more than the 1.9 ms of tq_colsum launches they replace.  Default off.
+FUSE_COLSUM = __import__("os").environ.get("TQDNE_FUSE_COLSUM", "0") != "0"
+
+
 def _nslots(T):
     return (T + STAT_SLOT - 1) // STAT_SLOT
 
@@ -184,20 +190,31 @@ class BackwardPlan:
         return self.gview[id(param)]
 
     # ------------------------------------------------------------------ emitters
-    def _wgrad(self, rec, dy, bias_colsum=True):
+    def _wgrad(self, rec, dy, bias_colsum=True, colsum=None):
+        """weight gradient of one conv; the column sums of dy that the block needs anyway (bias gradients, the per-sample gradient of
+        the broadcast time embedding) ride in the same launch: ``colsum`` = (per-sample destination address | None, its row stride,
+        bias gradient tensor | None, second bias gradient tensor | None); ``bias_colsum``: default = this conv's own bias."""
         lib, site = self.lib, rec.site
         need = lib.tq_conv1d_bwd_weight_workspace(C.byref(rec.desc))
         self.ws_bytes = max(getattr(self, "ws_bytes", 0), need)
         self._wgrad_ops.append(len(self.ops))
         s0 = rec.srcs[0]
         s1 = rec.srcs[1] if len(rec.srcs) > 1 else None
-        self.op_flops[len(self.ops)] = 2 * site.C_in * site.C_out * site.K * rec.desc.T_out * self.B
-        self.ops.append([lib.tq_conv1d_bwd_weight, [C.byref(rec.desc), _p(dy), _p(s0.buf), _p(s1.buf) if s1 else None,
-                                                    _p(rec.gn[0]) if rec.gn else None, _p(rec.gn[1]) if rec.gn else None,
-                                                    _p(self.g(site.weight)), None, 0], "wgrad:" + site.name])
-        if site.bias is not None and bias_colsum:
-            self.ops.append([lib.tq_colsum, [_p(dy), self.B, rec.out.T, site.C_out, None, 0, _p(self.g(site.bias)), None, None],
+        if colsum is None and bias_colsum and site.bias is not None:
+            colsum = (None, 0, site.bias, None)
+        bc, stride, c1, c2 = colsum if colsum is not None else (None, 0, None, None)
+        if FUSE_COLSUM is False and colsum is not None:   # A/B switch: the column sums as their own pass over dy
+            self.ops.append([lib.tq_colsum, [_p(dy), self.B, rec.out.T if rec.out is not None else rec.desc.T_out, site.C_out, bc, stride,
+                                             _p(self.g(c1)) if c1 is not None else None, _p(self.g(c2)) if c2 is not None else None, None],
                              "colsum:" + site.name])
+            bc, stride, c1, c2 = None, 0, None, None
+            self._wgrad_ops[-1] = len(self.ops)
+        self.op_flops[len(self.ops)] = 2 * site.C_in * site.C_out * site.K * rec.desc.T_out * self.B
+        self.ops.append([lib.tq_conv1d_bwd_weight_colsum, [C.byref(rec.desc), _p(dy), _p(s0.buf), _p(s1.buf) if s1 else None,
+                                                           _p(rec.gn[0]) if rec.gn else None, _p(rec.gn[1]) if rec.gn else None,
+                                                           _p(self.g(site.weight)), None, 0, bc, stride,
+                                                           _p(self.g(c1)) if c1 is not None else None,
+                                                           _p(self.g(c2)) if c2 is not None else None], "wgrad:" + site.name])
 
     def _dgrad(self, rec, dy, T, dsts, accumulate, chain=True, stats=True):
         """dy (B,T,C_out of the forward conv) -> gradient wrt the forward conv's (activated) inputs.
@@ -311,9 +328,7 @@ class BackwardPlan:
         dout = out.grad
         # conv2 (out_layers.3): weight grad, then data grad chained through dropout / SiLU / GN2.  The bias gradients of conv2
         # and of the 1x1 skip conv are the same column sums of d out: one pass
-        self._wgrad(rec2, dout, bias_colsum=False)
-        self.ops.append([self.lib.tq_colsum, [_p(dout), B, T, Co, None, 0, _p(self.g(rec2.site.bias)),
-                                              _p(self.g(rec_sk.site.bias)) if rec_sk is not None else None, None], "colsum:out"])
+        self._wgrad(rec2, dout, colsum=(None, 0, rec2.site.bias, rec_sk.site.bias if rec_sk is not None else None))
         G2 = self.scratch("G", T, Co)
         gst2 = self._dgrad(rec2, dout, T, [G2], accumulate=False)
         coef2 = self._gn_bwd(gst2, t["g2"], rb.out_layers[0], T, Co)
@@ -324,10 +339,8 @@ class BackwardPlan:
         emb_dst = None
         if hasattr(rb, "emb_layers"):
             emb_dst = self.demb_all.data_ptr() + 4 * self.e.emb_offsets[id(rb)]
-        self.ops.append([self.lib.tq_colsum, [_p(dh1), B, T, Co, emb_dst, self.e.emb_total, _p(self.g(rec1.site.bias)), None, None],
-                         "colsum:h1"])
         # conv1 (in_layers.2)
-        self._wgrad(rec1, dh1, bias_colsum=False)
+        self._wgrad(rec1, dh1, colsum=(emb_dst, self.e.emb_total, rec1.site.bias, None))
         Ctot = sum(s.C for s in srcs)
         G1 = [self.scratch("G1_%d" % i, T, s.C) for i, s in enumerate(srcs)]
         gst1 = self._dgrad(rec1, dh1, T, G1, accumulate=False)
