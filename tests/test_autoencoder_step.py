@@ -35,7 +35,7 @@ def test_oracle_ae_step_matches_reference():
         # fp32 autograd on both sides, different summation order; gradients that are zero in exact arithmetic (a conv bias in
         # front of a GroupNorm with one channel per group) are rounding noise of ~1e-10 and differ between hosts: hence the floor
         ref = torch.from_numpy(s["g:" + k])
-        assert float((v.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-6 * gmax) < 2e-5, k
+        assert float((v.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax) < 2e-5, k
 
 
 @pytest.mark.gpu
