@@ -430,16 +430,24 @@ def main():
     if rank == 0:
         flops_fwd = conv_flops_per_sample(edm.unet, T)
         k_ms, k_flops, k_name, k_n = probe.result()
-        mx8 = os.environ.get("TQDNE_CONV_SCHEME", "f16mx8").lower() == "f16mx8"
+        from tqdne_amd import _lib as _tl
+        scheme = os.environ.get("TQDNE_CONV_SCHEME", _tl.DEFAULT_SCHEME).lower()
+        if any(e.scheme == "bf16x3" for e in edm.unet._engine_cache.values()):
+            scheme = "bf16x3"   # (the range guard moved the plans)
+        mult = {"f16mx6": 1.5, "f16mx8": 2.0, "bf16x3": 3.0}[scheme]
+        notes = {
+            "f16mx6": "fp32 product contracted as 2 fp16 MFMAs + 1 block-scaled fp6 (e2m3, per-lane E8M0 scales) MFMA per 64 channels "
+                      "(TQ_WFMT_F16_MX6: the MFMA cycles of 1.5 bf16 products per algorithmic product; no TF32/xf32 on gfx950); frac = "
+                      "algorithmic FLOP/s over the dense bf16 MFMA peak, so 2/3 is the ceiling of this scheme",
+            "f16mx8": "fp32 product contracted as 2 fp16 MFMAs + 1 block-scaled fp8 MFMA per 64 channels (TQ_WFMT_F16_MX8: the MFMA "
+                      "cycles of 2 bf16 products per algorithmic product; no TF32/xf32 on gfx950); frac = algorithmic FLOP/s over the "
+                      "dense bf16 MFMA peak, so 1/2 is the ceiling of this scheme",
+            "bf16x3": "fp32 operands as bf16 hi/lo, 3 MFMA products per algorithmic product (no TF32/xf32 on gfx950); frac = algorithmic "
+                      "FLOP/s over the dense bf16 MFMA peak, so 1/3 is the ceiling of this scheme"}
         roofline = dict(bound="mfma", achieved=(k_flops / (k_ms * 1e-3) / 1e12) if k_ms else None,
                         peak=MFMA_BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
                         kernel=k_name, launches_timed=k_n, avg_launch_ms=k_ms, algorithmic_flop_per_launch=k_flops,
-                        executed_mfma_flop_equiv_per_launch=(2 if mx8 else 3) * k_flops,
-                        note=("fp32 product contracted as 2 fp16 MFMAs + 1 block-scaled fp8 MFMA per 64 channels (TQ_WFMT_F16_MX8: "
-                              "the MFMA cycles of 2 bf16 products per algorithmic product; no TF32/xf32 on gfx950); frac = algorithmic "
-                              "FLOP/s over the dense bf16 MFMA peak, so 1/2 is the ceiling of this scheme") if mx8 else
-                             ("fp32 operands as bf16 hi/lo, 3 MFMA products per algorithmic product (no TF32/xf32 on gfx950); "
-                              "frac = algorithmic FLOP/s over the dense bf16 MFMA peak, so 1/3 is the ceiling of this scheme"))
+                        executed_mfma_flop_equiv_per_launch=mult * k_flops, scheme=scheme, note=notes[scheme])
         if roofline["achieved"]:
             roofline["frac"] = roofline["achieved"] / roofline["peak"]
         # HBM traffic of the same launch from PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
@@ -498,7 +506,7 @@ def main():
             "value": value, "unit": "waveforms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median": _median(per_step), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (contractions on MFMA with fp32 accumulate: bf16x3, and fp16 + block-scaled-fp8 corrections on the 128/256-channel forward convs; sampler state f64)", "data": "synthetic",
+            "dtype": "f32 (contractions on MFMA with fp32 accumulate: bf16x3, and fp16 + block-scaled-fp6 corrections on the 128/256-channel forward convs; sampler state f64)", "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}",
                        "hip_graph": use_graph, "sampler_lanes": 1 if use_graph else sampler_lanes(B), "mode": args.mode},
             "parts": parts,

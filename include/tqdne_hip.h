@@ -52,6 +52,10 @@ typedef struct ihipStream_t* hipStream_t;
  * channels (pack mode 2). */
 #define TQ_WFMT_BF16X3 0
 #define TQ_WFMT_F16_MX8 1
+/* F16_MX6: as F16_MX8 with e2m3 (fp6) correction operands and per-lane E8M0 block scales (one per 16 channels): 12 instead of 16
+ * MFMA passes per 64 channels and corrections that do not clamp; same shapes, same fp16 RANGE of the activation operand (pack
+ * mode 3). */
+#define TQ_WFMT_F16_MX6 2
 
 typedef struct TqConvDesc {
     int32_t B, T_in, T_out;
@@ -97,7 +101,7 @@ int tq_abi_version(void);
 /* ---- weights -------------------------------------------------------------------------------------------- */
 /* Pack a torch Conv1d weight (C_out, C_in, K) fp32 into per-lane MFMA fragments.
  * mode 0: forward operand, TQ_WFMT_BF16X3; mode 1: data-gradient operand (transposed + tap-flipped), TQ_WFMT_BF16X3;
- * mode 2: forward operand, TQ_WFMT_F16_MX8. */
+ * mode 2: forward operand, TQ_WFMT_F16_MX8; mode 3: forward operand, TQ_WFMT_F16_MX6. */
 size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode);
 int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* packed, hipStream_t stream);
 int tq_conv_tile_co(int C_out);

@@ -98,8 +98,9 @@ def _heavy(shape, g, tail_every, tail, scale=1.0):
     return torch.where(m, x * tail, x)
 
 
+@pytest.mark.parametrize("scheme", ["f16mx8", "f16mx6"])
 @pytest.mark.parametrize("case", ["normalised", "residual_stream", "fused_skip"])
-def test_f16_mx8_conv_on_trained_like_statistics(case):
+def test_f16_mx8_conv_on_trained_like_statistics(case, scheme):
     """|x| up to ~1e4 with a per-channel scale spread of 1e3, |w| up to ~10 with heavy tails: the fp16-range scheme must stay inside
     1e-3 (its fp8 corrections saturate gracefully: beyond their range the product keeps fp16's 2^-12 relative accuracy)"""
     from tqdne_amd import _lib, ops
@@ -129,12 +130,13 @@ def test_f16_mx8_conv_on_trained_like_statistics(case):
         kw = dict(gscale=gs.to(d), gshift=gh.to(d), silu=True)
         ref_x = torch.nn.functional.silu(x * gs[:, None, :] + gh[:, None, :])
         skip = (xs.to(d), None, ws.to(d), bs.to(d))
-    y, _ = ops.conv1d(x.to(d), w.to(d), bias.to(d), wfmt=_lib.TQ_WFMT_F16_MX8, skip=skip, **kw)
+    wfmt = _lib.TQ_WFMT_F16_MX8 if scheme == "f16mx8" else _lib.TQ_WFMT_F16_MX6
+    y, _ = ops.conv1d(x.to(d), w.to(d), bias.to(d), wfmt=wfmt, skip=skip, **kw)
     ref = torch.nn.functional.conv1d(ref_x.double().permute(0, 2, 1), w.double(), bias.double(), padding=K // 2)
     if skip is not None:
         ref = ref + torch.nn.functional.conv1d(xs.double().permute(0, 2, 1), ws.double(), bs.double())
     e = rel_err(y.cpu().permute(0, 2, 1), ref)
-    print(f"f16+mx8 on trained-like statistics ({case}): max|x| {float(x.abs().max()):.3g}, max|w| {float(w.abs().max()):.3g}, "
+    print(f"{scheme} on trained-like statistics ({case}): max|x| {float(x.abs().max()):.3g}, max|w| {float(w.abs().max()):.3g}, "
           f"rel err {e:.2e}")
     assert torch.isfinite(y).all() and e < TOL
 
@@ -158,7 +160,7 @@ def test_range_guard_moves_the_plan_to_bf16x3():
     B, T = 2, 1024
     x, t = torch.randn(B, 3, T, generator=g), torch.randn(B, generator=g) * 0.5
     eng = m._engine(B, T, dev())
-    assert eng.scheme == "auto" and any(d.wfmt == 1 for d, _, _ in eng._wfmt_sites), "the test net must have fp16-range launches"
+    assert eng.scheme == "auto" and any(d.wfmt != 0 for d, _, _ in eng._wfmt_sites), "the test net must have fp16-range launches"
     with warnings.catch_warnings(record=True) as rec, torch.no_grad():
         warnings.simplefilter("always")
         y = m(x.to(dev()), t.to(dev())).cpu()

@@ -72,24 +72,28 @@ def test_conv_both_contraction_schemes(cin0, cin1, cout, k, T, gn):
     b = torch.randn(cout, generator=g)
     a, sh = (torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g)) if gn else (None, None)
     d = dev()
-    assert _lib.forward_wfmt(cout, [cin0, cin1]) == _lib.TQ_WFMT_F16_MX8 or os.environ.get("TQDNE_CONV_SCHEME") == "bf16x3"
+    assert _lib.forward_wfmt(cout, [cin0, cin1]) != _lib.TQ_WFMT_BF16X3 or os.environ.get("TQDNE_CONV_SCHEME") == "bf16x3"
     xin = torch.cat([x0, x1], 1) if cin1 else x0
     if gn:
         xin = F.silu(xin * a[:, :, None] + sh[:, :, None])
     ref = F.conv1d(xin, w, b, padding=k // 2)
-    for wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX8):
+    errs = {}
+    for wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX8, _lib.TQ_WFMT_F16_MX6):
         y, st = ops.conv1d(cl(x0), w.to(d), b.to(d), x1=cl(x1) if cin1 else None, gscale=a.to(d) if gn else None,
                            gshift=sh.to(d) if gn else None, silu=gn, wfmt=wfmt)
-        assert rel_err(ncw(y), ref) < TOL, wfmt
+        errs[wfmt] = rel_err(ncw(y), ref)
+        assert errs[wfmt] < TOL, (wfmt, errs)
         assert rel_err(st.cpu(), ref_stats(ref)) < TOL, wfmt
+    print("rel err bf16x3 / f16+mx8 / f16+mx6:", " / ".join(f"{errs[k]:.1e}" for k in sorted(errs)))
     # fp16 range of the activation operand: inputs beyond 65504 surface as inf / NaN (loud), NaN inputs stay NaN
-    big = cl(x0 * 1e6)
-    y, _ = ops.conv1d(big, w[:, :cin0].contiguous().to(d), b.to(d), wfmt=_lib.TQ_WFMT_F16_MX8, stats=False)
-    assert not torch.isfinite(y).all()
-    xn = cl(x0).clone()
-    xn[0, 5, 3] = float("nan")
-    y, _ = ops.conv1d(xn, w[:, :cin0].contiguous().to(d), b.to(d), wfmt=_lib.TQ_WFMT_F16_MX8, stats=False)
-    assert torch.isnan(y[0, 5]).any() and torch.isfinite(y[1]).all()
+    for wfmt in (_lib.TQ_WFMT_F16_MX8, _lib.TQ_WFMT_F16_MX6):
+        big = cl(x0 * 1e6)
+        y, _ = ops.conv1d(big, w[:, :cin0].contiguous().to(d), b.to(d), wfmt=wfmt, stats=False)
+        assert not torch.isfinite(y).all()
+        xn = cl(x0).clone()
+        xn[0, 5, 3] = float("nan")
+        y, _ = ops.conv1d(xn, w[:, :cin0].contiguous().to(d), b.to(d), wfmt=wfmt, stats=False)
+        assert torch.isnan(y[0, 5]).any() and torch.isfinite(y[1]).all()
 
 
 @pytest.mark.parametrize("cin0,cin1,cout,T,gn", [
@@ -202,7 +206,7 @@ def test_conv_upsample_polyphase(C0, C1, Co, T):
     d = dev()
     x0, x1 = cl(x[:, :C0]), (cl(x[:, C0:]) if C1 else None)
     for wfmt in {_lib.forward_wfmt(2 * Co, [C0, C1]), _lib.TQ_WFMT_BF16X3}:
-        wp = ops.pack_conv_weight(w2.to(d), 2 if wfmt == _lib.TQ_WFMT_F16_MX8 else 0)
+        wp = ops.pack_conv_weight(w2.to(d), _lib.PACK_MODE[wfmt])
         y = torch.full((B, 2 * T, Co), float("nan"), device=d)
         st = torch.full((B, 2 * T // 128, Co, 2), float("nan"), device=d)
         desc = _lib.TqConvDesc()

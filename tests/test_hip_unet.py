@@ -513,7 +513,7 @@ def test_inference_forward_matches_backward_capable_forward(which):
     assert torch.equal(a2, a)
     npoly = sum(op[2].endswith("+polyphase") for op in eng2.ops_infer)
     assert npoly == (3 if which == "paper" else 0)
-    assert rel_err(b2.cpu(), a.cpu()) < 2e-5
+    assert rel_err(b2.cpu(), a.cpu()) < 4e-5
 
 
 def test_latent_edm_training_step_gradients_vs_oracle():

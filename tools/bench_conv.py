@@ -25,7 +25,7 @@ for (C0, C1, Co, K, T, gn) in LAYERS:
     y = torch.empty(B, T, Co, device=dev)
     st = torch.empty(B, (T + 127) // 128, Co, 2, device=dev)
     d_wfmt = _lib.forward_wfmt(Co, [C0, C1])
-    wp = ops.pack_conv_weight(w, 2 if d_wfmt == _lib.TQ_WFMT_F16_MX8 else 0)
+    wp = ops.pack_conv_weight(w, _lib.PACK_MODE[d_wfmt])
     d = _lib.TqConvDesc()
     d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T, T, C0, C1, Co
     d.ktaps, d.stride, d.pad, d.upsample = K, 1, K // 2, 0

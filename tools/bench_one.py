@@ -19,7 +19,7 @@ gh = torch.randn(B, C0 + C1, device=dev)
 y = torch.empty(B, T, Co, device=dev)
 st = torch.empty(B, (T + 127) // 128, Co, 2, device=dev)
 wfmt = _lib.forward_wfmt(Co, [C0, C1])
-wp = ops.pack_conv_weight(w, 2 if wfmt == _lib.TQ_WFMT_F16_MX8 else 0)
+wp = ops.pack_conv_weight(w, _lib.PACK_MODE[wfmt])
 d = _lib.TqConvDesc()
 d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T, T, C0, C1, Co
 d.ktaps, d.stride, d.pad, d.upsample, d.flags = K, 1, K // 2, 0, 3 | 16

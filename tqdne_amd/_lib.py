@@ -18,20 +18,27 @@ SZ = C.c_size_t
 
 TQ_CONV_GN, TQ_CONV_SILU, TQ_CONV_EMB, TQ_CONV_RES, TQ_CONV_STATS, TQ_CONV_DROPOUT = 1, 2, 4, 8, 16, 32
 TQ_CONV_POLY2 = 64
-TQ_WFMT_BF16X3, TQ_WFMT_F16_MX8 = 0, 1
+TQ_WFMT_BF16X3, TQ_WFMT_F16_MX8, TQ_WFMT_F16_MX6 = 0, 1, 2
+PACK_MODE = {TQ_WFMT_BF16X3: 0, TQ_WFMT_F16_MX8: 2, TQ_WFMT_F16_MX6: 3}   # tq_pack_conv_weight mode of a forward weight format
+
+
+DEFAULT_SCHEME = "f16mx6"
 
 
 def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False) -> int:
-    """Contraction scheme of a forward conv launch (include/tqdne_hip.h, TQ_WFMT_*): fp16 + block-scaled-fp8 corrections where
-    the kernel is built for the shape (stride 1 incl. the nearest-upsampling convs, 128 | C_out, 64 | every source's channels incl. a fused skip conv's), bf16x3 elsewhere.
-    TQDNE_CONV_SCHEME=bf16x3 forces the fp32-range three-product scheme everywhere."""
-    v = os.environ.get("TQDNE_CONV_SCHEME", "f16mx8").lower()
-    if v not in ("bf16x3", "f16mx8"):
-        raise ValueError(f"TQDNE_CONV_SCHEME={v!r}: expected bf16x3 or f16mx8")
+    """Contraction scheme of a forward conv launch (include/tqdne_hip.h, TQ_WFMT_*): fp16 + block-scaled corrections where the kernel
+    is built for the shape (stride 1 incl. the nearest-upsampling convs, 128 | C_out, 64 | every source's channels incl. a fused skip
+    conv's), bf16x3 elsewhere.  TQDNE_CONV_SCHEME: f16mx6 (default: e2m3 corrections with per-lane block scales), f16mx8 (round 1's
+    e4m3 corrections with uniform scales), bf16x3 (the fp32-range three-product scheme everywhere)."""
+    v = os.environ.get("TQDNE_CONV_SCHEME", DEFAULT_SCHEME).lower()
+    if v not in ("bf16x3", "f16mx8", "f16mx6"):
+        raise ValueError(f"TQDNE_CONV_SCHEME={v!r}: expected bf16x3, f16mx8 or f16mx6")
     ok = stride == 1 and C_out % 128 == 0 and all(c % 64 == 0 for c in sources if c)
     if fused_skip:
         ok = ok and os.environ.get("TQDNE_FUSED_SKIP_MX8", "1") != "0"
-    return TQ_WFMT_F16_MX8 if (v == "f16mx8" and ok) else TQ_WFMT_BF16X3
+    if not ok or v == "bf16x3":
+        return TQ_WFMT_BF16X3
+    return TQ_WFMT_F16_MX6 if v == "f16mx6" else TQ_WFMT_F16_MX8
 TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_DROPOUT, TQ_BWD_ACCUM, TQ_BWD_STATS = 1, 2, 4, 8, 16
 STAT_SLOT = 128
 

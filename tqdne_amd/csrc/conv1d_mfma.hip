@@ -105,11 +105,16 @@ struct ConvArgs {
 //      fp8(w), bytes 16..31 fp8(x) against fp8(wl * 2^12), uniform E8M0 scales 2^0 (A) and 2^-12 (B).  The corrections are 2^-12
 //      of the product, so fp8's 2^-4 leaves ~2^-15 like bf16x3, at 2/3 of its MFMA cycles.  fp16 RANGE applies to x (|x| > 65504
 //      becomes inf in the output, relative precision is lost below 6e-5): forward activations only.
+//   2  "f16+mx6": as 1, but the correction operands are e2m3 (fp6) with a per-lane E8M0 block scale (one per 16 channels x
+//      {x_l * 2^12, x}), produced by v_cvt_scalef32_2xpk16_fp6_f32: the block-scaled MFMA then takes 4 passes instead of 8 (12
+//      instead of 16 per 64 channels) and the corrections no longer clamp (fp8 with uniform scales saturates beyond |x| = 448 and
+//      |x_l| = 0.109): measured 5e-5 against 7e-4 of the output scale on heavy-tailed data (tools/micro/fp6_scheme_probe.hip).
+//      Staging layout: a thread owns 16 consecutive channels of a row (= exactly one lane fragment of the correction operand).
 template <int KT, int STRIDE, int UPS, int WM, int WN, int SCH = 0>
 struct Cfg {
     static constexpr int CH = SCH ? 64 : 32;     // channels per chunk
     static constexpr int ROWB = 2 * CH;          // bytes per row of one LDS plane
-    static constexpr int TPR = CH / 4;           // staging threads per row (4 channels each)
+    static constexpr int TPR = (SCH == 2) ? 4 : CH / 4;  // staging threads per row (4 channels each; scheme 2: 16 channels each)
     static constexpr int NW = SCH ? 8 : 4;       // 16-byte weight fragments per lane and (chunk, tap): 2 co blocks x NW/2
     static constexpr int NBF = SCH ? 4 : 2;      // 16-byte activation fragments per lane and (tap, t-block)
     static constexpr int NTHR = 64 * WM * WN;
@@ -124,12 +129,32 @@ struct Cfg {
     static constexpr int PRE = NIT < PRE_MAX ? NIT : PRE_MAX;
     static constexpr int SYNC_BATCH = 4;           // the rest is loaded+written synchronously in batches
     static constexpr int ITERS = (NIT <= PRE) ? NIT : PRE + ((NIT - PRE + SYNC_BATCH - 1) / SYNC_BATCH) * SYNC_BATCH;
-    static constexpr int ROWS_PAD = (ITERS * NTHR + TPR - 1) / TPR;  // every staging task lands in-bounds: no predicate
+    // scheme 2 stages rows [0, NT) in NFULL full iterations of NTHR 16-channel tasks and the KT - 1 halo rows in one predicated step
+    static constexpr int NFULL = (SCH == 2) ? (NT * 4) / NTHR : 0;
+    static constexpr int HALO_TASKS = (SCH == 2) ? (ROWS - NT) * 4 : 0;
+    static constexpr int ROWS_PAD = (SCH == 2) ? ROWS : (ITERS * NTHR + TPR - 1) / TPR;  // every staging task lands in-bounds: no predicate
     static constexpr int PLANE = (ROWS_PAD > ROWS ? ROWS_PAD : ROWS) * ROWB;  // bytes per plane
     static constexpr int BUF = 2 * PLANE;         // hi + lo
     static constexpr int LDS_BYTES = 2 * BUF;     // double buffered
     static constexpr int PAD = (STRIDE == 1) ? (KT / 2) : 1;
 };
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+
+// hipcc (ROCm 7.2) lets the destination of v_cvt_scalef32_2xpk16_fp6_f32 overlap its scale / source registers and the instruction
+// does not read everything before it writes (tools/micro/fp6_scheme_probe.hip): the early-clobber output keeps them apart.
+// out[2i] = fp6(a[i] / scale), out[2i + 1] = fp6(b[i] / scale), e2m3, round to nearest, saturating.
+__device__ __forceinline__ u32x6 cvt_2xpk16_fp6(const f32x16& a, const f32x16& b, float scale) {
+    u32x6 out;
+    asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(out) : "v"(a), "v"(b), "v"(scale));
+    return out;
+}
+// biased E8M0 exponent of the smallest power of two 2^e with mx / 2^e <= 7.5 (the e2m3 maximum); >= 13 so that "- 12" stays valid
+__device__ __forceinline__ unsigned e8m0_block_scale(float mx) {
+    const unsigned b = (__float_as_uint(mx * (1.0f / 7.5f)) + 0x7FFFFFu) >> 23;
+    return b < 13u ? 13u : (b > 254u ? 254u : b);
+}
 
 // ACT (compile time): prologue applied while staging -- 0 none, 1 folded GN, 2 GN + SiLU, 3 GN + SiLU + dropout
 // FUSE: the ResBlock's 1x1 skip convolution (unet.py:112,143) is accumulated into the same MFMA accumulators as extra
@@ -141,7 +166,8 @@ struct Cfg {
 template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
     static_assert(SCH == 0 || (EPI != 1 && STRIDE == 1), "the fp16-range scheme serves stride-1 forward launches");
-    static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH == 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, f16+mx8");
+    static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH >= 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, fp16-range schemes");
+    static_assert(SCH != 2 || WN == 1, "scheme 2 tiles are 128 positions wide");
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef TQ_STAMP
@@ -300,8 +326,90 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         }
     };
 
+    // ---- scheme 2 staging: a thread owns the 16 consecutive channels 16 m2 .. 16 m2 + 15 of a row (one lane fragment of the
+    // block-scaled operand); folded GroupNorm coefficients come from an LDS table filled once per workgroup (32 of them per
+    // thread would not fit in registers across the MFMA phase)
+    const int m2 = tid & 3;
+    float4 raw2[4];
+    float* gtab = reinterpret_cast<float*>(lds + (PW ? 4 * C::BUF : C::LDS_BYTES));   // [Cin] scale, [Cin] shift of sample b
+    auto chunk_base2 = [&](int stage, int& cs) -> const float* __attribute__((always_inline)) {
+        const bool sk = FUSE && stage >= nchunks;
+        const int cb = (sk ? stage - nchunks : stage) * C::CH;
+        const float* a0 = sk ? p.sx0 : p.x0;
+        const float* a1 = sk ? p.sx1 : p.x1;
+        const int c0 = sk ? p.sC0 : p.C0, c1 = sk ? p.sC1 : p.C1;
+        const bool first = cb < c0;
+        cs = first ? c0 : c1;
+        return (first ? a0 : a1) + (size_t)b * p.T_in * cs + (first ? cb : cb - c0) + 16 * m2;
+    };
+    auto load16 = [&](const float* base, int cs, int row, float4 (&v)[4]) __attribute__((always_inline)) {
+        int pos = src_pos(row);
+        pos = pos < 0 ? 0 : (pos >= T_src ? T_src - 1 : pos);
+        const float4* q = reinterpret_cast<const float4*>(base + (size_t)(UPS ? (pos >> 1) : pos) * cs);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    };
+    auto write16 = [&](int chunk, int buf, int row, const float4 (&v)[4]) __attribute__((always_inline)) {
+        unsigned char* hi_plane = lds + buf * C::BUF;
+        unsigned char* lo_plane = hi_plane + C::PLANE;
+        const int pos = src_pos(row);
+        const float msk = (pos >= 0 && pos < T_src) ? 1.f : 0.f;
+        float u[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                       v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+        const bool act = !(FUSE && chunk >= nchunks);  // skip stages stage the raw block input
+        if (ACT >= 1 && act) {
+            const int cb = chunk * C::CH + 16 * m2;
+            const float4* ga = reinterpret_cast<const float4*>(gtab + cb);
+            const float4* gs = reinterpret_cast<const float4*>(gtab + Cin + cb);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 a = ga[q4], sh = gs[q4];
+                u[4 * q4 + 0] = fmaf(a.x, u[4 * q4 + 0], sh.x); u[4 * q4 + 1] = fmaf(a.y, u[4 * q4 + 1], sh.y);
+                u[4 * q4 + 2] = fmaf(a.z, u[4 * q4 + 2], sh.z); u[4 * q4 + 3] = fmaf(a.w, u[4 * q4 + 3], sh.w);
+            }
+        }
+        if (ACT >= 2 && act) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                u[j] = u[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[j] * -1.4426950408889634f));
+        }
+        if (ACT == 3 && act) {
+            const int pc = pos < 0 ? 0 : pos;
+            const uint64_t e0 = ((uint64_t)b * T_src + pc) * Cin + chunk * C::CH + 16 * m2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                u[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? u[j] * p.drop_scale : 0.f;
+        }
+        f16x8 h0, h1;
+        f32x16 xl, xf;
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float x = u[j] * msk;
+            const _Float16 hv = (_Float16)x;  // |x| > 65504 -> inf, NaN stays NaN: out-of-range inputs surface in the output
+            if (j < 8) h0[j] = hv; else h1[j - 8] = hv;
+            const float r = (x - (float)hv) * 4096.f;
+            xl[j] = r; xf[j] = x;
+            mx = fmaxf(mx, fmaxf(fabsf(r), fabsf(x)));
+        }
+        const unsigned bb = e8m0_block_scale(mx);
+        const u32x6 pk = cvt_2xpk16_fp6(xl, xf, __uint_as_float(bb << 23));
+        const int sw = row & 7;
+        const int ro = row * 128;
+        *reinterpret_cast<uint4*>(hi_plane + ro + (((2 * m2) ^ sw) << 4)) = __builtin_bit_cast(uint4, h0);
+        *reinterpret_cast<uint4*>(hi_plane + ro + (((2 * m2 + 1) ^ sw) << 4)) = __builtin_bit_cast(uint4, h1);
+        *reinterpret_cast<uint4*>(lo_plane + ro + ((m2 ^ sw) << 4)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        // the lane's E8M0 byte for the MFMA, with the 2^-12 of both correction products folded in
+        *reinterpret_cast<uint4*>(lo_plane + ro + (((4 + m2) ^ sw) << 4)) = make_uint4(pk[4], pk[5], bb - 12u, 0u);
+    };
+
     // phase 1 (before the MFMAs of the previous chunk): issue the first PRE iterations' loads
     auto stage_load = [&](int chunk) __attribute__((always_inline)) {
+        if constexpr (SCH == 2) {
+            int cs2;
+            const float* base2 = chunk_base2(chunk, cs2);
+            load16(base2, cs2, tid >> 2, raw2);
+            return;
+        }
         int cs;
         const float* base = chunk_base(chunk, cs);
 #pragma unroll
@@ -315,6 +423,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 
     // phase 2 (after them): transform + LDS write; iterations beyond PRE are loaded here in small batches
     auto stage_write = [&](int chunk, int buf) __attribute__((always_inline)) {
+        if constexpr (SCH == 2) {
+            int cs2;
+            const float* base2 = chunk_base2(chunk, cs2);
+            // the KT - 1 halo rows: loads issued first by every thread (tasks past the halo re-read its last row: an L1 hit),
+            // converted last, by the HALO_TASKS threads that own them -- their latency hides behind the main conversion
+            float4 hv4[4];
+            if constexpr (C::HALO_TASKS > 0) {
+                const int hr = tid >> 2;
+                load16(base2, cs2, C::NT + (hr < C::ROWS - C::NT ? hr : C::ROWS - C::NT - 1), hv4);
+            }
+            write16(chunk, buf, tid >> 2, raw2);
+#pragma unroll 1
+            for (int it = 1; it < C::NFULL; ++it) {   // (4-wave tile: second half of the rows, loaded here)
+                float4 t4[4];
+                load16(base2, cs2, (tid >> 2) + it * (C::NTHR / 4), t4);
+                write16(chunk, buf, (tid >> 2) + it * (C::NTHR / 4), t4);
+            }
+            if constexpr (C::HALO_TASKS > 0) {
+                if (tid < C::HALO_TASKS) write16(chunk, buf, C::NT + (tid >> 2), hv4);
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < PRE; ++it)
             write_one(chunk, buf, it, raw[it]);
@@ -369,7 +499,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // leaves the swizzle term unchanged (both schemes): one address per tap, t-blocks are immediate offsets.
     auto tap_base = [&](int k) -> int __attribute__((always_inline)) {
         int tl = tl_lane;
-        if constexpr (SCH == 1) {
+        if constexpr (SCH >= 1) {
             // recomputed per tap (4 VALU): hoisted out of the chunk loop the per-tap addresses are live across it, get spilled,
             // and each reload waits for vmcnt(0), i.e. for the staging loads in flight
             asm volatile("" : "+v"(tl));
@@ -403,6 +533,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
                 acc[cbk][tb] = mfma_x3(w[cbk * 2].v, w[cbk * 2 + 1].v, f[0].v, f[1].v, acc[cbk][tb]);
+        } else if constexpr (SCH == 2) {
+            // fp6 fragments: dwords 0..5 of the i32x8 (the last two are ignored for 6-bit operands); the lane's E8M0 byte travels
+            // in dword 6 of its own fragment (weights: from the packer; activations: from write16, with the 2^-12 folded in)
+            const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
+                              (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
+            const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 0].u), b0v, acc[cbk][tb], 0, 0, 0);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 1].u), b1v, acc[cbk][tb], 0, 0, 0);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const Frag& c0 = w[cbk * 4 + 2];
+                const Frag& c1 = w[cbk * 4 + 3];
+                const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
+                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, (int)c1.u.z, 0, (int)f[3].u.z);
+            }
         } else {
             const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
                               (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
@@ -441,7 +590,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
     // b = tap 1 already in flight.
     Frag wa[C::NW], wb[C::NW];
-    constexpr int LDS_DEP = SCH ? TQ_LDS_DEPTH1 : TQ_LDS_DEPTH;  // scheme 1: 128 MFMA cycles per step, and registers are tight
+#ifndef TQ_LDS_DEPTH2
+#define TQ_LDS_DEPTH2 1
+#endif
+    // scheme 1: 128 MFMA cycles per step, and registers are tight; scheme 2: 96 cycles per step, ~225 registers
+    constexpr int LDS_DEP = SCH == 2 ? TQ_LDS_DEPTH2 : (SCH ? TQ_LDS_DEPTH1 : TQ_LDS_DEPTH);
 
     // MFMA phase of one chunk = ONE stream of NTAPS x 8 (tap, t-block) steps.  B fragments are read LDS_DEP steps ahead of the
     // MFMAs that consume them, across tap boundaries too (a per-tap restart exposed the LDS latency KT times per chunk).
@@ -500,10 +653,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if constexpr (SCH == 2 && ACT >= 1) {  // folded GroupNorm coefficients of sample b -> LDS (read by write16)
+        const float4* gsrc = reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin);
+        const float4* hsrc = reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin);
+        float4* g4 = reinterpret_cast<float4*>(gtab);
+        for (int i = tid; i < (Cin >> 2); i += C::NTHR) { g4[i] = gsrc[i]; g4[(Cin >> 2) + i] = hsrc[i]; }
+        __syncthreads();
+    }
     const int npass = PW ? n_ctiles : 1;
     if constexpr (PW) {
         // every chunk's loads in flight together (64 + 32 registers, nothing else is live yet), then one transform + store pass
-        static_assert(!PW || C::NIT == C::PRE, "PW stages a chunk in PRE iterations");
+        static_assert(!PW || SCH == 2 || C::NIT == C::PRE, "PW stages a chunk in PRE iterations");
+        static_assert(!PW || SCH != 2 || (C::NFULL == 1 && C::HALO_TASKS == 0), "PW, scheme 2: one 16-channel task per thread and chunk");
+        if constexpr (SCH == 2) {
+            float4 rr2[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int cs2;
+                const float* base2 = chunk_base2(c < nchunks ? c : nchunks - 1, cs2);
+                load16(base2, cs2, tid >> 2, rr2[c]);
+            }
+            load_w(0, wa);
+            load_w(1, wb);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) write16(c < nchunks ? c : nchunks - 1, c, tid >> 2, rr2[c]);
+            __syncthreads();
+        } else {
         float4 rr[4][C::PRE], ga4[4], gs4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -526,6 +701,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             for (int it = 0; it < C::PRE; ++it) write_one(c < nchunks ? c : nchunks - 1, c, it, rr[c][it]);
         }
         __syncthreads();
+        }
     }
     int pass = 0;
 next_pass:  // (PW only: a loop statement here costs the other instantiations registers)
@@ -837,7 +1013,10 @@ template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FU
 int launch(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
     auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW>;
-    constexpr int LDS_BYTES = PW ? 4 * C::BUF : C::LDS_BYTES;
+    // scheme 2 keeps the folded GroupNorm coefficients of the workgroup's sample behind the staging buffers (2 x C_in floats)
+    constexpr int GTAB_MAX = (SCH == 2 && ACT >= 1) ? 2 * 4 * 1024 : 0;   // room for C_in <= 1024
+    constexpr int LDS_BYTES = (PW ? 4 * C::BUF : C::LDS_BYTES) + GTAB_MAX;
+    if (SCH == 2 && a.C0 + a.C1 > 1024) return TQ_ERR_SHAPE;
     // The dynamic-LDS limit is a per-device property of the kernel: remember, per device ordinal, that it has been raised
     // (idempotent call: two threads racing here both set the same value; the mask only saves the repeated runtime call).
     static std::atomic<uint64_t> attr_done{0};
@@ -860,6 +1039,19 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 
 template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
+    if (a.wfmt == TQ_WFMT_F16_MX6) {  // same shapes as TQ_WFMT_F16_MX8 (below), fp6 block-scaled corrections
+        if constexpr (STRIDE == 1 && EPI != 1) {
+            if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
+            if constexpr (KT == 1 && UPS == 0 && ACT <= 1) {
+                const int cin = a.C0 + a.C1;
+                if (a.C_out % 256 == 0 && a.C_out >= 512 && (cin == 128 || cin == 256))
+                    return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2, true>(a, s);
+            }
+            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
+            if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 2>(a, s);
+        }
+        return TQ_ERR_SHAPE;
+    }
     if (a.wfmt == TQ_WFMT_F16_MX8) {  // built for stride-1 forward launches with 128 | C_out and 64-channel sources; with the fused
         // skip conv only for the 256-channel tile (the 128-channel one has 4 of its 8 waves' worth of registers to hide latency
         // with and spills > 100 of them)
@@ -1116,6 +1308,47 @@ __global__ void pack_conv_weight_mx_kernel(const float* __restrict__ w, int C_ou
     out[o + 192] = make_uint4((unsigned)c1[0], (unsigned)c1[1], (unsigned)c1[2], (unsigned)c1[3]);
 }
 
+// mode 3 (TQ_WFMT_F16_MX6): fragments [0], [1] as mode 2; [2] = dwords 0..3 and [3] = {dwords 4, 5, E8M0 byte, 0} of the lane's
+// e2m3 block: channels 16 kq + i, element 2i = W, element 2i + 1 = (W - fp16(W)) * 2^12, both divided by the block's 2^e
+__global__ void pack_conv_weight_mx6_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
+                                            uint4* __restrict__ out) {
+    const int nchunks = (C_in + 63) / 64;
+    const size_t total = (size_t)nchunks * K * ncob_pad * 64;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int lane = gid & 63;
+    size_t r = gid >> 6;
+    const int cob = r % ncob_pad; r /= ncob_pad;
+    const int tap = r % K;
+    const int chunk = r / K;
+    const int row = cob * 16 + (lane & 15), kq = lane >> 4;
+    auto wv = [&](int ch) -> float {
+        return (row < C_out && ch < C_in) ? w[((size_t)row * C_in + ch) * K + tap] : 0.f;
+    };
+    f16x8 m0, m1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m0[j] = (_Float16)wv(chunk * 64 + 8 * kq + j);
+        m1[j] = (_Float16)wv(chunk * 64 + 32 + 8 * kq + j);
+    }
+    f32x16 wa, wl;
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = wv(chunk * 64 + 16 * kq + i);
+        const float l = (v - (float)(_Float16)v) * 4096.f;
+        wa[i] = v; wl[i] = l;
+        mx = fmaxf(mx, fmaxf(fabsf(v), fabsf(l)));
+    }
+    const unsigned ba = e8m0_block_scale(mx);
+    const u32x6 pk = cvt_2xpk16_fp6(wa, wl, __uint_as_float(ba << 23));
+    const size_t o = ((((size_t)chunk * K + tap) * ncob_pad + cob) * 4) * 64 + lane;
+    out[o] = __builtin_bit_cast(uint4, m0);
+    out[o + 64] = __builtin_bit_cast(uint4, m1);
+    out[o + 128] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    out[o + 192] = make_uint4(pk[4], pk[5], ba, 0u);
+}
+
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int mode,
                                         int rows, int kdim, int ncob_pad, uint4* __restrict__ out) {
     const int nchunks = (kdim + 31) / 32;
@@ -1148,7 +1381,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int C_out, 
 }  // namespace
 
 extern "C" size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode) {
-    if (mode == 2) {
+    if (mode == 2 || mode == 3) {
         const int tile2 = tq_conv_tile_co(C_out);
         return (size_t)((C_in + 63) / 64) * K * (((C_out + tile2 - 1) / tile2) * tile2 / 16) * 4 * 64 * 16;
     }
@@ -1161,15 +1394,20 @@ extern "C" size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode
 }
 
 extern "C" int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* out, hipStream_t stream) {
-    if (!w || !out || C_out <= 0 || C_in <= 0 || K <= 0 || mode < 0 || mode > 2) return TQ_ERR_ARG;
+    if (!w || !out || C_out <= 0 || C_in <= 0 || K <= 0 || mode < 0 || mode > 3) return TQ_ERR_ARG;
     const int rows = mode != 1 ? C_out : C_in;
     const int kdim = mode != 1 ? C_in : C_out;
     const int tile = tq_conv_tile_co(rows);
     const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
-    if (mode == 2) {
+    if (mode == 2 || mode == 3) {
         const size_t total2 = (size_t)((C_in + 63) / 64) * K * ncob_pad * 64;
-        hipLaunchKernelGGL(pack_conv_weight_mx_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, w, C_out,
-                           C_in, K, ncob_pad, reinterpret_cast<uint4*>(out));
+        if (mode == 2) {
+            hipLaunchKernelGGL(pack_conv_weight_mx_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, w, C_out,
+                               C_in, K, ncob_pad, reinterpret_cast<uint4*>(out));
+        } else {
+            hipLaunchKernelGGL(pack_conv_weight_mx6_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, w, C_out,
+                               C_in, K, ncob_pad, reinterpret_cast<uint4*>(out));
+        }
         TQ_CHECK_LAUNCH();
         return 0;
     }

@@ -282,7 +282,7 @@ class UNetEngine:
         srcs_c = [d.C_in0, d.C_in1] + ([a.C for a in skip[0]] if skip is not None else [])
         d.wfmt = _lib.forward_wfmt(site.C_out, srcs_c, stride, upsample, fused_skip=skip is not None) if launch else 0
         if launch:
-            site.pack_mode = 2 if d.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+            site.pack_mode = _lib.PACK_MODE[d.wfmt]
             if skip is not None:
                 skip[1].pack_mode = site.pack_mode
             self._wfmt_sites.append((d, [site] + ([skip[1]] if skip is not None else []), d.wfmt))
@@ -341,7 +341,7 @@ class UNetEngine:
         d2.flags = (d.flags & TQ_CONV_STATS) | _lib.TQ_CONV_POLY2
         d2.emb_stride = 0
         d2.wfmt = _lib.forward_wfmt(2 * Cr, [d.C_in0, d.C_in1])
-        ps.pack_mode = 2 if d2.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+        ps.pack_mode = _lib.PACK_MODE[d2.wfmt]
         self._wfmt_sites.append((d2, [ps], d2.wfmt))
         if d2.flags & TQ_CONV_STATS:
             d2.range_flag = self.range_flag.data_ptr()
@@ -380,7 +380,7 @@ class UNetEngine:
             d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = 1, B, B, self.E, 0, self.emb_total
             d.ktaps, d.stride, d.pad, d.upsample, d.flags = 1, 1, 0, 0, 0
             d.wfmt = _lib.forward_wfmt(self.emb_total, [self.E])
-            self.emb_pack_mode = 2 if d.wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+            self.emb_pack_mode = _lib.PACK_MODE[d.wfmt]
             self.emb_entry = self.store.entry("emb_packed", lib.tq_conv_weight_pack_bytes(self.emb_total, self.E, 1, self.emb_pack_mode))
             self.emb_packed = self.emb_entry["buf"]
             self._keep.append(d)

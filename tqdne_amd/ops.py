@@ -68,7 +68,7 @@ def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=Fal
         srcs = [C0, C1] + ([skip[0].shape[2], 0 if skip[1] is None else skip[1].shape[2]] if skip is not None else [])
         wfmt = _lib.forward_wfmt(C_out, srcs, stride, upsample, fused_skip=skip is not None)
     d.wfmt = wfmt
-    pmode = 2 if wfmt == _lib.TQ_WFMT_F16_MX8 else 0
+    pmode = _lib.PACK_MODE[wfmt]
     wp = pack_conv_weight(weight, pmode)
     if skip is not None:
         sx0, sx1, wsk, bsk = skip
