@@ -331,6 +331,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // thread would not fit in registers across the MFMA phase)
     const int m2 = tid & 3;
     float4 raw2[4];
+
     float* gtab = reinterpret_cast<float*>(lds + (PW ? 4 * C::BUF : C::LDS_BYTES));   // [Cin] scale, [Cin] shift of sample b
     auto chunk_base2 = [&](int stage, int& cs) -> const float* __attribute__((always_inline)) {
         const bool sk = FUSE && stage >= nchunks;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             }
             write16(chunk, buf, tid >> 2, raw2);
 #pragma unroll 1
-            for (int it = 1; it < C::NFULL; ++it) {   // (4-wave tile: second half of the rows, loaded here)
+            for (int it = 1; it < C::NFULL; ++it) {   // (4-wave tile: second half of the rows, loaded here; prefetching it too: neutral)
                 float4 t4[4];
                 load16(base2, cs2, (tid >> 2) + it * (C::NTHR / 4), t4);
                 write16(chunk, buf, (tid >> 2) + it * (C::NTHR / 4), t4);
