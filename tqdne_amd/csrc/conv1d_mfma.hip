@@ -738,6 +738,29 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             tl[0] = r_entry; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[4] = t_entry; tl[5] = t_begin;
         }
 #endif
+#ifdef TQ_SKEW
+        // Half-phase skew of the two waves of a SIMD (8-wave tile: waves w and w + 4 share one): waves 4-7 convert + store their
+        // share of chunk c + 1 BEFORE their MFMA phase of chunk c (from loads issued one chunk earlier), waves 0-3 after theirs, so
+        // that one of the two is in its matrix stream while the other one stages.  Same barriers, same LDS hand-over: at the start
+        // of an iteration every wave has left the MFMA phase that read the buffer about to be overwritten.
+        // Diagnostic build only (-DTQ_SKEW): parity-green and spill-free in the fp6 layout (232-242 registers), but measured no
+        // faster (18-step sample 164.7 vs 165.7 ms, single layers 0-7 % slower): moving staging between the two waves of a SIMD
+        // is zero-sum here, as MI355X_MICROARCH.md's two-waves-per-SIMD section predicts.
+        if constexpr (!FUSE && SCH == 2 && WM == 8) {
+            // (ONE copy of the MFMA stream: two copies behind a wave-uniform branch made hipcc spill ~60 registers)
+            const bool skew = wave >= 4;
+            if (skew && nstages > 1) stage_load(1);
+            for (int c = 0; c + 1 < nstages; ++c) {
+                if (skew) stage_write(c + 1, (c + 1) & 1);
+                const int nxt = c + (skew ? 2 : 1);
+                stage_load(nxt < nstages ? nxt : nstages - 1);
+                if (wave_active) compute(c, c & 1);
+                if (!skew) stage_write(c + 1, (c + 1) & 1);
+                __syncthreads();
+            }
+            if (wave_active) compute(nstages - 1, (nstages - 1) & 1);
+        } else
+#endif
         if constexpr (!FUSE) {
             for (int c = 0; c + 1 < nstages; ++c) {
                 TQ_T(tA)
