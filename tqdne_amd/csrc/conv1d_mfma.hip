@@ -376,9 +376,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         if (ACT == 3 && act) {
             const int pc = pos < 0 ? 0 : pos;
             const uint64_t e0 = ((uint64_t)b * T_src + pc) * Cin + chunk * C::CH + 16 * m2;
-#pragma unroll
+            // the 16 keep decisions one after the other into a bit mask (a rolled loop: 16 interleaved 64-bit hash chains are what
+            // made this variant spill), then applied with static indices
+            unsigned keep = 0;
+#pragma unroll 1
             for (int j = 0; j < 16; ++j)
-                u[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? u[j] * p.drop_scale : 0.f;
+                keep |= (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh ? 1u : 0u) << j;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) u[j] = ((keep >> j) & 1u) ? u[j] * p.drop_scale : 0.f;
         }
         f16x8 h0, h1;
         f32x16 xl, xf;
