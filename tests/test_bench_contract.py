@@ -1,0 +1,51 @@
+"""bench.py's output contract (the driver parses it): ONE JSON line on stdout with the headline fields, the roofline and CPU-baseline
+objects; partial modes are labelled.  Run on the tiny configuration so that it takes seconds."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*args, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must carry the JSON line only, got {len(lines)} lines"
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_json_contract_tiny_config():
+    d = _run("--config", "tiny", "--batch", "4", "--steps", "2", "--warmup", "1", "--cpu-batch", "1")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "waveforms/s" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["value"] > 0 and c["one_thread"]["cores"] == 1
+    assert set(d["kernel_classes"]) >= {"inference_forward_1lane", "train_forward", "train_backward"}
+
+
+@pytest.mark.timeout(600)
+def test_bench_partial_modes_are_labelled():
+    d = _run("--config", "tiny", "--batch", "4", "--steps", "1", "--warmup", "1", "--mode", "sample", "--no-cpu-baseline", "--no-tables")
+    assert "DEBUG" in d["metric"] and "cpu_baseline" not in d
+    d = _run("--config", "tiny", "--batch", "4", "--steps", "1", "--warmup", "1", "--mode", "consistency", "--no-cpu-baseline")
+    assert "consistency" in d["metric"] and d["config"]["mode"] == "consistency"
