@@ -141,6 +141,7 @@ struct Cfg {
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 
 // hipcc (ROCm 7.2) lets the destination of v_cvt_scalef32_2xpk16_fp6_f32 overlap its scale / source registers and the instruction
@@ -332,6 +333,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     // thread would not fit in registers across the MFMA phase)
     const int m2 = tid & 3;
     float4 raw2[4];
+    float nlog2e = -1.4426950408889634f, n4096 = -4096.f;
+    asm volatile("" : "+s"(nlog2e), "+s"(n4096));  // kept in an SGPR: a literal would split the packed multiply into two scalar-literal ones
 
     float* gtab = reinterpret_cast<float*>(lds + (PW ? 4 * C::BUF : C::LDS_BYTES));   // [Cin] scale, [Cin] shift of sample b
     auto chunk_base2 = [&](int stage, int& cs) -> const float* __attribute__((always_inline)) {
@@ -369,11 +372,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                 u[4 * q4 + 2] = fmaf(a.z, u[4 * q4 + 2], sh.z); u[4 * q4 + 3] = fmaf(a.w, u[4 * q4 + 3], sh.w);
             }
         }
+        // Per element (this conversion runs in lock-step on both waves of a SIMD with the matrix pipe idle -- tools/stamps.py:
+        // 18 % of the chunk loop of the 512 -> 256 layer -- so every VALU instruction counts): packed fp32 ops wherever two
+        // elements share an operation; rows outside the signal are zeroed through the sigmoid (1 / (inf + e) = 0) instead of a
+        // multiplication by the mask; the fp16 remainder comes from ONE mixed-precision fma on the packed half.
         if (ACT >= 2 && act) {
+            const float one = (pos >= 0 && pos < T_src) ? 1.0f : __builtin_inff();
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                u[j] = u[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[j] * -1.4426950408889634f));
+            for (int j = 0; j < 16; j += 2) {
+                f32x2 uu = {u[j], u[j + 1]};
+                f32x2 e = uu * nlog2e;   // u * sigmoid(u) = u / (1 + 2^(-u log2 e))
+                e = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + one;
+                uu = uu * f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+                u[j] = uu.x; u[j + 1] = uu.y;
+            }
         }
+        const float mm = (ACT >= 2 && act) ? 1.f : msk;  // (skip stages and un-activated inputs: the plain mask)
         if (ACT == 3 && act) {
             const int pc = pos < 0 ? 0 : pos;
             const uint64_t e0 = ((uint64_t)b * T_src + pc) * Cin + chunk * C::CH + 16 * m2;
@@ -390,13 +404,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         f32x16 xl, xf;
         float mx = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float x = u[j] * msk;
-            const _Float16 hv = (_Float16)x;  // |x| > 65504 -> inf, NaN stays NaN: out-of-range inputs surface in the output
-            if (j < 8) h0[j] = hv; else h1[j - 8] = hv;
-            const float r = (x - (float)hv) * 4096.f;
-            xl[j] = r; xf[j] = x;
-            mx = fmaxf(mx, fmaxf(fabsf(r), fabsf(x)));
+        for (int j = 0; j < 16; j += 2) {
+            f32x2 x = {u[j], u[j + 1]};
+            if constexpr (ACT < 2 || FUSE) x = x * mm;
+            // |x| > 65504 -> inf, NaN stays NaN: out-of-range inputs surface in the output
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 hp = {(_Float16)x.x, (_Float16)x.y};
+            if (j < 8) { h0[j] = hp.x; h0[j + 1] = hp.y; } else { h1[j - 8] = hp.x; h1[j - 7] = hp.y; }
+            const f32x2 x4k = x * 4096.f;
+            // (x - fp16(x)) * 2^12 = x * 2^12 - fp16(x) * 2^12, exact (both products and their difference are representable):
+            // one v_fma_mix_f32 per element straight from the packed half (hipcc's own choice is two conversions + a packed fma)
+            float r0, r1;
+            const unsigned hpu = __builtin_bit_cast(unsigned, hp);
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hpu), "s"(n4096), "v"(x4k.x));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hpu), "s"(n4096), "v"(x4k.y));
+            xl[j] = r0; xl[j + 1] = r1; xf[j] = x.x; xf[j + 1] = x.y;
+            mx = fmaxf(fmaxf(mx, fabsf(r0)), fabsf(x.x));
+            mx = fmaxf(fmaxf(mx, fabsf(r1)), fabsf(x.y));
         }
         const unsigned bb = e8m0_block_scale(mx);
         const u32x6 pk = cvt_2xpk16_fp6(xl, xf, __uint_as_float(bb << 23));
@@ -406,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         *reinterpret_cast<uint4*>(hi_plane + ro + (((2 * m2 + 1) ^ sw) << 4)) = __builtin_bit_cast(uint4, h1);
         *reinterpret_cast<uint4*>(lo_plane + ro + ((m2 ^ sw) << 4)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         // the lane's E8M0 byte for the MFMA, with the 2^-12 of both correction products folded in
-        *reinterpret_cast<uint4*>(lo_plane + ro + (((4 + m2) ^ sw) << 4)) = make_uint4(pk[4], pk[5], bb - 12u, 0u);
+        *reinterpret_cast<uint4*>(lo_plane + ro + (((4 + m2) ^ sw) << 4)) = make_uint4(pk[4], pk[5], 0u, bb - 12u);
     };
 
     // phase 1 (before the MFMAs of the previous chunk): issue the first PRE iterations' loads
@@ -531,7 +555,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             f[0].u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);          // fp16, channels 8 kq ...
             f[1].u = *reinterpret_cast<const uint4*>(hi_plane + (b0 ^ 64) + toff);   // fp16, channels 32 + 8 kq ...
             f[2].u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);          // fp8(xl * 2^12), channels 16 kq ...
-            f[3].u = *reinterpret_cast<const uint4*>(lo_plane + (b0 ^ 64) + toff);   // fp8(x), same channels
+            if constexpr (SCH == 2) {
+                // fp6: dwords 4, 5 of the lane's 24 operand bytes as an 8-byte read and its E8M0 byte (dword 3 of the same unit) as
+                // a 4-byte one: the six operand registers of the MFMA are then {16-byte read, 8-byte read} back to back.  With one
+                // 16-byte read for {dword 4, dword 5, scale} hipcc copied two registers per (tap, t-block) step to make the
+                // operand contiguous (80 v_mov per chunk and wave inside the MFMA stream); same LDS-array cycles (4 = 2 + 2).
+                f[3].h[0] = *reinterpret_cast<const uint2*>(lo_plane + (b0 ^ 64) + toff);
+                f[3].u.w = *reinterpret_cast<const unsigned*>(lo_plane + (b0 ^ 64) + toff + 12);
+            } else {
+                f[3].u = *reinterpret_cast<const uint4*>(lo_plane + (b0 ^ 64) + toff);   // fp8(x), same channels
+            }
         }
     };
     // the MFMAs of one (tap, t-block) step for both 16-channel blocks of the wave
@@ -542,9 +575,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                 acc[cbk][tb] = mfma_x3(w[cbk * 2].v, w[cbk * 2 + 1].v, f[0].v, f[1].v, acc[cbk][tb]);
         } else if constexpr (SCH == 2) {
             // fp6 fragments: dwords 0..5 of the i32x8 (the last two are ignored for 6-bit operands); the lane's E8M0 byte travels
-            // in dword 6 of its own fragment (weights: from the packer; activations: from write16, with the 2^-12 folded in)
+            // in its own fragment (weights: dword 6, from the packer; activations: dword 7, from write16, with the 2^-12 folded in)
             const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
-                              (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
+                              (int)f[3].u.x, (int)f[3].u.y, 0, 0};
             const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
@@ -557,7 +590,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                 const Frag& c0 = w[cbk * 4 + 2];
                 const Frag& c1 = w[cbk * 4 + 3];
                 const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
-                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, (int)c1.u.z, 0, (int)f[3].u.z);
+                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, (int)c1.u.z, 0, (int)f[3].u.w);
             }
         } else {
             const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
