@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         *reinterpret_cast<uint4*>(hi_plane + ro + (((2 * m2 + 1) ^ sw) << 4)) = __builtin_bit_cast(uint4, h1);
         *reinterpret_cast<uint4*>(lo_plane + ro + ((m2 ^ sw) << 4)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         // the lane's E8M0 byte for the MFMA, with the 2^-12 of both correction products folded in
-        *reinterpret_cast<uint4*>(lo_plane + ro + (((4 + m2) ^ sw) << 4)) = make_uint4(pk[4], pk[5], 0u, bb - 12u);
+        *reinterpret_cast<uint4*>(lo_plane + ro + (((4 + m2) ^ sw) << 4)) = make_uint4(pk[4], pk[5], bb - 12u, 0u);
     };
 
     // phase 1 (before the MFMAs of the previous chunk): issue the first PRE iterations' loads
@@ -555,16 +555,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
             f[0].u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);          // fp16, channels 8 kq ...
             f[1].u = *reinterpret_cast<const uint4*>(hi_plane + (b0 ^ 64) + toff);   // fp16, channels 32 + 8 kq ...
             f[2].u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);          // fp8(xl * 2^12), channels 16 kq ...
-            if constexpr (SCH == 2) {
-                // fp6: dwords 4, 5 of the lane's 24 operand bytes as an 8-byte read and its E8M0 byte (dword 3 of the same unit) as
-                // a 4-byte one: the six operand registers of the MFMA are then {16-byte read, 8-byte read} back to back.  With one
-                // 16-byte read for {dword 4, dword 5, scale} hipcc copied two registers per (tap, t-block) step to make the
-                // operand contiguous (80 v_mov per chunk and wave inside the MFMA stream); same LDS-array cycles (4 = 2 + 2).
-                f[3].h[0] = *reinterpret_cast<const uint2*>(lo_plane + (b0 ^ 64) + toff);
-                f[3].u.w = *reinterpret_cast<const unsigned*>(lo_plane + (b0 ^ 64) + toff + 12);
-            } else {
-                f[3].u = *reinterpret_cast<const uint4*>(lo_plane + (b0 ^ 64) + toff);   // fp8(x), same channels
-            }
+            f[3].u = *reinterpret_cast<const uint4*>(lo_plane + (b0 ^ 64) + toff);   // fp8(x), same channels
         }
     };
     // the MFMAs of one (tap, t-block) step for both 16-channel blocks of the wave
@@ -575,9 +566,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                 acc[cbk][tb] = mfma_x3(w[cbk * 2].v, w[cbk * 2 + 1].v, f[0].v, f[1].v, acc[cbk][tb]);
         } else if constexpr (SCH == 2) {
             // fp6 fragments: dwords 0..5 of the i32x8 (the last two are ignored for 6-bit operands); the lane's E8M0 byte travels
-            // in its own fragment (weights: dword 6, from the packer; activations: dword 7, from write16, with the 2^-12 folded in)
+            // in dword 6 of its own fragment (weights: from the packer; activations: from write16, with the 2^-12 folded in).  (Reading
+            // dwords 4, 5 and the scale with an 8- and a 4-byte LDS read makes the six operand registers contiguous without the
+            // two v_mov per step hipcc inserts here, but those reads are 2-way bank-conflicted in this image: measured equal.)
             const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
-                              (int)f[3].u.x, (int)f[3].u.y, 0, 0};
+                              (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
             const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
@@ -590,7 +583,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
                 const Frag& c0 = w[cbk * 4 + 2];
                 const Frag& c1 = w[cbk * 4 + 3];
                 const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
-                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, (int)c1.u.z, 0, (int)f[3].u.w);
+                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, (int)c1.u.z, 0, (int)f[3].u.z);
             }
         } else {
             const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
