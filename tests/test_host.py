@@ -66,8 +66,10 @@ def test_cpu_tensors_are_refused_not_silently_computed():
 
 def test_unsupported_options_fail_loudly():
     from tqdne_amd import UNetModel
-    with pytest.raises(NotImplementedError):
-        UNetModel(3, 32, 3, 1, dims=2)
+    for kw in (dict(dims=3), dict(dims=1, use_scale_shift_norm=True), dict(dims=1, use_causal_mask=True),
+               dict(dims=2, use_causal_mask=True)):
+        with pytest.raises(NotImplementedError):
+            UNetModel(3, 32, 3, 1, **kw)
 
 
 def test_edm_surface():

@@ -1,4 +1,4 @@
-"""Config surface of the 1-D path: the dict builders of reference tqdne/architectures.py:1-37, returning the
+"""Config surface: the dict builders of reference tqdne/architectures.py:1-79 (1-D hot path, 2-D family), returning the
 keyword dictionaries that ``UNetModel`` / ``Encoder`` / ``Decoder`` are constructed from."""
 
 
@@ -27,6 +27,18 @@ def get_1d_autoencoder_configs(config):
     enc = dict(shared, in_channels=config.channels, out_channels=config.latent_channels * 2)
     dec = dict(shared, in_channels=config.latent_channels, out_channels=config.channels)
     return enc, dec
+
+
+def get_2d_unet_config(config, in_channels, out_channels, model_channels=128, use_causal_mask=False):
+    """2-D UNet of the generate_waveforms.py family (architectures.py:61-79); built on stock PyTorch operators (family2d.py)."""
+    return dict(get_1d_unet_config(config, in_channels, out_channels), dims=2, conv_kernel_size=3,
+                model_channels=model_channels, use_causal_mask=use_causal_mask)
+
+
+def get_2d_autoencoder_configs(config):
+    """2-D VAE encoder / decoder (architectures.py:40-58)."""
+    enc, dec = get_1d_autoencoder_configs(config)
+    return dict(enc, dims=2, conv_kernel_size=3), dict(dec, dims=2, conv_kernel_size=3)
 
 
 def paper_1d_unet_config(in_channels=3, out_channels=3, cond_features=5):

@@ -16,12 +16,15 @@ from torch import nn
 
 from . import engine, rng
 from .lightning_compat import LightningModule
-from .unet import AttentionParams, DownsampleParams, ResBlockParams, UpsampleParams
+from .unet import AttentionParams, DownsampleParams, ResBlockParams, UpsampleParams, _conv
 
 
 def _check(dims, conv_resample):
-    if dims != 1 or not conv_resample:
-        raise NotImplementedError("tqdne_amd autoencoder implements the 1-D conv-resample path (dims=1)")
+    if dims not in (1, 2) or not conv_resample:
+        raise NotImplementedError("tqdne_amd autoencoder: conv-resample, dims=1 (HIP path) or dims=2 (stock-PyTorch family)")
+    if dims == 2:
+        from . import family2d
+        family2d.announce()
 
 
 class Encoder(nn.Module):
@@ -33,28 +36,31 @@ class Encoder(nn.Module):
         super().__init__()
         _check(dims, conv_resample)
         self.in_channels, self.out_channels, self.num_heads = in_channels, out_channels, num_heads
-        self.dropout = dropout
+        self.dropout, self.dims = dropout, dims
         k = conv_kernel_size
         ch = int(channel_mult[0] * model_channels)
-        self.input_layer = nn.Conv1d(in_channels, ch, k, padding="same")
+        self.input_layer = _conv(dims)(in_channels, ch, k, padding="same")
         ds, blocks = 1, []
         for level, mult in enumerate(channel_mult):
             for _ in range(num_res_blocks):
-                blocks.append(ResBlockParams(ch, None, dropout, int(mult * model_channels), k))
+                blocks.append(ResBlockParams(ch, None, dropout, int(mult * model_channels), k, dims))
                 ch = int(mult * model_channels)
                 if ds in attention_resolutions:
-                    blocks.append(AttentionParams(ch, num_heads))
+                    blocks.append(AttentionParams(ch, num_heads, dims))
             if level != len(channel_mult) - 1:
-                blocks.append(DownsampleParams(ch, ch))  # kernel 3 (blocks.py:337 passes none)
+                blocks.append(DownsampleParams(ch, ch, dims=dims))  # kernel 3 (blocks.py:337 passes none)
                 ds *= 2
         self.down_blocks = nn.Sequential(*blocks)
-        self.output_layer = nn.Conv1d(ch, out_channels, k, padding="same")
+        self.output_layer = _conv(dims)(ch, out_channels, k, padding="same")
         self.time_scale = ds  # T_out = T_in / ds
         self._engine_cache = {}
 
     blocks_attr = "down_blocks"
 
     def forward(self, x):
+        if self.dims == 2:   # stock PyTorch operators (family2d.py): the generate_waveforms.py family only
+            from . import family2d
+            return family2d.coder_forward(self, x)
         engine.require_device(x)
         eng = _seq_engine(self, x)
         y = eng.forward(x).clone()
@@ -77,27 +83,30 @@ class Decoder(nn.Module):
         super().__init__()
         _check(dims, conv_resample)
         self.in_channels, self.out_channels, self.num_heads = in_channels, out_channels, num_heads
-        self.dropout = dropout
+        self.dropout, self.dims = dropout, dims
         k = conv_kernel_size
         ch = int(channel_mult[-1] * model_channels)
-        self.input_layer = nn.Conv1d(in_channels, ch, k, padding="same")
+        self.input_layer = _conv(dims)(in_channels, ch, k, padding="same")
         ds, blocks = 2 ** (len(channel_mult) - 1), []
         for level, mult in reversed(list(enumerate(channel_mult))):
             if level != len(channel_mult) - 1:
-                blocks.append(UpsampleParams(ch, ch))  # kernel 3 (blocks.py:408 passes none)
+                blocks.append(UpsampleParams(ch, ch, dims=dims))  # kernel 3 (blocks.py:408 passes none)
                 ds //= 2
             for _ in range(num_res_blocks):
-                blocks.append(ResBlockParams(ch, None, dropout, int(mult * model_channels), k))
+                blocks.append(ResBlockParams(ch, None, dropout, int(mult * model_channels), k, dims))
                 ch = int(mult * model_channels)
                 if ds in attention_resolutions:
-                    blocks.append(AttentionParams(ch, num_heads))
+                    blocks.append(AttentionParams(ch, num_heads, dims))
         self.up_blocks = nn.Sequential(*blocks)
-        self.output_layer = nn.Conv1d(ch, out_channels, k, padding="same")
+        self.output_layer = _conv(dims)(ch, out_channels, k, padding="same")
         self._engine_cache = {}
 
     blocks_attr = "up_blocks"
 
     def forward(self, x):
+        if self.dims == 2:   # stock PyTorch operators (family2d.py): the generate_waveforms.py family only
+            from . import family2d
+            return family2d.coder_forward(self, x)
         engine.require_device(x)
         eng = _seq_engine(self, x)
         y = eng.forward(x).clone()
@@ -160,6 +169,9 @@ class LightningAutoencoder(LightningModule):
         from . import _lib
         enc = self.encoder(x)
         mean, log_std = th.chunk(enc, 2, dim=1)
+        if self.encoder.dims == 2:   # stock-PyTorch family (family2d.py)
+            eps = th.randn_like(mean) if unit_noise is None else unit_noise
+            return mean + eps * th.exp(log_std), mean, log_std
         eps = (th.randn_like(mean) if unit_noise is None else unit_noise).contiguous().float()
         latent = th.empty_like(eps)
         B, L, Tl = eps.shape
@@ -171,7 +183,7 @@ class LightningAutoencoder(LightningModule):
         return self._encode(x)[0]
 
     def decode(self, x):
-        return self.decoder(x.contiguous())
+        return self.decoder(x.contiguous())   # (dims=2: Decoder.forward dispatches to family2d)
 
     def forward(self, x):
         return self.decode(self._encode(x)[0])
@@ -224,8 +236,22 @@ class LightningAutoencoder(LightningModule):
             g_enc, _ = e_eng.backward(bufs["denc"], want_dx=False, clone=True)
         return recon_loss, kl, list(g_enc) + list(g_dec)
 
+    def _step_2d(self, x, stage, prefix):
+        """autoencoder.py:59-69 on torch operators and torch.autograd (dims=2 family)."""
+        latent, mean, log_std = self._encode(x)
+        recon_loss = th.mean((x - self.decode(latent)) ** 2)
+        kl = th.mean(self.kl_divergence(mean, log_std))
+        loss = recon_loss + self.kl_weight * kl
+        self.log(f"{stage}/{prefix}reconstruction_loss", recon_loss.detach().item(), sync_dist=True)
+        self.log(f"{stage}/{prefix}kl_divergence", kl.detach().item(), sync_dist=True)
+        self.log(f"{stage}/{prefix}loss", loss.detach().item(), sync_dist=True)
+        return loss
+
     def step(self, batch, stage="training"):
         x = batch["signal"]
+        if self.encoder.dims == 2:
+            loss = self._step_2d(x, stage, "")
+            return loss if "cond_signal" not in batch else loss + self._step_2d(batch["cond_signal"], stage, "cond_")
         loss = _AELossFn.apply(self, x, stage, "", *self.parameters())
         if "cond_signal" not in batch:
             return loss
@@ -233,6 +259,8 @@ class LightningAutoencoder(LightningModule):
 
     def step_and_backward(self, batch):
         """``step`` + backward without the autograd round trip: gradients are left in ``p.grad`` (DataParallelTrainer)."""
+        if self.encoder.dims == 2:
+            raise NotImplementedError("DataParallelTrainer drives the 1-D HIP path; train dims=2 models with step() + torch.autograd")
         xs = [batch["signal"]] + ([batch["cond_signal"]] if "cond_signal" in batch else [])
         total, grads = None, None
         for x in xs:

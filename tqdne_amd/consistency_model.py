@@ -68,6 +68,8 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
     def __init__(self, net, sigma_min=0.002, sigma_max=80.0, rho=7.0, sigma_data=0.5, initial_timesteps=10,
                  final_timesteps=1280, lognormal_mean=-1.1, lognormal_std=2.0, lr=1e-4):
         super().__init__()
+        if getattr(net, "dims", 1) != 1:
+            raise NotImplementedError("the consistency model runs on the 1-D HIP path (every reference config that uses it is 1-D)")
         self.net = net
         self.sigma_min, self.sigma_max, self.rho, self.sigma_data = sigma_min, sigma_max, rho, sigma_data
         self.initial_timesteps, self.final_timesteps = initial_timesteps, final_timesteps

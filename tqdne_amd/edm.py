@@ -156,6 +156,9 @@ class LightningEDM(LightningModule):
 
     def forward(self, sample, sigma, cond_sample=None, cond=None):
         """Make a forward pass through the network with skip connection (edm.py:105-113)."""
+        if self.unet.dims == 2:   # generate_waveforms.py family: stock PyTorch operators, differentiable by torch.autograd
+            from . import family2d
+            return family2d.denoise(self, sample, sigma, cond_sample, cond)
         engine.require_device(sample)
         sample = sample.contiguous()
         sigma = sigma.contiguous().float()
@@ -188,6 +191,9 @@ class LightningEDM(LightningModule):
 
     def step_with_noise(self, sample, eps, unit_noise, cond=None, cond_sample=None):
         """``step`` with the two random draws of edm.py:126,128 supplied by the caller (tests inject CPU draws)."""
+        if self.unet.dims == 2:
+            from . import family2d
+            return family2d.edm_loss(self, sample, eps, unit_noise, cond, cond_sample)
         from .autograd import edm_loss
         return edm_loss(self, sample.contiguous(), eps.contiguous().float(), unit_noise.contiguous(), cond,
                         None if cond_sample is None else cond_sample.contiguous())
@@ -196,6 +202,8 @@ class LightningEDM(LightningModule):
         """``step`` + backward in one call, gradients left in ``p.grad`` (views of one flat buffer, returned as well).
         ``on_bucket``: gradient-exchange hook, called as buckets of the flat buffer become final (BackwardPlan.run)."""
         from .autograd import edm_loss_and_grads
+        if self.unet.dims == 2:
+            raise NotImplementedError("DataParallelTrainer drives the 1-D HIP path; train dims=2 models with step() + torch.autograd")
         sample = batch["signal"]
         cond = batch["cond"] if "cond" in batch else None
         cond_sample = batch["cond_signal"] if "cond_signal" in batch else None
@@ -231,10 +239,15 @@ class LightningEDM(LightningModule):
             # the reference encodes a zeros tensor just to learn the latent shape (edm.py:154-157); the shape is known
             # in closed form, so the wasted encoder pass is skipped
             enc = self.autoencoder.encoder
-            shape = (shape[0], enc.out_channels // 2, shape[2] // enc.time_scale)
+            shape = (shape[0], enc.out_channels // 2) + tuple(n // enc.time_scale for n in shape[2:])
         # schedule built on the host in fp32 exactly like the reference's CPU path, then moved (pow differs by ulps on device)
         sigmas = self.edm.sampling_sigmas(self.num_sampling_steps).to(self.device)
         eps = th.randn(shape, device=self.device, dtype=dtype) * sigmas[0]
+        if self.unet.dims == 2:
+            from . import family2d
+            churn = None if self.deterministic_sampling else th.randn_like
+            sample = family2d.heun_sample(self, eps, sigmas, cond_sample, cond, churn).to(th.float32)
+            return self.autoencoder.decode(sample) if self.autoencoder else sample
         if self.deterministic_sampling:
             sample = self.sample_deterministically(eps, sigmas, cond_sample, cond)
         else:

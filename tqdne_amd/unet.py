@@ -6,9 +6,13 @@ unet.py:378-380), same ``state_dict`` keys / shapes / registration order (SURVEY
 default initialisation (parameters are created by the same torch initialisers in the same order, so
 ``torch.manual_seed(s); UNetModel(**cfg)`` yields bit-identical weights to the reference).
 
-The torch ``nn.Conv1d`` / ``nn.GroupNorm`` / ``nn.Linear`` objects below are *parameter containers only*: their
-``forward`` is never called.  There is no CPU or ATen fallback: tensors must live on a ROCm device and the
-HIP library must be built, otherwise ``forward`` raises.
+For ``dims=1`` (the hot path) the torch ``nn.Conv1d`` / ``nn.GroupNorm`` / ``nn.Linear`` objects below are *parameter
+containers only*: their ``forward`` is never called.  There is no CPU or ATen fallback for that path: tensors must live on a
+ROCm device and the HIP library must be built, otherwise ``forward`` raises.
+
+``dims=2`` builds the reference's other model family (``generate_waveforms.py``, ``architectures.py:40-79``) with ``nn.Conv2d``
+containers and runs it on stock PyTorch operators (``family2d.py``) -- a separate family, not a
+fallback of the 1-D path.
 """
 
 from __future__ import annotations
@@ -25,6 +29,11 @@ GN_GROUPS = 32
 
 def _gn(ch: int) -> nn.GroupNorm:  # reference nn.py:90-105 (GroupNorm32(32, ch))
     return nn.GroupNorm(GN_GROUPS, ch)
+
+
+def _conv(dims: int):  # reference nn.py:16-24
+    """dims=1: the hot path's parameter container; dims=2: a stock ``nn.Conv2d`` that family2d.py calls."""
+    return {1: nn.Conv1d, 2: nn.Conv2d}[dims]
 
 
 def _zero(m: nn.Module) -> nn.Module:  # reference nn.py:59-63
@@ -46,21 +55,22 @@ class ResBlockParams(nn.Module):
 
     kind = "res"
 
-    def __init__(self, channels, emb_channels, dropout, out_channels=None, kernel_size=3):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, kernel_size=3, dims=1):
         super().__init__()
+        conv = _conv(dims)
         out_channels = out_channels or channels
         self.channels, self.out_channels, self.kernel_size, self.dropout = channels, out_channels, kernel_size, dropout
-        self.in_layers = nn.Sequential(_gn(channels), nn.SiLU(), nn.Conv1d(channels, out_channels, kernel_size, padding="same"))
+        self.in_layers = nn.Sequential(_gn(channels), nn.SiLU(), conv(channels, out_channels, kernel_size, padding="same"))
         if emb_channels is not None:
             self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, out_channels))
         self.out_layers = nn.Sequential(
             _gn(out_channels), nn.SiLU(), nn.Dropout(p=dropout),
-            _zero(nn.Conv1d(out_channels, out_channels, kernel_size, padding="same")),
+            _zero(conv(out_channels, out_channels, kernel_size, padding="same")),
         )
         if out_channels == channels:
             self.skip_connection = nn.Identity()
         else:
-            self.skip_connection = nn.Conv1d(channels, out_channels, 1)
+            self.skip_connection = conv(channels, out_channels, 1)
 
 
 class AttentionParams(nn.Module):
@@ -68,12 +78,12 @@ class AttentionParams(nn.Module):
 
     kind = "attn"
 
-    def __init__(self, channels, num_heads=1):
+    def __init__(self, channels, num_heads=1, dims=1):
         super().__init__()
         self.channels, self.num_heads = channels, num_heads
         self.norm = _gn(channels)
-        self.qkv = nn.Conv1d(channels, channels * 3, 1)
-        self.proj_out = _zero(nn.Conv1d(channels, channels, 1))
+        self.qkv = _conv(dims)(channels, channels * 3, 1)
+        self.proj_out = _zero(_conv(dims)(channels, channels, 1))
 
 
 class DownsampleParams(nn.Module):
@@ -81,10 +91,10 @@ class DownsampleParams(nn.Module):
 
     kind = "down"
 
-    def __init__(self, channels, out_channels=None, kernel_size=3):
+    def __init__(self, channels, out_channels=None, kernel_size=3, dims=1):
         super().__init__()
         self.channels, self.out_channels = channels, out_channels or channels
-        self.op = nn.Conv1d(channels, self.out_channels, kernel_size, stride=2, padding=kernel_size // 2)
+        self.op = _conv(dims)(channels, self.out_channels, kernel_size, stride=2, padding=kernel_size // 2)
 
 
 class UpsampleParams(nn.Module):
@@ -92,10 +102,10 @@ class UpsampleParams(nn.Module):
 
     kind = "up"
 
-    def __init__(self, channels, out_channels=None, kernel_size=3):
+    def __init__(self, channels, out_channels=None, kernel_size=3, dims=1):
         super().__init__()
         self.channels, self.out_channels = channels, out_channels or channels
-        self.conv = nn.Conv1d(channels, self.out_channels, kernel_size, padding="same")
+        self.conv = _conv(dims)(channels, self.out_channels, kernel_size, padding="same")
 
 
 class BlockSeq(nn.Sequential):
@@ -124,12 +134,14 @@ class UNetModel(nn.Module):
         use_causal_mask=False,
     ):
         super().__init__()
-        if dims != 1:
-            raise NotImplementedError(
-                "tqdne_amd.UNetModel implements the 1-D hot path (dims=1); the 2-D spectrogram family is out of scope"
-            )
+        if dims not in (1, 2):
+            raise NotImplementedError("tqdne_amd.UNetModel: dims=1 (the HIP hot path) or dims=2 (stock-PyTorch family, family2d.py)")
         if use_scale_shift_norm or cond_emb_scale is not None or not conv_resample or use_causal_mask:
-            raise NotImplementedError("option unused by every reference 1-D config and not implemented on the HIP path")
+            raise NotImplementedError("option unused by every reference config of the supported families and not implemented")
+        self.dims = dims
+        if dims == 2:
+            from . import family2d
+            family2d.announce()
         # flash_attention is accepted and ignored: the fused kernel is always flash-style (blocks.py:193-230 needs flash_attn)
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
         self.num_res_blocks, self.attention_resolutions = num_res_blocks, tuple(attention_resolutions)
@@ -146,41 +158,41 @@ class UNetModel(nn.Module):
 
         k = conv_kernel_size
         ch = input_ch = int(channel_mult[0] * model_channels)
-        self.input_blocks = nn.ModuleList([BlockSeq(nn.Conv1d(in_channels, ch, k, padding="same"))])
+        self.input_blocks = nn.ModuleList([BlockSeq(_conv(dims)(in_channels, ch, k, padding="same"))])
         skip_chans = [ch]
         ds = 1
         for level, mult in enumerate(channel_mult):
             for _ in range(num_res_blocks):
-                layers = [ResBlockParams(ch, embed_dim, dropout, int(mult * model_channels), k)]
+                layers = [ResBlockParams(ch, embed_dim, dropout, int(mult * model_channels), k, dims)]
                 ch = int(mult * model_channels)
                 if ds in self.attention_resolutions:
-                    layers.append(AttentionParams(ch, num_heads))
+                    layers.append(AttentionParams(ch, num_heads, dims))
                 self.input_blocks.append(BlockSeq(*layers))
                 skip_chans.append(ch)
             if level != len(channel_mult) - 1:
-                self.input_blocks.append(BlockSeq(DownsampleParams(ch, ch)))  # kernel 3: unet.py:273 passes none
+                self.input_blocks.append(BlockSeq(DownsampleParams(ch, ch, dims=dims)))  # kernel 3: unet.py:273 passes none
                 skip_chans.append(ch)
                 ds *= 2
 
         self.middle_block = BlockSeq(
-            ResBlockParams(ch, embed_dim, dropout, None, k), AttentionParams(ch, num_heads),
-            ResBlockParams(ch, embed_dim, dropout, None, k),
+            ResBlockParams(ch, embed_dim, dropout, None, k, dims), AttentionParams(ch, num_heads, dims),
+            ResBlockParams(ch, embed_dim, dropout, None, k, dims),
         )
 
         self.output_blocks = nn.ModuleList([])
         for level, mult in list(enumerate(channel_mult))[::-1]:
             for i in range(num_res_blocks + 1):
                 ich = skip_chans.pop()
-                layers = [ResBlockParams(ch + ich, embed_dim, dropout, int(model_channels * mult), k)]
+                layers = [ResBlockParams(ch + ich, embed_dim, dropout, int(model_channels * mult), k, dims)]
                 ch = int(model_channels * mult)
                 if ds in self.attention_resolutions:
-                    layers.append(AttentionParams(ch, num_heads))
+                    layers.append(AttentionParams(ch, num_heads, dims))
                 if level and i == num_res_blocks:
-                    layers.append(UpsampleParams(ch, ch, k))
+                    layers.append(UpsampleParams(ch, ch, k, dims))
                     ds //= 2
                 self.output_blocks.append(BlockSeq(*layers))
 
-        self.out = nn.Sequential(_gn(ch), nn.SiLU(), _zero(nn.Conv1d(input_ch, out_channels, k, padding="same")))
+        self.out = nn.Sequential(_gn(ch), nn.SiLU(), _zero(_conv(dims)(input_ch, out_channels, k, padding="same")))
         self._engine_cache = {}
         self._conv_scheme = "auto"   # "bf16x3" once the range guard of the fp16-range scheme has fired (engine.py)
 
@@ -199,6 +211,9 @@ class UNetModel(nn.Module):
         assert (cond is not None) == (self.cond_features is not None), (
             "must specify cond if and only if the model is conditioned"
         )
+        if self.dims == 2:   # the generate_waveforms.py family: stock PyTorch operators (family2d.py), never the 1-D path
+            from . import family2d
+            return family2d.unet_forward(self, x, timesteps, cond)
         engine.require_device(x)
         eng = self._engine(x.shape[0], x.shape[2], x.device)
         train = self.training and torch.is_grad_enabled()
