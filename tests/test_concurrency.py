@@ -116,3 +116,69 @@ def test_sampler_lanes_are_deterministic_at_the_bench_batch():
     runs = [edm.sample_deterministically(eps, s3, None, cond, lanes=n).clone() for n in (4, 4, 1, 2)]
     assert torch.equal(runs[0], runs[1]), "two 4-lane integrations differ: a race between the lanes"
     assert torch.equal(runs[0], runs[2]) and torch.equal(runs[0], runs[3]), "lanes change the result"
+
+
+def test_training_step_next_to_other_streams():
+    """The data-parallel trainer starts the gradient all-reduce from inside the backward sweep: RCCL's kernels then share compute
+    units with the weight- / data-gradient, GroupNorm-backward and attention-backward launches.  The 1-GPU box cannot run RCCL
+    between two ranks, so other kernels play that part here: a second stream keeps attention kernels (the aggressors that exposed
+    the head-conv fault) and streaming copies / reductions over an all-reduce-sized buffer in flight while the main stream runs
+    the paper UNet's training step (dropout on).  Gradients written by plain stores must be bit-identical to the quiet run; the
+    few that are accumulated by fp32 atomics (bias column sums, GroupNorm affine) to rounding."""
+    from tqdne_amd import LightningEDM, ops, paper_1d_unet_config, rng
+    from tqdne_amd.autograd import edm_loss_and_grads
+    torch.manual_seed(0)
+    edm = LightningEDM(paper_1d_unet_config(), {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
+    edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
+    edm = edm.to(dev()).train()
+    B, T = 8, 4096
+    g = torch.Generator().manual_seed(5)
+    x = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev())
+    cond = torch.randn(B, 5, generator=g).to(dev())
+    eps, noise = torch.randn(B, generator=g).to(dev()), torch.randn(B, 3, T, generator=g).to(dev())
+    qkv = torch.randn(16, 512, 768, generator=g).to(dev())
+    dout = torch.randn(16, 512, 256, generator=g).to(dev())
+    o_ref, lse = ops.attention(qkv, 4, return_lse=True)
+    big = torch.randn(16 << 20, generator=g).to(dev())   # 64 MB: the flat gradient buffer's size
+    big2 = torch.empty_like(big)
+
+    def step():
+        rng.seed_rank(3, 0)   # same dropout masks every time
+        loss, flat = edm_loss_and_grads(edm, x, eps, noise, cond, lanes=1)
+        bwd = edm.unet._engine(B, T, dev())._bwd
+        return float(loss), flat[:bwd.n_grad].clone(), bwd
+
+    loss0, g0, bwd = step()
+    loss1, g1, _ = step()
+    torch.cuda.synchronize()
+    atomic = set()   # gradients accumulated with fp32 atomics: their bits depend on the arrival order even in a quiet run
+    for name, p in edm.unet.named_parameters():
+        o = bwd.offs[id(p)]
+        if not torch.equal(g0[o:o + p.numel()], g1[o:o + p.numel()]):
+            atomic.add(name)
+    # by design (backward.hip): bias / embedding column sums, GroupNorm affine, embedding MLPs (fed by those sums), and the stem / head
+    # weights (3-channel convs, accumulated over the batch with atomics)
+    by_design = lambda n: (n.endswith(".bias") or ".in_layers.0." in n or ".out_layers.0." in n or ".norm." in n or n.startswith("out.0.")
+                           or "emb" in n or "mlp" in n or n in ("input_blocks.0.0.weight", "out.2.weight"))
+    assert all(by_design(n) for n in atomic), sorted(n for n in atomic if not by_design(n))[:8]
+    side = torch.cuda.Stream(dev())
+    aggressors = [lambda: ops.attention(qkv, 4), lambda: ops.attention_bwd(qkv, o_ref, dout, lse, 4),
+                  lambda: big2.copy_(big), lambda: big2.add_(big), lambda: torch.sum(big)]
+    for rep in range(3):
+        side.wait_stream(torch.cuda.current_stream(dev()))
+        with torch.cuda.stream(side):
+            for _ in range(40):   # ~40 ms of foreign kernels: longer than the step
+                for a in aggressors:
+                    a()
+        loss, gr, _ = step()
+        torch.cuda.synchronize()
+        assert loss == pytest.approx(loss0, rel=1e-6)
+        worst = 0.0
+        for name, p in edm.unet.named_parameters():
+            o = bwd.offs[id(p)]
+            a, b = gr[o:o + p.numel()], g0[o:o + p.numel()]
+            if name in atomic:
+                worst = max(worst, float((a - b).abs().max()) / max(float(b.abs().max()), 1e-4 * float(g0.abs().max())))
+            else:
+                assert torch.equal(a, b), f"round {rep}: gradient of {name} changed next to foreign kernels"
+        assert worst < 1e-4, worst
