@@ -318,13 +318,48 @@ int wgrad_nci(const TqConvDesc* d) {
     return (d->C_in0 % 64 == 0 && d->C_in1 % 64 == 0) ? 2 : 1;
 }
 
+// Workgroups of the weight-gradient kernel the device holds at once (occupancy of the instantiation x compute units), per
+// (taps, stride, upsample, chunk width); queried once.  The (b, t) reduction is split over as many workgroups as fill ONE
+// residency round: with the former fixed target of 768 the paper UNet's launches were 1.46 rounds of 512 resident workgroups
+// (256 -> 256, k = 5: 752), i.e. the second round ran on half the chip (rocprofv3: 1.28 waves per SIMD on average).
+template <int KT, int STRIDE, int UPS, int NCI>
+int wgrad_slots_of() {
+    static const int slots = [] {
+        constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
+        const size_t sh = 2 * WG_TT * WG_DY_STRIDE + 2 * XR * 64 * NCI + 128 * sizeof(float);
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_kernel<KT, STRIDE, UPS, NCI>, 256, sh) != hipSuccess ||
+            per_cu < 1 || cus < 1) {
+            (void)hipGetLastError();
+            return 512;   // (no device: 2 workgroups x 256 compute units, what __launch_bounds__(256, 2) asks for on MI355X)
+        }
+        return per_cu * cus;
+    }();
+    return slots;
+}
+
+int wgrad_slots(const TqConvDesc* d, int nci) {
+    if (d->stride == 2) return nci == 2 ? wgrad_slots_of<3, 2, 0, 2>() : wgrad_slots_of<3, 2, 0, 1>();
+    if (d->upsample) {
+        if (d->ktaps == 5) return nci == 2 ? wgrad_slots_of<5, 1, 1, 2>() : wgrad_slots_of<5, 1, 1, 1>();
+        return nci == 2 ? wgrad_slots_of<3, 1, 1, 2>() : wgrad_slots_of<3, 1, 1, 1>();
+    }
+    if (d->ktaps == 5) return nci == 2 ? wgrad_slots_of<5, 1, 0, 2>() : wgrad_slots_of<5, 1, 0, 1>();
+    if (d->ktaps == 3) return nci == 2 ? wgrad_slots_of<3, 1, 0, 2>() : wgrad_slots_of<3, 1, 0, 1>();
+    return nci == 2 ? wgrad_slots_of<1, 1, 0, 2>() : wgrad_slots_of<1, 1, 0, 1>();
+}
+
 void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_ttiles, int& nsplit, int& ups) {
+    const int nci = wgrad_nci(d);
     n_cotiles = (d->C_out + 127) / 128;
-    n_cichunks = (d->C_in0 + d->C_in1) / (32 * wgrad_nci(d));
+    n_cichunks = (d->C_in0 + d->C_in1) / (32 * nci);
     n_ttiles = (d->T_out + WG_TT - 1) / WG_TT;
     const int U = d->B * n_ttiles;
     const int ntiles = n_cotiles * n_cichunks;
-    int want = (768 + ntiles - 1) / ntiles;
+    static const int forced = [] { const char* e = getenv("TQDNE_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();   // (A/B switch)
+    const int slots = forced > 0 ? forced : wgrad_slots(d, nci);
+    int want = slots / ntiles;   // splits per output tile: the grid fills one round of resident workgroups, not more
     if (want < 1) want = 1;
     if (want > U) want = U;
     ups = (U + want - 1) / want;
