@@ -53,6 +53,7 @@ struct WgArgs {
 };
 
 constexpr int WG_TT = 64;        // reduction positions per staged tile
+constexpr int TQ_WGRAD_PLAIN_ORDER = 1 << 30;  // (internal flag bit of WgArgs.flags: A/B switch TQDNE_WGRAD_XCD=0)
 constexpr int WG_DY_STRIDE = 272;  // bytes per dy image row (128 co * 2 B + 16 pad)
 
 // NCI: input-channel chunk of a workgroup in units of 32.  The dy tile (128 co) is staged, split and read once per workgroup and
@@ -75,10 +76,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    const int ct = bid % p.n_cotiles; bid /= p.n_cotiles;
-    const int cc = bid % p.n_cichunks;
-    const int sp = bid / p.n_cichunks;
+    // Workgroups are dealt round-robin over the 8 XCDs (ids i and i + 8 share an L2).  The input-channel-chunk workgroups of one
+    // (split, co-tile) pair all stage the same dy tile: keep a pair on ONE XCD, so its L2 serves the re-reads (with the plain
+    // order every XCD fetched every dy tile: 404 MB from HBM for 134 MB of operands, 57 % L2 misses).
+    int ct, cc, sp;
+    {
+        const int bid = blockIdx.x;
+        const int npairs = p.nsplit * p.n_cotiles;
+        if ((npairs & 7) == 0 && !(p.flags & TQ_WGRAD_PLAIN_ORDER)) {
+            const int xcd = bid & 7, j = bid >> 3;
+            const int pi = (j / p.n_cichunks) * 8 + xcd;
+            cc = j % p.n_cichunks;
+            sp = pi / p.n_cotiles;
+            ct = pi % p.n_cotiles;
+        } else {
+            ct = bid % p.n_cotiles;
+            cc = (bid / p.n_cotiles) % p.n_cichunks;
+            sp = bid / (p.n_cotiles * p.n_cichunks);
+        }
+    }
     const int co0 = ct * 128;
     const int cb = cc * 32 * NCI;
     const int Cin = p.C0 + p.C1;
@@ -410,6 +426,8 @@ extern "C" int tq_conv1d_bwd_weight_colsum(const TqConvDesc* d, const float* dy,
     a.flags = d->flags;
     a.cs_bc = colsum_bc; a.cs_stride = bc_stride; a.cs_c = colsum_c; a.cs_c2 = colsum_c2;
     wgrad_plan(d, a.n_cotiles, a.n_cichunks, a.n_ttiles, a.nsplit, a.units_per_split);
+    static const bool plain_order = [] { const char* e = getenv("TQDNE_WGRAD_XCD"); return e && atoi(e) == 0; }();
+    if (plain_order) a.flags |= TQ_WGRAD_PLAIN_ORDER;
     a.drop_site = d->dropout_site; a.drop_seed = d->dropout_seed;
     float pdrop = d->dropout_p;
     if (!(d->flags & TQ_CONV_DROPOUT) || pdrop <= 0.f) { a.flags &= ~TQ_CONV_DROPOUT; pdrop = 0.f; }
