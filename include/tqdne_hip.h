@@ -105,6 +105,19 @@ int tq_abi_version(void);
 size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode);
 int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* packed, hipStream_t stream);
 int tq_conv_tile_co(int C_out);
+/* All (re)packs of a plan in one launch (what a training step re-does after every optimizer update: torch parameters ->
+ * forward / transposed fragments, plus the gather of the ResBlocks' embedding projections into their concatenated buffers,
+ * unet.py:91-97).  jobs: a DEVICE array, block_begin = running sum of tq_pack_job_blocks over the preceding jobs.
+ * mode 0..3 as tq_pack_conv_weight; mode 4: copy C_out floats src -> dst. */
+typedef struct TqPackJob {
+    const void* src;
+    void* dst;
+    int32_t C_out, C_in, K, mode;
+    int32_t block_begin;
+    int32_t reserved;
+} TqPackJob;
+int tq_pack_job_blocks(int C_out, int C_in, int K, int mode);
+int tq_pack_jobs(const TqPackJob* jobs_device, int njobs, int total_blocks, hipStream_t stream);
 
 /* ---- fused convolution ---------------------------------------------------------------------------------- */
 /* Replaces GroupNorm32 -> SiLU -> Dropout -> Conv1d(k in {1,3,5}) -> +emb -> +residual, the channel concat and the

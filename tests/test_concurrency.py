@@ -161,6 +161,7 @@ def test_training_step_next_to_other_streams():
     by_design = lambda n: (n.endswith(".bias") or ".in_layers.0." in n or ".out_layers.0." in n or ".norm." in n or n.startswith("out.0.")
                            or "emb" in n or "mlp" in n or n in ("input_blocks.0.0.weight", "out.2.weight"))
     assert all(by_design(n) for n in atomic), sorted(n for n in atomic if not by_design(n))[:8]
+    atomic = {n for n, _ in edm.unet.named_parameters() if by_design(n)}   # (two quiet runs may agree by chance: judge all of them to rounding)
     side = torch.cuda.Stream(dev())
     aggressors = [lambda: ops.attention(qkv, 4), lambda: ops.attention_bwd(qkv, o_ref, dout, lse, 4),
                   lambda: big2.copy_(big), lambda: big2.add_(big), lambda: torch.sum(big)]

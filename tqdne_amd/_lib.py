@@ -70,6 +70,11 @@ class TqGemmJob(C.Structure):
                 ("pre_b", C.c_int32), ("tile_begin", C.c_int32)]
 
 
+class TqPackJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("C_out", C.c_int32), ("C_in", C.c_int32), ("K", C.c_int32),
+                ("mode", C.c_int32), ("block_begin", C.c_int32), ("reserved", C.c_int32)]
+
+
 class TqConvBwdDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T", C.c_int32), ("C_dy", C.c_int32), ("C_dx0", C.c_int32), ("C_dx1", C.c_int32),
@@ -118,6 +123,8 @@ _PROTOS = {
     "tq_conv1d_bwd_weight_colsum": (I, [VP] * 8 + [SZ, VP, I, VP, VP, VP]),
     "tq_gn_bwd_finalize": (I, [VP, VP, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
     "tq_gn_bwd_apply": (I, [VP] * 7 + [I] * 6 + [VP]),
+    "tq_pack_job_blocks": (I, [I, I, I, I]),
+    "tq_pack_jobs": (I, [VP, I, I, VP]),
     "tq_gemm_tiles": (I, [I, I]),
     "tq_gemm_f32_jobs": (I, [VP, I, I, VP]),
     "tq_fourier_features": (I, [VP, VP, VP, I, I, VP]),

@@ -1322,11 +1322,10 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
 //   [2] fp8(W) of channels 16 kq + j,  [3] fp8((W - fp16(W)) * 2^12) of the same channels (j < 16)
 // ------------------------------------------------------------------------------------------------
 namespace {
-__global__ void pack_conv_weight_mx_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
-                                           uint4* __restrict__ out) {
+__device__ __forceinline__ void pack_mx_body(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
+                                             uint4* __restrict__ out, size_t gid) {
     const int nchunks = (C_in + 63) / 64;
     const size_t total = (size_t)nchunks * K * ncob_pad * 64;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int lane = gid & 63;
     size_t r = gid >> 6;
@@ -1367,11 +1366,15 @@ __global__ void pack_conv_weight_mx_kernel(const float* __restrict__ w, int C_ou
 
 // mode 3 (TQ_WFMT_F16_MX6): fragments [0], [1] as mode 2; [2] = dwords 0..3 and [3] = {dwords 4, 5, E8M0 byte, 0} of the lane's
 // e2m3 block: channels 16 kq + i, element 2i = W, element 2i + 1 = (W - fp16(W)) * 2^12, both divided by the block's 2^e
-__global__ void pack_conv_weight_mx6_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
-                                            uint4* __restrict__ out) {
+__global__ void pack_conv_weight_mx_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
+                                           uint4* __restrict__ out) {
+    pack_mx_body(w, C_out, C_in, K, ncob_pad, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__device__ __forceinline__ void pack_mx6_body(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
+                                              uint4* __restrict__ out, size_t gid) {
     const int nchunks = (C_in + 63) / 64;
     const size_t total = (size_t)nchunks * K * ncob_pad * 64;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int lane = gid & 63;
     size_t r = gid >> 6;
@@ -1406,11 +1409,15 @@ __global__ void pack_conv_weight_mx6_kernel(const float* __restrict__ w, int C_o
     out[o + 192] = make_uint4(pk[4], pk[5], ba, 0u);
 }
 
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int mode,
-                                        int rows, int kdim, int ncob_pad, uint4* __restrict__ out) {
+__global__ void pack_conv_weight_mx6_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
+                                            uint4* __restrict__ out) {
+    pack_mx6_body(w, C_out, C_in, K, ncob_pad, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__device__ __forceinline__ void pack_bf16_body(const float* __restrict__ w, int C_out, int C_in, int K, int mode, int rows, int kdim,
+                                               int ncob_pad, uint4* __restrict__ out, size_t gid) {
     const int nchunks = (kdim + 31) / 32;
     const size_t total = (size_t)nchunks * K * ncob_pad * 64;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int lane = gid & 63;
     size_t r = gid >> 6;
@@ -1435,7 +1442,59 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int C_out, 
     out[o] = hi.u;
     out[o + 64] = lo.u;
 }
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int mode,
+                                        int rows, int kdim, int ncob_pad, uint4* __restrict__ out) {
+    pack_bf16_body(w, C_out, C_in, K, mode, rows, kdim, ncob_pad, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Every weight (re)pack of a plan in ONE launch: after an optimizer step the paper UNet re-packs ~160 tensors (forward fragments,
+// transposed fragments for the data gradients) and gathers 44 embedding-projection tensors into their concatenated buffers -- as
+// separate 4-8 us launches that was ~1.2 ms of a 28 ms training step at < 0.1 waves per SIMD.  Workgroup -> job by binary search
+// over the jobs' first block.
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const TqPackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const TqPackJob jb = jobs[lo];
+    const size_t gid = (size_t)(blockIdx.x - jb.block_begin) * 256 + threadIdx.x;
+    const float* w = reinterpret_cast<const float*>(jb.src);
+    if (jb.mode == 4) {   // plain copy of C_out floats
+        if (gid < (size_t)jb.C_out) reinterpret_cast<float*>(jb.dst)[gid] = w[gid];
+        return;
+    }
+    const int rows = jb.mode != 1 ? jb.C_out : jb.C_in;
+    const int kdim = jb.mode != 1 ? jb.C_in : jb.C_out;
+    const int tile = (rows % 128 == 0) ? 128 : ((rows % 64 == 0) ? 64 : 32);   // = tq_conv_tile_co
+    const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
+    uint4* out = reinterpret_cast<uint4*>(jb.dst);
+    if (jb.mode == 2) pack_mx_body(w, jb.C_out, jb.C_in, jb.K, ncob_pad, out, gid);
+    else if (jb.mode == 3) pack_mx6_body(w, jb.C_out, jb.C_in, jb.K, ncob_pad, out, gid);
+    else pack_bf16_body(w, jb.C_out, jb.C_in, jb.K, jb.mode, rows, kdim, ncob_pad, out, gid);
+}
 }  // namespace
+
+extern "C" int tq_pack_job_blocks(int C_out, int C_in, int K, int mode) {
+    if (C_out <= 0 || mode < 0 || mode > 4) return 0;
+    if (mode == 4) return (C_out + 255) / 256;
+    if (C_in <= 0 || K <= 0) return 0;
+    const int rows = mode != 1 ? C_out : C_in;
+    const int kdim = mode != 1 ? C_in : C_out;
+    const int tile = tq_conv_tile_co(rows);
+    const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
+    const size_t total = (mode == 2 || mode == 3) ? (size_t)((C_in + 63) / 64) * K * ncob_pad * 64
+                                                  : (size_t)((kdim + 31) / 32) * K * ncob_pad * 64;
+    return (int)((total + 255) / 256);
+}
+
+extern "C" int tq_pack_jobs(const TqPackJob* jobs_device, int njobs, int total_blocks, hipStream_t stream) {
+    if (!jobs_device || njobs <= 0 || total_blocks <= 0) return TQ_ERR_ARG;
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, jobs_device, njobs);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode) {
     if (mode == 2 || mode == 3) {

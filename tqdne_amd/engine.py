@@ -70,6 +70,52 @@ class ConvRec:
         self.stride, self.upsample, self.silu, self.dropout = stride, upsample, silu, dropout
 
 
+_PACK_TABLES: dict = {}
+PACK_BATCH = os.environ.get("TQDNE_PACK_BATCH", "1") != "0"   # A/B switch: 0 = one launch per tensor (rounds 1-2 behaviour)
+
+
+def pack_batch(lib, dev, jobs, stream, capturing=False):
+    """Run a list of (src_ptr, dst_ptr, C_out, C_in, K, mode) weight packs / copies (mode 4: C_out floats) as ONE launch
+    (tq_pack_jobs).  The device job table is built once per distinct list (a host-to-device copy) and cached; under stream capture
+    an unseen list falls back to one launch per job."""
+    if not jobs:
+        return
+    key = (str(dev), tuple(jobs))
+    ent = _PACK_TABLES.get(key)
+    if ent is None and (capturing or not PACK_BATCH or len(jobs) < 2):
+        ent = False
+    if ent is None:
+        arr = (_lib.TqPackJob * len(jobs))()
+        total = 0
+        for jb, (src, dst, co, ci, k, mode) in zip(arr, jobs):
+            jb.src, jb.dst, jb.C_out, jb.C_in, jb.K, jb.mode, jb.block_begin = src, dst, co, ci, k, mode, total
+            nb = lib.tq_pack_job_blocks(co, ci, k, mode)
+            if nb <= 0:
+                raise ValueError(f"bad pack job {(co, ci, k, mode)}")
+            total += nb
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        if len(_PACK_TABLES) > 64:
+            _PACK_TABLES.clear()
+        ent = _PACK_TABLES[key] = (table, len(jobs), total)
+    if ent is False:
+        for src, dst, co, ci, k, mode in jobs:
+            if mode == 4:
+                _lib_copy_floats(dst, src, co, stream)
+            else:
+                check(lib.tq_pack_conv_weight(src, co, ci, k, mode, dst, stream), "pack")
+        return
+    table, n, total = ent
+    check(lib.tq_pack_jobs(table.data_ptr(), n, total, stream), "pack jobs")
+
+
+def _lib_copy_floats(dst, src, n, stream):
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    rc = rt.hipMemcpyAsync(ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(4 * n), 3, ctypes.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpyAsync failed: {rc}")
+
+
 class PackedStore:
     """The packed MFMA weight fragments (and the derived weight tensors) of ONE model on one device, shared by every execution
     plan of that model: the fragments depend on the weights only, not on the batch, the length or the sampler lane.  One copy
@@ -601,14 +647,21 @@ class UNetEngine:
                 for sid, ev in store.users.items():   # nobody may still be reading the fragments about to be overwritten
                     if sid != stream:
                         cur.wait_event(ev)
+            jobs = []
             for st, ver in sites:
-                check(lib.tq_pack_conv_weight(st.weight.data_ptr(), st.C_out, st.C_in, st.K, st.pack_mode, st.packed.data_ptr(), stream),
-                      "pack " + st.name)
+                jobs.append((st.weight.data_ptr(), st.packed.data_ptr(), st.C_out, st.C_in, st.K, st.pack_mode))
                 if st.tail is not None:
                     t = st.tail
-                    check(lib.tq_pack_conv_weight(t.weight.data_ptr(), t.C_out, t.C_in, t.K, t.pack_mode, t.packed.data_ptr(), stream),
-                          "pack " + t.name)
+                    jobs.append((t.weight.data_ptr(), t.packed.data_ptr(), t.C_out, t.C_in, t.K, t.pack_mode))
                 st.entry["ver"] = ver
+            if emb is not None:   # gather of the ResBlocks' embedding projections into the concatenated (emb_total, E) buffers
+                for rb in self.res_blocks:
+                    if hasattr(rb, "emb_layers"):
+                        o = self.emb_offsets[id(rb)]
+                        w, b_ = rb.emb_layers[1].weight, rb.emb_layers[1].bias
+                        jobs.append((w.data_ptr(), self.emb_w.data_ptr() + 4 * o * self.E, w.numel(), 0, 0, 4))
+                        jobs.append((b_.data_ptr(), self.emb_b.data_ptr() + 4 * o, b_.numel(), 0, 0, 4))
+            pack_batch(lib, self.dev, jobs, stream, capturing)
             with torch.no_grad():
                 for ps, src, ver in polys:  # two-phase k = 3 restatement of the upsampling convs (see _polyphase_op)
                     w, Cr = src.weight, src.C_out
@@ -622,12 +675,7 @@ class UNetEngine:
                           "pack " + ps.name)
                     ps.entry["ver"] = ver
                 if emb is not None:
-                    for rb in self.res_blocks:
-                        if hasattr(rb, "emb_layers"):
-                            o = self.emb_offsets[id(rb)]
-                            self.emb_w[o:o + rb.out_channels].copy_(rb.emb_layers[1].weight)
-                            self.emb_b[o:o + rb.out_channels].copy_(rb.emb_layers[1].bias)
-                    if getattr(self, "emb_desc", None) is not None:
+                    if getattr(self, "emb_desc", None) is not None:   # (reads emb_w: stream-ordered behind the gather above)
                         check(lib.tq_pack_conv_weight(self.emb_w.data_ptr(), self.emb_total, self.E, 1, self.emb_pack_mode,
                                                       self.emb_packed.data_ptr(), stream), "pack emb projections")
                     store.entries["emb_w"]["ver"] = emb
@@ -652,9 +700,8 @@ class UNetEngine:
         v = sum(s.weight._version for s in self.dgrad_sites)
         if v == self._wt_version:
             return
-        for s in self.dgrad_sites:
-            check(self.lib.tq_pack_conv_weight(s.weight.data_ptr(), s.C_out, s.C_in, s.K, 1, s.packed_t.data_ptr(), stream),
-                  "pack^T " + s.name)
+        pack_batch(self.lib, self.dev, [(s.weight.data_ptr(), s.packed_t.data_ptr(), s.C_out, s.C_in, s.K, 1) for s in self.dgrad_sites],
+                   stream, torch.cuda.is_current_stream_capturing())
         self._wt_version = v
 
     # ------------------------------------------------------------------ run

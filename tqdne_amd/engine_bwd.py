@@ -8,7 +8,7 @@ Per block (reverse of the fusion map in engine.py):
                   gn_bwd_finalize | gn_bwd_apply (+ residual)
   Downsample      wgrad(stride 2) | zero_stuff + stride-1 dgrad      Upsample   wgrad(upsampled gather) | dgrad + pair_sum
   head / stem     dedicated small kernels
-The tiny (B x 256) embedding-MLP backward is a handful of plain library GEMMs (torch.mm -> hipBLASLt).
+The tiny (B x 256) embedding-MLP backward is four launches of a job-table fp32 GEMM kernel (tq_gemm_f32_jobs, _embedding_jobs).
 Tensors consumed twice (the UNet skip stack) get their gradient written by the first consumer met in the reverse
 sweep and accumulated by the second (accumulate flags are resolved when the plan is built).
 """
@@ -489,8 +489,9 @@ class BackwardPlan:
 
     def _embedding_jobs(self):
         """The job tables of the embedding backward (built once: every operand is a static buffer of the plan or a parameter).
-        Three dependent levels, each ONE tq_gemm_f32_jobs launch:
-          1  d W_proj = d emb_all^T . SiLU(emb);  d b_proj = 1^T . d emb_all;  d emb = (d emb_all . W_proj) * SiLU'(emb)
+        Dependent levels, each ONE tq_gemm_f32_jobs launch:
+          1  d W_proj = d emb_all^T . SiLU(emb);  d b_proj = 1^T . d emb_all;  partial products of d emb_all . W_proj
+          1b d emb = (sum of the partial products) * SiLU'(emb)
           2  per MLP (time, cond): d W_2 = d emb^T . SiLU(h);  d b_2 = 1^T . d emb;  d h = (d emb . W_2) * SiLU'(h)
           3  per MLP: d W_0 = d h^T . input;  d b_0 = 1^T . d h      (input = Fourier features / cond)"""
         from ._lib import TqGemmJob
@@ -517,9 +518,19 @@ class BackwardPlan:
 
         demb, ones = self.demb_all, self.ones
         hid = e.emb_hidden.stride(0)
+        # d emb = d emb_all . W_proj reduces over all Et = sum of the blocks' channels (5632 for the paper UNet) into only
+        # B x E / 32^2 = 16 output tiles: as one job that is 16 workgroups walking 176 dependent load -> barrier -> FMA rounds
+        # (measured 160 us for 0.18 GFLOP).  Split along the reduction into KS partial products (same launch as the weight /
+        # bias gradients), summed and multiplied by SiLU'(emb) by a one-row "GEMM" with a vector of ones in a launch of its own.
+        KS = max(1, min(int(__import__("os").environ.get("TQDNE_EMB_KSPLIT", "16")), Et // 256, B))   # (env: A/B switch, 1 = one job)
+        self.d_emb_part = self._empty(KS, B, E)
+        kcut = [(Et * i // KS) // 32 * 32 for i in range(KS)] + [Et]
         lv1 = [job(_p(demb), 1, Et, _p(e.silu_emb), E, 1, _p(self.g_emb_w), E, Et, E, B),          # d W_proj
-               job(_p(ones), 0, 1, _p(demb), Et, 1, _p(self.g_emb_b), Et, 1, Et, B),                # d b_proj
-               job(_p(demb), Et, 1, _p(e.emb_w), E, 1, _p(self.d_emb), E, B, E, Et, U=_p(e.emb), ldu=E)]
+               job(_p(ones), 0, 1, _p(demb), Et, 1, _p(self.g_emb_b), Et, 1, Et, B)]               # d b_proj
+        for i in range(KS):
+            k0, k1 = kcut[i], kcut[i + 1]
+            lv1.append(job(_p(demb) + 4 * k0, Et, 1, _p(e.emb_w) + 4 * k0 * E, E, 1, _p(self.d_emb_part[i]), E, B, E, k1 - k0))
+        lv1b = [job(_p(ones), 0, 1, _p(self.d_emb_part), B * E, 1, _p(self.d_emb), B * E, 1, B * E, KS, U=_p(e.emb), ldu=B * E)]
         lv2 = [job(_p(self.d_emb), 1, E, _p(h0), hid, 1, _p(self.gv(tm[2].weight)), E, E, E, B, pre_b=1),
                job(_p(ones), 0, 1, _p(self.d_emb), E, 1, _p(self.gv(tm[2].bias)), E, 1, E, B),
                job(_p(self.d_emb), E, 1, _p(tm[2].weight), E, 1, _p(self.dh0), E, B, E, E, U=_p(h0), ldu=hid)]
@@ -533,7 +544,7 @@ class BackwardPlan:
             lv3 += [job(_p(self.dc0), 1, E, _p(self.cond_buf), nc, 1, _p(self.gv(cm[0].weight)), nc, E, nc, B),
                     job(_p(ones), 0, 1, _p(self.dc0), E, 1, _p(self.gv(cm[0].bias)), E, 1, E, B)]
         self._gemm_levels = []
-        for jobs in (lv1, lv2, lv3):
+        for jobs in (lv1, lv1b, lv2, lv3):
             total = 0
             for jb in jobs:
                 jb.tile_begin = total
