@@ -537,17 +537,18 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ g, const float* __
 // out_bc[b*stride + c] += sum_t dy[b,t,c];  out_c[c] += sum_{b,t} dy   (both optional; atomics into zeroed buffers)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int T, int C, float* __restrict__ out_bc,
                                                      int bc_stride, float* __restrict__ out_c, float* __restrict__ out_c2,
-                                                     const float* __restrict__ bscale) {
+                                                     const float* __restrict__ bscale, int rpw) {
+    // rpw: rows (positions) per workgroup
     extern __shared__ float red[];
-    const int nsl = (T + STAT_SLOT - 1) / STAT_SLOT;
+    const int nsl = (T + rpw - 1) / rpw;
     const int slot = blockIdx.x % nsl, b = blockIdx.x / nsl;
     const int c4n = C >> 2;
     const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
     const int c4 = threadIdx.x % c4n, tr = threadIdx.x / c4n;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tr < nrow && threadIdx.x < nrow * c4n) {
-        const int nvalid = min(STAT_SLOT, T - slot * STAT_SLOT);
-        const float* src = dy + ((size_t)b * T + slot * STAT_SLOT) * C + 4 * c4;
+        const int nvalid = min(rpw, T - slot * rpw);
+        const float* src = dy + ((size_t)b * T + (size_t)slot * rpw) * C + 4 * c4;
         int tl = tr;
         // 8 rows in flight per thread (a dependent load-add chain over up to 128 rows ran at 2 TB/s)
         for (; tl + 7 * nrow < nvalid; tl += 8 * nrow) {
@@ -638,11 +639,17 @@ extern "C" int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, in
                          const float* bscale, hipStream_t stream) {
     if (!dy || (!out_bc && !out_c && !out_c2)) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || C < 4 || C % 4 || C > 1024) return TQ_ERR_SHAPE;
-    const int nsl = (T + STAT_SLOT - 1) / STAT_SLOT;
+    // Every workgroup ends in C atomic adds onto the same C addresses (plus its sample's): those, not the loads, bound the
+    // kernel (more, smaller workgroups measured SLOWER).  So: as many rows per workgroup as still leaves >= 512 workgroups.
+    static const int forced = [] { const char* e = getenv("TQDNE_COLSUM_ROWS"); return e ? atoi(e) : 0; }();   // (A/B switch)
+    int rpw = STAT_SLOT;
+    while (rpw < 1024 && (size_t)B * ((T + 2 * rpw - 1) / (2 * rpw)) >= 512) rpw <<= 1;
+    if (forced > 0) rpw = forced;
+    const int nsl = (T + rpw - 1) / rpw;
     const int c4n = C / 4;
     const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
     const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float);
-    hipLaunchKernelGGL(colsum_kernel, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, out_c2, bscale);
+    hipLaunchKernelGGL(colsum_kernel, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, out_c2, bscale, rpw);
     TQ_CHECK_LAUNCH();
     return 0;
 }
