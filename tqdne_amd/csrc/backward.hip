@@ -54,7 +54,15 @@ struct WgArgs {
 
 constexpr int WG_TT = 64;        // reduction positions per staged tile
 constexpr int TQ_WGRAD_PLAIN_ORDER = 1 << 30;  // (internal flag bit of WgArgs.flags: A/B switch TQDNE_WGRAD_XCD=0)
-constexpr int WG_DY_STRIDE = 272;  // bytes per dy image row (128 co * 2 B + 16 pad)
+// LDS images of the weight gradient, conflict-free for ds_read_b64_tr_b16 (32-lane groups: rows {r .. r+3} and {r+8 .. r+11},
+// 8 bytes per lane): row stride = 8 banks (mod 64) for dy, 16 banks for the 64-byte xhat rows, and the 8-byte column slot is
+// XOR-ed with bit 3 of the row (dy: slot ^ 16, xhat: slot ^ 4), so that the two 4-row halves of a group -- 8 rows apart, i.e. a
+// multiple of 64 banks -- land in different halves of their rows' bank windows.  (272-byte / plain rows: 40 % of the LDS-active
+// cycles were conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.)
+constexpr int WG_DY_STRIDE1 = 288;  // bytes per dy image row, 32-channel chunks (128 co * 2 B + 32 pad: 72 banks = 8 mod 64)
+constexpr int WG_DY_STRIDE2 = 272;  // 64-channel chunks (k = 1 only): the plain image -- 288-byte rows would cost the third resident workgroup
+template <int NCI> __device__ __forceinline__ int wg_dy_swz(int row) { return NCI == 1 ? ((row >> 3) & 1) << 7 : 0; }   // slot ^ 16
+__device__ __forceinline__ int wg_x_swz(int row) { return ((row >> 3) & 1) << 5; }    // byte offset XOR: slot ^ 4 (64-byte rows)
 
 // NCI: input-channel chunk of a workgroup in units of 32.  The dy tile (128 co) is staged, split and read once per workgroup and
 // unit whatever the chunk width, so the 64-channel chunk (NCI = 2) halves the number of times dy is re-read from L2 / HBM and
@@ -66,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
     constexpr int WG_X_STRIDE = 64 * NCI;    // bytes per xhat image row (32 NCI ci * 2 B)
     constexpr int XC4 = 8 * NCI;             // float4 columns of the xhat tile
     constexpr int XIT = (XR * XC4 + 255) / 256;
+    constexpr int WG_DY_STRIDE = NCI == 1 ? WG_DY_STRIDE1 : WG_DY_STRIDE2;
     constexpr int DY_PLANE = WG_TT * WG_DY_STRIDE;
     constexpr int X_PLANE = XR * WG_X_STRIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
             bf16x4 h, l;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { __bf16 hh, ll; split_bf16(v[j], hh, ll); h[j] = hh; l[j] = ll; }
-            const int off = row * WG_DY_STRIDE + c4 * 8;
+            const int off = row * WG_DY_STRIDE + ((c4 * 8) ^ wg_dy_swz<NCI>(row));
             *reinterpret_cast<bf16x4*>(dy_hi + off) = h;
             *reinterpret_cast<bf16x4*>(dy_lo + off) = l;
         }
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
             bf16x4 h, l;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { __bf16 hh, ll; split_bf16(v[j], hh, ll); h[j] = hh; l[j] = ll; }
-            const int off = i * WG_X_STRIDE + m * 8;
+            const int off = i * WG_X_STRIDE + (NCI == 1 ? ((m * 8) ^ wg_x_swz(i)) : m * 8);
             *reinterpret_cast<bf16x4*>(x_hi + off) = h;
             *reinterpret_cast<bf16x4*>(x_lo + off) = l;
         }
@@ -243,23 +252,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
             Frag ah[2], al[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                const int off = r0 * WG_DY_STRIDE + (wave * 32 + mb * 16 + 4 * pp) * 2;
+                const int col = (wave * 32 + mb * 16 + 4 * pp) * 2;
+                const int off = r0 * WG_DY_STRIDE + (col ^ wg_dy_swz<NCI>(r0));
+                const int off4 = off + 4 * WG_DY_STRIDE;   // (rows r0 and r0 + 4 share bit 3: r0 = 32 ks + 8 g + q, q < 4)
                 ah[mb].h[0] = lds_tr_read(dy_hi + off);
-                ah[mb].h[1] = lds_tr_read(dy_hi + off + 4 * WG_DY_STRIDE);
+                ah[mb].h[1] = lds_tr_read(dy_hi + off4);
                 al[mb].h[0] = lds_tr_read(dy_lo + off);
-                al[mb].h[1] = lds_tr_read(dy_lo + off + 4 * WG_DY_STRIDE);
+                al[mb].h[1] = lds_tr_read(dy_lo + off4);
             }
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const int xrow = (STRIDE == 1) ? (r0 + k) : ((k & 1) * (WG_TT + 1) + r0 + (k >> 1));
 #pragma unroll
                 for (int nb = 0; nb < 2 * NCI; ++nb) {
-                    const int off = xrow * WG_X_STRIDE + (nb * 16 + 4 * pp) * 2;
+                    const int colx = (nb * 16 + 4 * pp) * 2;
+                    const int off = xrow * WG_X_STRIDE + (NCI == 1 ? (colx ^ wg_x_swz(xrow)) : colx);
+                    const int off4 = NCI == 1 ? (xrow + 4) * WG_X_STRIDE + (colx ^ wg_x_swz(xrow + 4)) : off + 4 * WG_X_STRIDE;
                     Frag bh, bl;
                     bh.h[0] = lds_tr_read(x_hi + off);
-                    bh.h[1] = lds_tr_read(x_hi + off + 4 * WG_X_STRIDE);
+                    bh.h[1] = lds_tr_read(x_hi + off4);
                     bl.h[0] = lds_tr_read(x_lo + off);
-                    bl.h[1] = lds_tr_read(x_lo + off + 4 * WG_X_STRIDE);
+                    bl.h[1] = lds_tr_read(x_lo + off4);
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb)
                         acc[mb][nb][k] = mfma_x3(ah[mb].v, al[mb].v, bh.v, bl.v, acc[mb][nb][k]);
@@ -342,7 +355,7 @@ template <int KT, int STRIDE, int UPS, int NCI>
 int wgrad_slots_of() {
     static const int slots = [] {
         constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
-        const size_t sh = 2 * WG_TT * WG_DY_STRIDE + 2 * XR * 64 * NCI + 128 * sizeof(float);
+        const size_t sh = 2 * WG_TT * (NCI == 1 ? WG_DY_STRIDE1 : WG_DY_STRIDE2) + 2 * XR * 64 * NCI + 128 * sizeof(float);
         int per_cu = 0, dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_kernel<KT, STRIDE, UPS, NCI>, 256, sh) != hipSuccess ||
@@ -385,7 +398,7 @@ void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_tti
 template <int KT, int STRIDE, int UPS>
 int launch_wgrad(const WgArgs& a, int nci, hipStream_t stream) {
     constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
-    const size_t sh = 2 * WG_TT * WG_DY_STRIDE + 2 * XR * 64 * nci + 128 * sizeof(float);   // (+ the fused column sums)
+    const size_t sh = 2 * WG_TT * (nci == 1 ? WG_DY_STRIDE1 : WG_DY_STRIDE2) + 2 * XR * 64 * nci + 128 * sizeof(float);   // (+ the fused column sums)
     const unsigned grid = (unsigned)(a.n_cotiles * a.n_cichunks * a.nsplit);
     if (nci == 2) {
         hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 2>), dim3(grid), dim3(256), sh, stream, a);
