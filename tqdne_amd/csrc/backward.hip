@@ -134,6 +134,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         const int b = u / p.n_ttiles;
         const int t0 = (u % p.n_ttiles) * WG_TT;
         const float* dyb = p.dy + ((size_t)b * p.T_out) * p.C_out + co0;
+#ifdef TQ_ABL_NODY
+        if (u == u_begin)   // ablation (wrong numerics): the dy tile is loaded, split and stored for the first unit only
+#endif
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int task = tid + it * 256;
@@ -192,6 +195,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
             float* dst = cs_lds + 4 * (tid & 31);
             atomicAdd(dst, a4.x); atomicAdd(dst + 1, a4.y); atomicAdd(dst + 2, a4.z); atomicAdd(dst + 3, a4.w);
         }
+#ifdef TQ_ABL_NODY
+        if (u == u_begin)
+#endif
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int task = tid + it * 256;
