@@ -349,3 +349,31 @@ def test_dropout_mask_statistics_and_determinism():
     vals = torch.unique(y1)
     silu1 = float(torch.nn.functional.silu(torch.tensor(1.0)))
     assert len(vals) == 2 and abs(vals.max().item() - silu1 / 0.9) < 1e-4
+
+
+def test_pack_jobs_equals_one_pack_per_tensor():
+    """tq_pack_jobs (every re-pack of a plan in one launch) against tq_pack_conv_weight per tensor: same bytes, for every mode, odd
+    shapes (padding rows / channels), and the plain-copy jobs that gather the embedding projections"""
+    import torch
+    from tqdne_amd import _lib, engine, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    shapes = [((64, 64, 5), 0), ((256, 192, 5), 3), ((128, 128, 5), 2), ((96, 64, 3), 0), ((64, 3, 5), 0), ((256, 256, 1), 1),
+              ((768, 256, 1), 3), ((64, 128, 5), 1), ((32, 64, 3), 1), ((512, 256, 5), 3)]
+    ws, refs, outs, jobs = [], [], [], []
+    for (co, ci, k), mode in shapes:
+        w = torch.randn(co, ci, k, generator=g).to(dev)
+        ws.append(w)
+        refs.append(ops.pack_conv_weight(w, mode))
+        out = torch.zeros_like(refs[-1])
+        outs.append(out)
+        jobs.append((w.data_ptr(), out.data_ptr(), co, ci, k, mode))
+    src = torch.randn(1000, generator=g).to(dev)
+    dst = torch.zeros(1003, device=dev)
+    jobs.insert(4, (src.data_ptr(), dst.data_ptr() + 4 * 3, 1000, 0, 0, 4))     # a copy job in the middle of the table
+    engine.pack_batch(lib, dev, jobs, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    for (shape, mode), r, o in zip(shapes, refs, outs):
+        assert torch.equal(r, o), (shape, mode)
+    assert torch.equal(dst[3:], src) and float(dst[:3].abs().sum()) == 0.0
