@@ -34,6 +34,11 @@ def _p(t):
 FUSE_COLSUM = __import__("os").environ.get("TQDNE_FUSE_COLSUM", "0") != "0"
 
 
+# Weight-gradient launches on a second HIP stream next to the rest of the sweep (see BackwardPlan.run): measured -0.9 ms on the
+# 27 ms training step of the paper UNet at B = 64 (same box, twice).  TQDNE_BWD_STREAMS=1: everything on one stream.
+BWD_STREAMS = int(__import__("os").environ.get("TQDNE_BWD_STREAMS", "2"))
+
+
 def _nslots(T):
     return (T + STAT_SLOT - 1) // STAT_SLOT
 
@@ -439,6 +444,33 @@ class BackwardPlan:
                 self._trace.append((what, self.op_flops.get(i, 0), 0, a, _recorded_event()))
                 if rc:
                     check(rc, what)
+        elif BWD_STREAMS == 2:
+            # Weight gradients on a second stream: they only read (dy, forward activations) and write their own slice of the
+            # flat buffer, so the sweep's chain (data gradients, GroupNorm backward, column sums: half of it HBM-bound) does not
+            # have to wait for them.  Every gradient tensor a weight-gradient launch reads is a buffer of its own, never reused.
+            main_t = torch.cuda.current_stream(self.dev)
+            side = self.__dict__.get("_side")
+            if side is None:
+                side = self._side = torch.cuda.Stream(self.dev)
+                self._side_evs = {}
+            fire, late = self._fire_points(bucket_elems) if on_bucket is not None else ({}, ())
+            for i, (fn, args, what) in enumerate(self.ops):
+                if what.startswith("wgrad:"):
+                    ev = self._side_evs.get(i)
+                    if ev is None:
+                        ev = self._side_evs[i] = torch.cuda.Event()
+                    ev.record(main_t)
+                    side.wait_event(ev)
+                    rc = fn(*args, side.cuda_stream)
+                else:
+                    rc = fn(*args, stream)
+                if rc:
+                    check(rc, what)
+                if i in fire:
+                    main_t.wait_stream(side)   # (the exchange waits on the main stream only)
+                    for lo, hi in fire[i]:
+                        on_bucket(self.flat[lo:hi])
+            main_t.wait_stream(side)
         elif on_bucket is None:
             for fn, args, what in self.ops:
                 rc = fn(*args, stream)
