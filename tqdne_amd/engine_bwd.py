@@ -455,7 +455,7 @@ class BackwardPlan:
                 self._side_evs = {}
             fire, late = self._fire_points(bucket_elems) if on_bucket is not None else ({}, ())
             for i, (fn, args, what) in enumerate(self.ops):
-                if what.startswith("wgrad:"):
+                if what.startswith("wgrad:"):   # (the column sums on that stream too: measured equal)
                     ev = self._side_evs.get(i)
                     if ev is None:
                         ev = self._side_evs[i] = torch.cuda.Event()
