@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the device is touched: see tqdne_amd/__init__.py (4 lanes + RCCL's stream)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -147,3 +147,11 @@ def test_c_abi_argument_checks_return_error_codes_without_a_gpu():
     assert lib.tq_envelope_fwd(fake, fake, 2, 3, 100, 128, 1e-6, 1e-6, None) == -2   # window longer than the signal
     assert lib.tq_adam_ema_step(None, 3, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0.0, 1.0, 1.0, None) == -1
     assert lib.tq_conv_weight_pack_bytes(256, 256, 5, 0) == lib.tq_conv_weight_pack_bytes(256, 256, 5, 2) > 0
+
+
+def test_hardware_queue_default_is_set_before_the_device_is_touched():
+    """four sampler lanes + any other live stream (RCCL's, the backward plan's) need more than ROCm's default of 4 hardware queues:
+    tools/hwq_probe.py measured 163.9 -> 227.2 ms for the 18-step sample with one extra stream (tqdne_amd/__init__.py)"""
+    import os
+    import tqdne_amd  # noqa: F401
+    assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 8

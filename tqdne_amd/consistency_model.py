@@ -129,12 +129,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         return out
 
     def _side_stream(self, dev, i):
-        key = ("side_stream", str(dev), i)
-        s = self._scal.get(key)
-        if s is None:
-            s = torch.cuda.Stream(device=dev)
-            self._scal[key] = s
-        return s
+        return engine.side_stream(dev, i)   # (one pool per process, see engine.side_stream)
 
     @torch.no_grad()
     def sample(self, shape, sigmas=[1.0], cond_sample=None, cond=None):

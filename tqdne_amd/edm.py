@@ -332,12 +332,7 @@ class LightningEDM(LightningModule):
         return out
 
     def _side_stream(self, dev, i=1):
-        key = ("side_stream", str(dev), i)
-        s = self._scal.get(key)
-        if s is None:
-            s = th.cuda.Stream(device=dev)
-            self._scal[key] = s
-        return s
+        return engine.side_stream(dev, i)   # (one pool per process: the number of live streams matters, see engine.side_stream)
 
     def _heun_lane(self, eps, sigmas, cond_sample, cond, use_graph):
         """The Heun integration of one (half) batch as a resumable object: ``advance()`` enqueues one sampler step on the current

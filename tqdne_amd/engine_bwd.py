@@ -449,9 +449,9 @@ class BackwardPlan:
             # flat buffer, so the sweep's chain (data gradients, GroupNorm backward, column sums: half of it HBM-bound) does not
             # have to wait for them.  Every gradient tensor a weight-gradient launch reads is a buffer of its own, never reused.
             main_t = torch.cuda.current_stream(self.dev)
-            side = self.__dict__.get("_side")
-            if side is None:
-                side = self._side = torch.cuda.Stream(self.dev)
+            from .engine import side_stream
+            side = side_stream(self.dev, 1)   # (the sampler lanes' pool: a stream of its own would be one hardware queue too many)
+            if self.__dict__.get("_side_evs") is None:
                 self._side_evs = {}
             fire, late = self._fire_points(bucket_elems) if on_bucket is not None else ({}, ())
             for i, (fn, args, what) in enumerate(self.ops):
