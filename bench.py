@@ -90,7 +90,20 @@ def conv_flops_per_sample(unet, T):
     return total
 
 
-def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads, reps):
+def parity_inputs(cfg, B, T):
+    """Inputs of the same-run parity gate: drawn from a seeded CPU generator, so the GPU
+    process and the CPU-oracle child build bit-identical tensors without exchanging them."""
+    g = torch.Generator().manual_seed(4242)
+    d = dict(signal=0.5 * torch.randn(B, 3, T, generator=g),
+             cond=torch.randn(B, 5, generator=g) if cfg.get("cond_features") else None,
+             sigma=torch.tensor([0.02, 0.5, 5.0, 60.0] * ((B + 3) // 4))[:B],
+             eps=torch.randn(B, generator=g), noise=torch.randn(B, 3, T, generator=g),
+             start=torch.randn(B, 3, T, generator=g, dtype=torch.float64))
+    d["noisy"] = d["signal"] + d["sigma"][:, None, None] * d["noise"]
+    return d
+
+
+def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads, reps, parity_path=None):
     """Runs in a child process: time the CPU oracle (oracle/ = our PyTorch-CPU restatement, a "port") on a bounded
     sample of the same workload: full train steps (fwd + bwd + Adam) and 18-step samples at batch B; one untimed warm-up of
     each half (a train step and a 2-step sample), then ``reps`` timed repetitions, printed one JSON line each."""
@@ -120,8 +133,20 @@ def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads, reps):
         with torch.no_grad():
             OE.sample_deterministic(p, net, torch.randn(B, 3, T, generator=g, dtype=torch.float64), n, cond=cond)
 
-    train()
-    sample(2)
+    if parity_path:
+        # same-run parity gate: the oracle's denoiser output, loss (dropout off) and full sample for the injected inputs, on the
+        # INITIAL weights (before the first optimizer step below); doubles as the warm-up of the sampling half
+        import numpy as np
+        pin = parity_inputs(cfg, B, T)
+        with torch.no_grad():
+            den = OE.denoise(p, net, pin["noisy"], pin["sigma"], cond=pin["cond"])
+            lss = OE.loss_step(p, net, pin["signal"], pin["eps"], pin["noise"], cond=pin["cond"])
+            smp = OE.sample_deterministic(p, net, pin["start"], nsample_steps, cond=pin["cond"])
+        np.savez(parity_path, denoise=den.numpy(), loss=lss.numpy(), sample=smp.numpy())
+        train()
+    else:
+        train()
+        sample(2)
     print(json.dumps(dict(stage="warm")), flush=True)
     for r in range(reps):
         t0 = time.perf_counter()
@@ -143,10 +168,10 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def _cpu_run(cfg_name, B, T, nsample_steps, seed, nthreads, reps, timeout_s):
+def _cpu_run(cfg_name, B, T, nsample_steps, seed, nthreads, reps, timeout_s, parity_path=None):
     import subprocess
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
-            f"bench._cpu_baseline_worker({cfg_name!r}, {B}, {T}, {nsample_steps}, {seed}, {nthreads}, {reps})")
+            f"bench._cpu_baseline_worker({cfg_name!r}, {B}, {T}, {nsample_steps}, {seed}, {nthreads}, {reps}, {parity_path!r})")
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(nthreads))
     try:
         r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
@@ -164,7 +189,7 @@ def _median(v):
     return None if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
 
 
-def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=150):
+def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=150, parity_path=None):
     """The CPU oracle on the host cores of this box: all cores (<= 64 threads), warm-up + median of 3
     repetitions of the same workload at batch B, and a 1-thread line at batch 1 (one repetition after the warm-up; a
     1-thread step of the paper UNet takes ~10 s per waveform).  Each leg runs in a subprocess with a hard timeout."""
@@ -173,7 +198,7 @@ def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=150):
     except Exception:
         ncores = os.cpu_count() or 1
     nthreads = max(1, min(ncores, 64))
-    reps = _cpu_run(cfg_name, B, T, nsample_steps, seed, nthreads, 3, timeout_s)
+    reps = _cpu_run(cfg_name, B, T, nsample_steps, seed, nthreads, 3, timeout_s + (60 if parity_path else 0), parity_path)
     t_train, t_sample = _median([r["t_train"] for r in reps]), _median([r["t_sample"] for r in reps])
     res = dict(value=None, unit="waveforms/s", cores=nthreads, kind="port", train_s=t_train, sample_s=t_sample, reps=len(reps),
                sample=f"{cfg_name} UNet, B={B}, 3x{T}: warm-up, then median of {len(reps)} x (1 train step + 1 x {nsample_steps}-step "
@@ -190,6 +215,32 @@ def cpu_baseline(cfg_name, B, T, nsample_steps, seed, timeout_s=150):
     else:
         res["one_thread"] = dict(value=None, sample=f"B=1, 1 thread: did not finish within {timeout_s} s")
     return res
+
+
+def parity_block(gpu, cpu_path, args):
+    """The same-run parity gate of the bench line: HIP path vs the CPU oracle (child process of this run) on identical injected
+    inputs and the initial weights; both of SURVEY 8c(4)'s metrics per checkpoint, bar 1e-3."""
+    import numpy as np
+    blk = dict(reference="oracle/ (CPU restatement pinned to the reference by tests/golden), run in this bench's CPU child",
+               inputs=f"{args.config} UNet, initial weights, B={args.cpu_batch}, 3x{args.length}, seeded (bench.parity_inputs)",
+               tolerance=1e-3, checkpoints={}, **{"pass": None})
+    if not (cpu_path and os.path.exists(cpu_path)):
+        blk["error"] = "the CPU oracle child did not deliver its outputs (timeout?)"
+        return blk
+    z = np.load(cpu_path)
+    ok = True
+    names = {"denoise": "LightningEDM.forward, sigma in {0.02, 0.5, 5, 60}", "loss": "EDM loss (dropout off)",
+             "sample": f"{args.sample_steps}-step Heun sample ({2 * args.sample_steps - 1} NFE)"}
+    for k in ("denoise", "loss", "sample"):
+        a, b = gpu[k].double().reshape(-1), torch.from_numpy(z[k]).double().reshape(-1)
+        d = (a - b).abs()
+        norm = float(d.max() / b.abs().max().clamp_min(1e-30))
+        rms = b.pow(2).mean().sqrt().clamp_min(1e-30)
+        elem = float((d / (b.abs() + rms)).max())
+        blk["checkpoints"][k] = dict(what=names[k], max_rel=norm, allclose_rtol_atol_rms=elem)
+        ok = ok and norm < 1e-3 and elem <= 1e-3
+    blk["pass"] = bool(ok)
+    return blk
 
 
 def log(*a):
@@ -275,6 +326,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="= --mode sample")
     ap.add_argument("--no-sample", action="store_true", help="= --mode train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the same-run parity gate (it rides in the CPU-baseline child)")
     ap.add_argument("--no-tables", action="store_true", help="skip the per-class traced passes after the timed region")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gradient all-reduce after the backward instead of under it")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -337,6 +389,22 @@ def main():
         batch["cond"] = cond
     start_noise = torch.randn(B, 3, T, generator=g, dtype=torch.float64).to(dev)
 
+    # same-run parity gate, GPU half: the HIP path on the injected inputs, on the initial weights, outside the timed region
+    # (the CPU oracle child computes the other half at the end; compared in the JSON line's "parity" block)
+    gpu_parity = None
+    want_parity = rank == 0 and world == 1 and cm is None and not args.no_cpu_baseline and not args.no_parity
+    if want_parity:
+        pin = parity_inputs(cfg, args.cpu_batch, T)
+        pd = {k: (None if v is None else v.to(dev)) for k, v in pin.items()}
+        edm.eval()
+        with torch.no_grad():
+            den = edm(pd["noisy"], pd["sigma"], None, pd["cond"]).cpu()
+            lss = edm.step_with_noise(pd["signal"], pd["eps"], pd["noise"], cond=pd["cond"]).cpu()
+            psig = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
+            smp = edm.sample_deterministically(pd["start"] * psig[0], psig, None, pd["cond"]).cpu()
+        gpu_parity = dict(denoise=den, loss=lss, sample=smp)
+        del pd
+
     trainer = DataParallelTrainer(edm, world_size=world, overlap=not args.no_overlap) if do_train else None
     sigmas = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
     eps0 = start_noise * sigmas[0]
@@ -385,10 +453,21 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    dt_rank = dt
+    rank_ms = [1e3 * dt_rank / args.steps]
+    rccl_ranks = 1
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # self-evidence of the collective: a ones tensor summed over RCCL counts the ranks that took part, and every rank's own
+        # time per step is gathered (the headline uses the MAX, as the contract asks)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        allr = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allr, torch.tensor([1e3 * dt_rank / args.steps], device=dev, dtype=torch.float64))
+        rank_ms = [float(t.item()) for t in allr]
     ms_per_step = 1e3 * dt / args.steps
     log(f"timed region done: {ms_per_step:.1f} ms/step")
     value = world * B / (dt / args.steps)
@@ -406,6 +485,31 @@ def main():
             sync()
             ts.append(1e3 * (time.perf_counter() - t1))
         parts[name + "_ms"] = _median(ts)
+
+    # exposed (non-overlapped) part of the gradient exchange, same run: train half with the all-reduce issued after the backward
+    # minus the train half as benchmarked (issued from inside the sweep).  World 1: the exchange is a no-op, reported as 0.
+    exchange = None
+    if do_train and cm is None:
+        exchange = dict(rccl_ranks=rccl_ranks, overlap=not args.no_overlap, bucket_bytes=4 * getattr(trainer, "bucket_elems", 0))
+        if world > 1 and not args.no_overlap:
+            def med_train():
+                train_half(); sync()
+                ts = []
+                for _ in range(5):
+                    t1 = time.perf_counter()
+                    train_half()
+                    sync()
+                    ts.append(1e3 * (time.perf_counter() - t1))
+                return _median(ts)
+            trainer.overlap = False
+            t_after = med_train()
+            trainer.overlap = True
+            tt = torch.tensor([t_after, parts.get("train_ms", 0.0)], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            exchange.update(train_ms_exchange_after_backward=float(tt[0]), train_ms_exchange_under_backward=float(tt[1]),
+                            hidden_by_overlap_ms=float(tt[0] - tt[1]))
+        else:
+            exchange.update(hidden_by_overlap_ms=0.0 if world == 1 else None)
 
     tables = None
     if rank == 0 and not args.no_tables and cm is None:
@@ -512,6 +616,8 @@ def main():
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}",
                        "hip_graph": use_graph, "sampler_lanes": 1 if use_graph else sampler_lanes(B), "mode": args.mode},
             "parts": parts,
+            "rccl_ranks": rccl_ranks, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
+            "gradient_exchange": exchange,
             "whole_step_algorithmic_tflops": work_flop / (dt / args.steps) / 1e12,
             "whole_step_mfma_frac": work_flop / (dt / args.steps) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
             "roofline": roofline,
@@ -527,7 +633,11 @@ def main():
             out["metric"] += " [DEBUG: partial workload, not the headline metric]"
         if not args.no_cpu_baseline and world == 1 and cm is None:  # (a reported baseline of the same workload: rank 0 at N = 1 only)
             log("timing the CPU oracle (bounded sample, subprocess) ...")
-            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, T, args.sample_steps, 99)
+            import tempfile
+            ppath = os.path.join(tempfile.mkdtemp(prefix="tqdne_parity_"), "cpu.npz") if gpu_parity is not None else None
+            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, T, args.sample_steps, 99, parity_path=ppath)
+            if gpu_parity is not None:
+                out["parity"] = parity_block(gpu_parity, ppath, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -25,7 +25,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define TQ_ABI_VERSION 2
+#define TQ_ABI_VERSION 3
 
 #define TQ_ERR_ARG (-1)   /* null / inconsistent pointer arguments */
 #define TQ_ERR_SHAPE (-2) /* unsupported shape */
@@ -321,6 +321,13 @@ typedef struct TqAdamChunk {
 } TqAdamChunk;
 int tq_adam_ema_step(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2, double eps,
                      double inv_bias2_sqrt, double ema_weight, double grad_scale, double decay_factor, hipStream_t stream);
+/* ABI 3: the same update behind a DEVICE-side predicate: when `*skip_flag != 0` at execution time the launch leaves parameters,
+ * moments and EMA untouched.  The data-parallel trainer passes the range-guard flag of the fp16-range forward scheme
+ * (TqConvDesc.range_flag, max-reduced over the ranks): a step whose forward came close to the fp16 range is dropped on the device,
+ * without a host synchronisation, before the host has seen the flag and moved the plan to bf16x3.  NULL: unconditional. */
+int tq_adam_ema_step_guarded(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2, double eps,
+                             double inv_bias2_sqrt, double ema_weight, double grad_scale, double decay_factor,
+                             const int32_t* skip_flag, hipStream_t stream);
 
 /* ---- signal representation either side of the path (representation.py:41-60, MovingAverageEnvelope) ------- */
 /* x (N, C, T) fp32 NCW -> out (N, 2C, T) fp32: channels [0, C) = x / (env + eps), [C, 2C) = log(env + log_eps) - log(log_eps)/2,

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import grad_err, rel_err
 from test_hip_unet import perturbed_state
 
 pytestmark = pytest.mark.gpu
@@ -242,7 +242,7 @@ def test_dropout_on_training_step_vs_oracle(which, B, T):
         if not q.requires_grad:
             continue
         ref = params["unet." + name].grad
-        e = float((q.grad.cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-3 * gmax))
+        e = grad_err(q.grad, ref, gmax, name)
         if e > worst:
             worst, wname = e, name
     print(f"{which}: dropout {p} ON, masks rebuilt from the hash (kept {kept:.4f}): loss rel err {e_loss:.2e}; worst gradient rel err "
@@ -277,6 +277,39 @@ def test_edm_forward_is_differentiable_like_the_reference():
     for name, q in edm.unet.named_parameters():
         if q.requires_grad:
             ref = params["unet." + name].grad
-            worst = max(worst, float((q.grad.cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-3 * gmax)))
+            worst = max(worst, grad_err(q.grad, ref, gmax, name))
     print(f"differentiable forward: worst gradient rel err {worst:.2e}")
     assert worst < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------- (vi)
+def test_paper_config_consistency_sampling_b64_vs_oracle():
+    """BASELINE configs[4]: consistency-model sampling on the paper UNet at the bench batch (B = 64, 3 x 4096), the 1-step
+    sampler and one refinement step (consistency_model.py:63-106) -- samples {0, 17, 33, 63} vs the CPU oracle."""
+    from oracle import consistency as OC
+    from oracle import unet as OU
+    from tqdne_amd import LithningConsistencyModel, UNetModel, paper_1d_unet_config
+    cfg = paper_1d_unet_config()
+    torch.manual_seed(0)
+    net = UNetModel(**cfg)
+    sd = perturbed_state(net, 29)
+    net.load_state_dict(sd)
+    cm = LithningConsistencyModel(net).to(dev()).eval()
+    B, T = 64, 4096
+    g = torch.Generator().manual_seed(4321)
+    start = torch.randn(B, 3, T, generator=g)
+    cond = torch.randn(B, 5, generator=g)
+    uni = torch.rand(B, 3, T, generator=g)
+    y1 = cm.sample_from(start.to(dev()), [], [], cond=cond.to(dev()))
+    y2 = cm.sample_from(start.to(dev()), [1.0], [uni.to(dev())], cond=cond.to(dev()))
+    pick = [0, 17, 33, 63]
+    onet = lambda x, t, c: OU.unet_forward(sd, cfg, x, t, c)
+    with torch.no_grad():
+        r1 = OC.sample(onet, start[pick], cond=cond[pick])
+        r2 = OC.sample(onet, start[pick], [1.0], [uni[pick]], cond=cond[pick])
+    e1, e2 = rel_err(y1[pick].cpu(), r1), rel_err(y2[pick].cpu(), r2)
+    print(f"paper UNet, B=64, consistency sampling, samples {pick} vs oracle: 1-step {e1:.2e}, with one refinement step {e2:.2e}")
+    assert e1 < TOL and e2 < TOL
+    # batch independence at the bench batch: the same four waveforms sampled alone must be bit-identical
+    y1p = cm.sample_from(start[pick].to(dev()), [], [], cond=cond[pick].to(dev()))
+    assert torch.equal(y1p, y1[pick]), "a sample must not depend on what else is in the batch"

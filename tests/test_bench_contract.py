@@ -41,6 +41,14 @@ def test_bench_json_contract_tiny_config():
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and c["one_thread"]["cores"] == 1
     assert set(d["kernel_classes"]) >= {"inference_forward_1lane", "train_forward", "train_backward"}
+    # same-run parity gate: HIP path vs the CPU oracle child on identical injected inputs, both metrics per checkpoint
+    par = d["parity"]
+    assert par["pass"] is True and par["tolerance"] == 1e-3 and set(par["checkpoints"]) == {"denoise", "loss", "sample"}
+    for c in par["checkpoints"].values():
+        assert 0 <= c["max_rel"] < 1e-3 and 0 <= c["allclose_rtol_atol_rms"] <= 1e-3
+    # self-evidence of the collective path (a ones tensor summed over RCCL when N > 1), per-rank times, exchange exposure
+    assert d["rccl_ranks"] == 1 and d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] and len(d["rank_ms_per_step"]["all"]) == 1
+    assert d["gradient_exchange"]["rccl_ranks"] == 1 and d["gradient_exchange"]["hidden_by_overlap_ms"] == 0.0
 
 
 @pytest.mark.timeout(600)

@@ -113,3 +113,32 @@ def test_checkpoint_with_a_foreign_global_is_refused(tmp_path):
     with pytest.raises(pickle.UnpicklingError, match="allow-list"):
         load_checkpoint(path)
     assert not (tmp_path / "pwned").exists()
+
+
+def test_checkpoint_cannot_reach_an_unrestricted_unpickler(tmp_path):
+    """torch.storage._load_from_bytes is torch.load(weights_only=False) on a bytes argument: a payload nested through it
+    would bypass the allow-list, so the function itself is not on it."""
+    import pickle
+
+    from tqdne_amd.checkpoint import _SAFE_GLOBALS, load_checkpoint
+
+    assert ("torch.storage", "_load_from_bytes") not in _SAFE_GLOBALS
+    marker = tmp_path / "pwned2"
+
+    class Inner:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > %s" % marker,))
+
+    inner = io.BytesIO()
+    torch.save({"x": Inner()}, inner)  # a complete, unrestricted torch pickle
+
+    class Outer:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (inner.getvalue(),))
+
+    path = tmp_path / "nested.ckpt"
+    torch.save({"state_dict": {}, "hyper_parameters": {"x": Outer()}}, path)
+    with pytest.raises(pickle.UnpicklingError, match="allow-list"):
+        load_checkpoint(path)
+    assert not marker.exists()

@@ -23,6 +23,7 @@ PACK_MODE = {TQ_WFMT_BF16X3: 0, TQ_WFMT_F16_MX8: 2, TQ_WFMT_F16_MX6: 3}   # tq_p
 
 
 DEFAULT_SCHEME = "f16mx6"
+ABI_VERSION = 3   # include/tqdne_hip.h TQ_ABI_VERSION
 
 
 def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False) -> int:
@@ -117,6 +118,7 @@ _PROTOS = {
     "tq_envelope_fwd": (I, [VP, VP, I, I, I, I, C.c_double, C.c_double, VP]),
     "tq_envelope_inv": (I, [VP, VP, I, I, I, C.c_double, C.c_double, VP]),
     "tq_adam_ema_step": (I, [VP, I] + [C.c_double] * 8 + [VP]),
+    "tq_adam_ema_step_guarded": (I, [VP, I] + [C.c_double] * 8 + [VP, VP]),
     "tq_conv1d_bwd_data": (I, [VP] * 11),
     "tq_conv1d_bwd_weight_workspace": (SZ, [VP]),
     "tq_conv1d_bwd_weight": (I, [VP] * 8 + [SZ, VP]),
@@ -165,7 +167,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-    if lib.tq_abi_version() != 2:
+    if lib.tq_abi_version() != ABI_VERSION:
         raise RuntimeError("libtqdne_hip.so ABI version mismatch")
     _LIB = lib
     return lib

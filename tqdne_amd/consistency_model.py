@@ -92,7 +92,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         return eng.forward(sample, sigma, cond, in_scale=None, c_out=sc[0], c_skip=sc[1], skip_src=sample, train=train,
                            dropout_seed=dropout_seed, infer=infer)
 
-    def forward(self, sample, sigma, cond_sample=None, cond=None):
+    def forward(self, sample, sigma, cond_sample=None, cond=None, _check_range=True):
         """consistency_model.py:63-79."""
         engine.require_device(sample)
         if cond_sample is not None:
@@ -107,7 +107,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         if lanes < 2:
             infer = not torch.is_grad_enabled()
             y = self._forward_static(sample, sigma, cond, infer=infer).clone()
-            if infer and self.net._engine(B, sample.shape[2], sample.device, 0).check_range():
+            if infer and _check_range and self.net._engine(B, sample.shape[2], sample.device, 0).check_range():
                 y = self._forward_static(sample, sigma, cond, infer=infer).clone()  # (the plan is on bf16x3 now)
             return y
         # independent samples: sub-batches on separate HIP streams run out of phase (see LightningEDM.sample_deterministically)
@@ -139,12 +139,20 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
 
     @torch.no_grad()
     def sample_from(self, epsilon, sigmas, uniform_noises, cond_sample=None, cond=None):
-        ones = torch.ones(epsilon.shape[0], device=epsilon.device)
-        sample = self(epsilon, ones * self.sigma_max, cond_sample, cond)
-        for sigma, u in zip(sigmas, uniform_noises):
-            sample = sample + u * sigma
-            sample = self(sample, ones * sigma, cond_sample, cond)
-        return sample
+        def run():
+            ones = torch.ones(epsilon.shape[0], device=epsilon.device)
+            sample = self(epsilon, ones * self.sigma_max, cond_sample, cond, _check_range=False)
+            for sigma, u in zip(sigmas, uniform_noises):
+                sample = sample + u * sigma
+                sample = self(sample, ones * sigma, cond_sample, cond, _check_range=False)
+            return sample
+        out = run()
+        # range guard of the fp16-range conv scheme: ONE flag read per sample call (as the EDM samplers do), not one per network
+        # evaluation; if a tensor came near the fp16 range the plans are on bf16x3 now and the sampling is repeated
+        eng = self.net._engine(epsilon.shape[0], epsilon.shape[2], epsilon.device, 0)
+        if eng.check_range():
+            out = run()
+        return out
 
     # ------------------------------------------------------------------ iCT training (consistency_model.py:115-190)
     def _schedule(self):

@@ -99,6 +99,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
             gshift[(size_t)b * C + c] = bet[k] - mean * a;
         }
     }
+    for (int c = threadIdx.x + 512; c < C; c += 256) {   // wider (concatenated) tensors than the paper configs have: plain loop
+        const int g = c / G;
+        const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
+        const float a = gamma[c] * rstd;
+        gscale[(size_t)b * C + c] = a;
+        gshift[(size_t)b * C + c] = beta[c] - mean * a;
+    }
 }
 }  // namespace
 
@@ -106,7 +113,7 @@ extern "C" int tq_gn_finalize(const float* stats0, int C0, const float* stats1, 
                               const float* beta, float* gscale, float* gshift, float* mean_rstd, hipStream_t stream) {
     if (!stats0 || !gamma || !beta || !gscale || !gshift || (C1 > 0 && !stats1)) return TQ_ERR_ARG;
     const int C = C0 + C1;
-    if (B <= 0 || T <= 0 || C <= 0 || C % GN_GROUPS || C > 512) return TQ_ERR_SHAPE;  // (two channels per thread in the last step)
+    if (B <= 0 || T <= 0 || C <= 0 || C % GN_GROUPS || C > 3840) return TQ_ERR_SHAPE;  // (LDS: 16 C + 512 bytes <= 64 KB)
     const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
     const size_t shbytes = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(double);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), shbytes, stream, stats0, C0, stats1, C1, T, nslots, gamma,
@@ -877,7 +884,8 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 
 __global__ __launch_bounds__(256) void adam_ema_kernel(const TqAdamChunk* __restrict__ chunks, float step_size, float omb1, float b2,
                                                        float omb2, float eps, float ibc2, float ema_w, float gscale,
-                                                       float decay) {
+                                                       float decay, const int* __restrict__ skip_flag) {
+    if (skip_flag && *skip_flag != 0) return;   // (uniform scalar load: the whole launch drops out together)
     const TqAdamChunk c = chunks[blockIdx.x];
     const int n4 = c.n & ~3;
     for (int i = threadIdx.x * 4; i < n4; i += 256 * 4) {
@@ -909,16 +917,23 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(const TqAdamChunk* __rest
 }
 }  // namespace
 
-extern "C" int tq_adam_ema_step(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2, double eps,
-                                double inv_bias2_sqrt, double ema_weight, double grad_scale, double decay_factor,
-                                hipStream_t stream) {
+extern "C" int tq_adam_ema_step_guarded(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2,
+                                        double eps, double inv_bias2_sqrt, double ema_weight, double grad_scale,
+                                        double decay_factor, const int32_t* skip_flag, hipStream_t stream) {
     if (!chunks || n_chunks < 0) return TQ_ERR_ARG;
     if (n_chunks == 0) return 0;
     hipLaunchKernelGGL(adam_ema_kernel, dim3(n_chunks), dim3(256), 0, stream, chunks, (float)step_size, (float)(1.0 - beta1),
                        (float)beta2, (float)(1.0 - beta2), (float)eps, (float)inv_bias2_sqrt, (float)ema_weight, (float)grad_scale,
-                       (float)decay_factor);
+                       (float)decay_factor, reinterpret_cast<const int*>(skip_flag));
     TQ_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int tq_adam_ema_step(const TqAdamChunk* chunks, int n_chunks, double step_size, double beta1, double beta2, double eps,
+                                double inv_bias2_sqrt, double ema_weight, double grad_scale, double decay_factor,
+                                hipStream_t stream) {
+    return tq_adam_ema_step_guarded(chunks, n_chunks, step_size, beta1, beta2, eps, inv_bias2_sqrt, ema_weight, grad_scale,
+                                    decay_factor, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -282,7 +282,9 @@ class LightningEDM(LightningModule):
         out = self._sample_det(eps, sigmas, cond_sample, cond, use_graph, lanes)
         # range guard of the fp16-range conv scheme: one flag read per sample call; if a tensor came near the fp16 range the plans
         # have been moved to bf16x3 and the integration is repeated
-        if any(e.check_range() for e in list(self.unet._engine_cache.values())):
+        # (the flag is one per model and device, shared by every lane's plan: one read)
+        engs = [e for e in self.unet._engine_cache.values() if e.dev == eps.device]
+        if engs and engs[0].check_range():
             out = self._sample_det(eps, sigmas, cond_sample, cond, use_graph, lanes)
         return out
 

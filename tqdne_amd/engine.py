@@ -97,7 +97,9 @@ def pack_batch(lib, dev, jobs, stream, capturing=False):
         return
     key = (str(dev), tuple(jobs))
     ent = _PACK_TABLES.get(key)
-    if ent is None and (capturing or not PACK_BATCH or len(jobs) < 2):
+    # (tables are never evicted: a launch queued on another stream may still read one, and the caching allocator would hand its
+    # block to the next allocation; they are ~40 bytes per job, and past 4096 distinct lists new ones run as per-tensor launches)
+    if ent is None and (capturing or not PACK_BATCH or len(jobs) < 2 or len(_PACK_TABLES) >= 4096):
         ent = False
     if ent is None:
         arr = (_lib.TqPackJob * len(jobs))()
@@ -109,8 +111,6 @@ def pack_batch(lib, dev, jobs, stream, capturing=False):
                 raise ValueError(f"bad pack job {(co, ci, k, mode)}")
             total += nb
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        if len(_PACK_TABLES) > 64:
-            _PACK_TABLES.clear()
         ent = _PACK_TABLES[key] = (table, len(jobs), total)
     if ent is False:
         for src, dst, co, ci, k, mode in jobs:
@@ -198,6 +198,26 @@ def _recorded_event():
     return e
 
 
+def _check_head_limits(C_in: int, C_out: int, k: int):
+    """The limits of tq_head_conv_fwd (csrc/small_ops.hip), checked when the plan is built so that an unsupported model fails
+    at construction with a message rather than at its first forward with TQ_ERR_SHAPE."""
+    maxco = 4 if C_out <= 4 else 16
+    lds = 4 * (C_in * k * maxco + (128 + k - 1) * k * maxco)
+    if C_in < 16 or C_in % 16 or C_in > 128 or not (1 <= C_out <= 16) or k not in (1, 3, 5) or lds > 64 * 1024:
+        raise NotImplementedError(
+            f"output conv {C_in} -> {C_out} channels, k = {k}: the HIP head kernel takes 16 | C_in <= 128, C_out <= 16, k in (1, 3, 5) "
+            f"and <= 64 KB of LDS (this shape: {lds} bytes)")
+
+
+def shared_range_flag(model, device) -> torch.Tensor:
+    """The model's range-guard flag on ``device`` (int32[1]); created on first use."""
+    flags = model.__dict__.setdefault("_range_flags", {})
+    key = str(device)
+    if key not in flags:
+        flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return flags[key]
+
+
 class Probe:
     """HIP-event timings of one op of the plan (events are recorded on the stream the kernel is launched on)."""
 
@@ -233,7 +253,9 @@ class UNetEngine:
         self.scheme = "auto"
         self.plan_epoch = 0
         self._wfmt_sites = []               # (descriptor, [conv sites packed for it], preferred wfmt)
-        self.range_flag = torch.zeros(1, dtype=torch.int32, device=device)   # set by the conv epilogues (TqConvDesc.range_flag)
+        # set by the conv epilogues (TqConvDesc.range_flag); ONE flag per model and device, shared by every plan of the model (any
+        # batch, length, lane): the optimizer launch of the trainer is predicated on it (tq_adam_ema_step_guarded)
+        self.range_flag = shared_range_flag(model, device)
         self._range_host = torch.zeros(1, dtype=torch.int32).pin_memory() if device.type == "cuda" else torch.zeros(1, dtype=torch.int32)
         self._range_evt = None
         self._trace = None                  # list: HIP-event pairs around EVERY launch of the next forwards (measurement only)
@@ -485,6 +507,7 @@ class UNetEngine:
             skip = hs.pop()
             h = run_layers(blk, (h, skip), f"output_blocks.{i}")
         self.final = h
+        _check_head_limits(h.C, m.out[2].out_channels, m.out[2].kernel_size[0])
         self.head_gn = self._gn([h], m.out[0])
         self.out_nct = self._empty(B, m.out_channels, T)
 

@@ -437,13 +437,18 @@ class BackwardPlan:
             self.stem_x_btc[:, :, :cin].copy_(xs.permute(0, 2, 1))
         if self._trace is not None:
             from .engine import _recorded_event
-            late = ()
+            # (a traced pass still hands every bucket to the gradient exchange: a trainer that traces must not step on
+            # un-reduced gradients)
+            fire, late = self._fire_points(bucket_elems) if on_bucket is not None else ({}, ())
             for i, (fn, args, what) in enumerate(self.ops):
                 a = _recorded_event()
                 rc = fn(*args, stream)
                 self._trace.append((what, self.op_flops.get(i, 0), 0, a, _recorded_event()))
                 if rc:
                     check(rc, what)
+                if i in fire:
+                    for lo, hi in fire[i]:
+                        on_bucket(self.flat[lo:hi])
         elif BWD_STREAMS == 2:
             # Weight gradients on a second stream: they only read (dy, forward activations) and write their own slice of the
             # flat buffer, so the sweep's chain (data gradients, GroupNorm backward, column sums: half of it HBM-bound) does not

@@ -99,7 +99,9 @@ class FusedAdamEMA(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, skip_flag: Optional[torch.Tensor] = None):
+        """``skip_flag``: device int32 tensor; when it is non-zero at execution time the launch changes nothing (the range guard
+        of the fp16-range forward scheme, see tq_adam_ema_step_guarded) -- decided on the device, no host synchronisation."""
         loss = closure() if closure is not None else None
         key = self._key()
         if key != self._table_key:
@@ -113,8 +115,9 @@ class FusedAdamEMA(torch.optim.Optimizer):
         ibc2 = 1.0 / math.sqrt(1.0 - b2 ** t)
         ema_w = 0.0 if self.ema_decay is None else 1.0 - self.ema_decay
         stream = torch.cuda.current_stream(self._m.device).cuda_stream
-        check(self._lib.tq_adam_ema_step(self._table.data_ptr(), self._n_chunks, step_size, b1, b2, g["eps"], ibc2, ema_w,
-                                         grad_scale, 1.0 - g["lr"] * g["weight_decay"], stream), "adam")
+        check(self._lib.tq_adam_ema_step_guarded(self._table.data_ptr(), self._n_chunks, step_size, b1, b2, g["eps"], ibc2, ema_w,
+                                                 grad_scale, 1.0 - g["lr"] * g["weight_decay"],
+                                                 None if skip_flag is None else skip_flag.data_ptr(), stream), "adam")
         # the kernel wrote the parameters through raw pointers: bump their autograd version counters so that everything keyed
         # on ``p._version`` (the engines' packed MFMA weight fragments, engine.py repack / repack_transposed) sees the update
         torch._C._increment_version(self._updated)

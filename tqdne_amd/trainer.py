@@ -117,11 +117,12 @@ class DataParallelTrainer:
                 for i in range(0, f1.numel(), self.bucket_elems):
                     self.last_bucket_sizes.append(min(self.bucket_elems, f1.numel() - i))
                     works.append(self._allreduce_async(f1[i:i + self.bucket_elems]))
+        skip = self._range_skip_flag()
         for w in works:   # (NCCL: makes the current stream wait for the exchange; the host does not block)
             w.wait()
         if self.fused:
             # the 1 / world_size of the gradient mean rides in the optimizer launch
-            self.optimizer.step(grad_scale=1.0 / self.world)
+            self.optimizer.step(grad_scale=1.0 / self.world, skip_flag=skip)
         else:
             if self.world > 1:
                 flats = list(flat) if isinstance(flat, (list, tuple)) else [flat]
@@ -134,6 +135,31 @@ class DataParallelTrainer:
                     torch._foreach_lerp_(tuple(self._ema.values()), tuple(named[n] for n in self._ema), 1 - self.ema_decay)
         self.scheduler.step()
         return loss
+
+    def _range_skip_flag(self):
+        """Device predicate of the optimizer launch (fused optimizer only): the range-guard flag of the fp16-range forward scheme.
+        The host learns of a raised flag one or more steps late (engine._range_poll does not synchronise), so the step whose
+        forward raised it -- activations within a factor two of the fp16 range, possibly inf / NaN gradients -- is dropped ON
+        THE DEVICE, and so is every later step until the host has moved the plans to bf16x3.  With several ranks the flag is
+        max-reduced first (a rank that skipped alone would leave the replicas different); a rank already on bf16x3 contributes 0
+        (its kernels still raise the flag for large activations, which that scheme handles)."""
+        unet = getattr(self.module, "unet", None)
+        if not self.fused or unet is None or getattr(unet, "dims", 1) != 1:
+            return None
+        dev = next(self.module.parameters()).device
+        from .engine import shared_range_flag
+        flag = shared_range_flag(unet, dev)
+        auto = getattr(unet, "_conv_scheme", "auto") == "auto"
+        if self.world == 1:
+            return flag if auto else None
+        if getattr(self, "_skip", None) is None:
+            self._skip = torch.zeros(1, dtype=torch.int32, device=dev)
+        if auto:
+            self._skip.copy_(flag)
+        else:
+            self._skip.zero_()
+        dist.all_reduce(self._skip, op=dist.ReduceOp.MAX, group=self.group)
+        return self._skip
 
     def ema_state(self):
         """name -> EMA weights, as the reference's EMA callback stores them in a checkpoint (tqdne/ema.py:50-51)."""
