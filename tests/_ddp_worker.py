@@ -90,7 +90,7 @@ def main():
         opt_step = tr.optimizer.step
         grabbed = {}
 
-        def hold(grad_scale=1.0, _tr=tr, _m=m):
+        def hold(grad_scale=1.0, skip_flag=None, _tr=tr, _m=m):
             bwd = _m.unet._engine(per, T, dev)._bwd
             grabbed["g"] = (bwd.flat[:bwd.n_grad] * grad_scale).clone()
             grabbed["offs"] = dict((id(p), bwd.offs[id(p)]) for p in _m.unet.parameters())

@@ -55,7 +55,7 @@ def rel_err(a, b, elem=True):
 
 
 GRAD_LOG = []   # (test id, tensor name, floored error, own-scale error, |ref|max / gmax)
-GRAD_OWN_TOL = 1e-2     # bar on a gradient tensor's error against its OWN largest entry ...
+GRAD_OWN_TOL = 1e-3     # bar on a gradient tensor's error against its OWN largest entry (measured <= 4.2e-4, profiles/r03_*) ...
 GRAD_OWN_FROM = 1e-5    # ... for every tensor whose largest reference entry is at least this fraction of the largest gradient
 
 

@@ -135,7 +135,9 @@ def test_f16_mx8_conv_on_trained_like_statistics(case, scheme):
     ref = torch.nn.functional.conv1d(ref_x.double().permute(0, 2, 1), w.double(), bias.double(), padding=K // 2)
     if skip is not None:
         ref = ref + torch.nn.functional.conv1d(xs.double().permute(0, 2, 1), ws.double(), bs.double())
-    e = rel_err(y.cpu().permute(0, 2, 1), ref)
+    # (element-wise criterion for the default scheme; round 1's f16+mx8, kept selectable, clamps its fp8 corrections on the raw
+    # residual stream: 3.5e-4 norm-wise but 1.6e-3 element-wise on this stress input, which is why f16+mx6 superseded it)
+    e = rel_err(y.cpu().permute(0, 2, 1), ref, elem=(scheme == "f16mx6"))
     print(f"{scheme} on trained-like statistics ({case}): max|x| {float(x.abs().max()):.3g}, max|w| {float(w.abs().max()):.3g}, "
           f"rel err {e:.2e}")
     assert torch.isfinite(y).all() and e < TOL

@@ -81,7 +81,7 @@ def test_wide_unet_model_channels_128_vs_oracle():
     reads 128 channels) -- the shapes the kernels' former fixed limits rejected at the first forward"""
     from oracle import unet as OU
     from tqdne_amd import UNetModel, tiny_1d_unet_config
-    cfg = dict(tiny_1d_unet_config(), model_channels=128, channel_mult=(1, 2, 3), num_res_blocks=1)
+    cfg = dict(tiny_1d_unet_config(), model_channels=128, channel_mult=(1, 2, 3), num_res_blocks=1, num_heads=6)  # (middle attention: D = 64)
     torch.manual_seed(0)
     m = UNetModel(**cfg)
     sd = perturbed_state(m, 31)

@@ -46,7 +46,7 @@ def test_fused_and_torch_adam_train_the_same_trajectory():
     assert rel_err(y_f, y_t) < 1e-3
     # Adam turns a gradient that is rounding noise (a conv bias in front of a one-channel-per-group GroupNorm) into an update
     # of +-lr whatever its size, so those few tensors may differ between two correct implementations; the rest must agree
-    errs = {k: rel_err(w_f[k], w_t[k]) for k in w_f}
+    errs = {k: rel_err(w_f[k], w_t[k], elem=False) for k in w_f}   # (two trajectories, counted below: not a parity reference)
     close = sum(e < 2e-3 for e in errs.values())
     print("weights within 2e-3:", close, "of", len(errs), "; worst", max(errs.items(), key=lambda kv: kv[1]))
     assert close >= 0.9 * len(errs)

@@ -10,8 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libtqdne_hip.so")
-SOURCES = ["conv1d_mfma.hip", "small_ops.hip", "attention.hip", "backward.hip"]
+SOURCES = ["conv1d_mfma.hip", "conv1d_w4.hip", "small_ops.hip", "attention.hip", "backward.hip"]
 ARCH = "gfx950"
+# conv1d_w4.hip interleaves scalar fp32 VALU with MFMAs: packed fp32 ops (what the SLP vectoriser makes of adjacent scalar ones) cost
+# extra cycles beside MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+FILE_FLAGS = {"conv1d_w4.hip": ("-fno-slp-vectorize",)}
 
 
 def _hipcc() -> str:
@@ -43,7 +46,8 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), out_name=No
         if not os.path.exists(path):
             continue
         obj = os.path.join(LIBDIR, src.replace(".hip", tag + ".o"))
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", *extra_flags, "-c", path, "-o", obj]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", *FILE_FLAGS.get(src, ()), *extra_flags,
+               "-c", path, "-o", obj]
         if verbose:
             print("[tqdne_amd build]", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

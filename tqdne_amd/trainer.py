@@ -152,13 +152,15 @@ class DataParallelTrainer:
         auto = getattr(unet, "_conv_scheme", "auto") == "auto"
         if self.world == 1:
             return flag if auto else None
+        # (summed as a float through the same exchange path as the gradients; the kernel tests the word for "non-zero", and a sum of
+        # 0 / 1 flags has a non-zero bit pattern exactly when some rank raised its flag)
         if getattr(self, "_skip", None) is None:
-            self._skip = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._skip = torch.zeros(1, dtype=torch.float32, device=dev)
         if auto:
             self._skip.copy_(flag)
         else:
             self._skip.zero_()
-        dist.all_reduce(self._skip, op=dist.ReduceOp.MAX, group=self.group)
+        self._allreduce_async(self._skip).wait()
         return self._skip
 
     def ema_state(self):
