@@ -282,6 +282,18 @@ int tq_heun_churn(const double* x, const double* unit_noise, const float* coef, 
 int tq_axpy_sigma(const float* x, const float* noise, const float* sigma, float* out, int B, int n_per_sample,
                   hipStream_t stream);
 
+/* ---- DDPM (tqdne/diffusion.py:55-109; ABI 3).  The reference delegates this arithmetic to diffusers' DDPMScheduler, which is not in
+ * its lockfile: restated from the published algorithm (Ho et al. 2020), see tqdne_amd/diffusion.py. ------------------------------- */
+/* out[b] = a[b] x[b] + c[b] y[b]: the forward process of the training step (noise_scheduler.add_noise, diffusion.py:98). */
+int tq_scale_add2(const float* x, const float* y, const float* a, const float* c, float* out, int B, int n_per_sample,
+                  hipStream_t stream);
+/* One ancestral sampling step (noise_scheduler.step, diffusion.py:77): x0 = (x - sqrt(1 - abar_t) model_out) / sqrt(abar_t) for an
+ * epsilon-predicting network, else model_out; clipped to +-clip when clip > 0; out = coef_x0 x0 + coef_xt x + sigma noise
+ * (noise nullable: the last step adds none). */
+int tq_ddpm_step(const float* x, const float* model_out, const float* noise, float* out, size_t n, int epsilon_prediction,
+                 double sqrt_one_minus_abar, double inv_sqrt_abar, double clip, double coef_x0, double coef_xt, double sigma,
+                 hipStream_t stream);
+
 /* Weighted pseudo-Huber distance of improved consistency training (consistency_model.py:163-173):
  * loss = mean(w_b (sqrt((pred - target)^2 + c^2) - c)); dpred (nullable) = d loss / d pred.  loss_out is overwritten. */
 int tq_pseudo_huber_loss(const float* pred, const float* target, const float* weight, float c, float* loss_out, float* dpred,

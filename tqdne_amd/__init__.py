@@ -13,10 +13,11 @@ from .architectures import (get_1d_autoencoder_configs, get_1d_unet_config, get_
                             paper_1d_unet_config, tiny_1d_unet_config)
 from .autoencoder import Decoder, Encoder, LightningAutoencoder
 from .consistency_model import LithningConsistencyModel
+from .diffusion import DDPMScheduler, LightningDDMP
 from .edm import EDM, LightningEDM
 from .unet import UNetModel
 
 __version__ = "0.1.0"
-__all__ = ["UNetModel", "EDM", "LightningEDM", "LithningConsistencyModel", "LightningAutoencoder", "Encoder", "Decoder", "get_1d_unet_config",
+__all__ = ["UNetModel", "EDM", "LightningEDM", "LightningDDMP", "DDPMScheduler", "LithningConsistencyModel", "LightningAutoencoder", "Encoder", "Decoder", "get_1d_unet_config",
            "get_1d_autoencoder_configs", "get_2d_unet_config", "get_2d_autoencoder_configs", "paper_1d_unet_config",
            "tiny_1d_unet_config"]

@@ -112,6 +112,8 @@ _PROTOS = {
     "tq_axpy_sigma": (I, [VP, VP, VP, VP, I, I, VP]),
     "tq_pseudo_huber_loss": (I, [VP, VP, VP, F, VP, VP, I, I, VP]),
     "tq_mse_loss": (I, [VP, VP, VP, VP, SZ, VP]),
+    "tq_scale_add2": (I, [VP, VP, VP, VP, VP, I, I, VP]),
+    "tq_ddpm_step": (I, [VP, VP, VP, VP, SZ, I] + [C.c_double] * 6 + [VP]),
     "tq_vae_reparam_fwd": (I, [VP, VP, VP, VP, I, I, I, VP]),
     "tq_vae_reparam_bwd": (I, [VP, VP, VP, VP, F, I, I, I, VP]),
     "tq_concat_scale": (I, [VP, VP, VP, VP, I, I, I, I, VP]),

@@ -814,6 +814,54 @@ extern "C" int tq_axpy_sigma(const float* x, const float* noise, const float* si
     return 0;
 }
 
+// ---- DDPM (tqdne/diffusion.py; the scheduler arithmetic is the published algorithm of Ho et al. 2020, section 3) -----------------
+namespace {
+// out[b, :] = a[b] x[b, :] + c[b] y[b, :]   (forward process q(x_t | x_0): a = sqrt(abar_t), c = sqrt(1 - abar_t), diffusion.py:98)
+__global__ void scale_add2_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ a,
+                                  const float* __restrict__ c, float* __restrict__ out, int per) {
+    const int b = blockIdx.y;
+    const float fa = a[b], fc = c[b];
+    const size_t base = (size_t)b * per;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x)
+        out[base + i] = fa * x[base + i] + fc * y[base + i];
+}
+// one ancestral step x_t -> x_{t-1} (diffusion.py:77): x0 = epsilon-prediction ? (x - sqrt(1 - abar_t) eps) / sqrt(abar_t) : model output,
+// clipped to +-clip (clip <= 0: off); out = c0 x0 + ct x + sigma z
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ mo, const float* __restrict__ z,
+                                 float* __restrict__ out, size_t n, int eps_pred, float sqrt_1m_abar, float inv_sqrt_abar,
+                                 float clip, float c0, float ct, float sigma) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float xv = x[i];
+        float x0 = eps_pred ? (xv - sqrt_1m_abar * mo[i]) * inv_sqrt_abar : mo[i];
+        if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
+        float r = c0 * x0 + ct * xv;
+        if (z) r += sigma * z[i];
+        out[i] = r;
+    }
+}
+}  // namespace
+
+extern "C" int tq_scale_add2(const float* x, const float* y, const float* a, const float* c, float* out, int B, int n_per_sample,
+                             hipStream_t stream) {
+    if (!x || !y || !a || !c || !out || B <= 0 || n_per_sample <= 0) return TQ_ERR_ARG;
+    const int gx = (n_per_sample + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(scale_add2_kernel, dim3(gx, B), dim3(256), 0, stream, x, y, a, c, out, n_per_sample);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_ddpm_step(const float* x, const float* model_out, const float* noise, float* out, size_t n, int epsilon_prediction,
+                            double sqrt_one_minus_abar, double inv_sqrt_abar, double clip, double coef_x0, double coef_xt,
+                            double sigma, hipStream_t stream) {
+    if (!x || !model_out || !out || n == 0) return TQ_ERR_ARG;
+    size_t g = (n + 256 * 4 - 1) / (256 * 4);
+    if (g > 65535) g = 65535;
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, model_out, noise, out, n, epsilon_prediction,
+                       (float)sqrt_one_minus_abar, (float)inv_sqrt_abar, (float)clip, (float)coef_x0, (float)coef_xt, (float)sigma);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int tq_pseudo_huber_loss(const float* pred, const float* target, const float* weight, float c, float* loss_out,
                                     float* dpred, int B, int n_per_sample, hipStream_t stream) {
     if (!pred || !target || !weight || !loss_out || B <= 0 || n_per_sample <= 0) return TQ_ERR_ARG;
