@@ -243,6 +243,110 @@ def parity_block(gpu, cpu_path, args):
     return blk
 
 
+def other_configs(dev, args):
+    """BASELINE.json configs[0] and configs[3] next to the headline (configs[1]): parity-test cases, reported with the same step
+    definition (1 train step + one 18-step sample) so that the small / latent paths have a number in the driver's record.
+      cfg0  tiny UNet (32 base channels, no attention, unconditioned), B = 4, 3 x 4096 -- with its own CPU-oracle baseline at B = 4
+      cfg3  latent EDM: frozen autoencoder 3 x 16384 <-> 16 x 4096 + paper-shape latent UNet, B = 16 (sample = 18 steps + decode)"""
+    from tqdne_amd import LightningAutoencoder, LightningEDM, paper_1d_unet_config, rng, tiny_1d_unet_config
+    from tqdne_amd.trainer import DataParallelTrainer
+    res = []
+
+    def med(fn, n=5):
+        fn(); fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return _median(ts)
+
+    # ---- cfg0
+    try:
+        torch.manual_seed(args.seed)
+        cfg = tiny_1d_unet_config()
+        edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 100000, "eta_min": 0.0}, num_sampling_steps=args.sample_steps)
+        edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
+        edm = edm.to(dev)
+        B, T = 4, 4096
+        g = torch.Generator().manual_seed(4321)
+        batch = {"signal": (0.5 * torch.randn(B, 3, T, generator=g)).to(dev)}
+        tr = DataParallelTrainer(edm, world_size=1)
+        sig = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
+        eps0 = torch.randn(B, 3, T, generator=g, dtype=torch.float64).to(dev) * sig[0]
+
+        def step():
+            edm.train()
+            tr.train_step(batch)
+            edm.eval()
+            edm.sample_deterministically(eps0, sig, None, None)
+
+        def train_only():
+            edm.train()
+            tr.train_step(batch)
+
+        ms, ms_train = med(step), med(train_only)
+        r = dict(config="cfg0: tiny 1-D EDM UNet (32 base channels, 2 res blocks, no attention), B=4, 3x4096: 1 train step + "
+                        f"{args.sample_steps}-step Heun sample (whole integration replayed from one HIP graph)",
+                 value=B / (ms * 1e-3), unit="waveforms/s", ms_per_step=ms, parts=dict(train_ms=ms_train, sample_ms=ms - ms_train))
+        if not args.no_cpu_baseline:
+            try:
+                ncores = len(os.sched_getaffinity(0))
+            except Exception:
+                ncores = os.cpu_count() or 1
+            nth = max(1, min(ncores, 64))
+            reps = _cpu_run("tiny", B, T, args.sample_steps, 99, nth, 2, 120)
+            if reps:
+                tt, tsm = _median([x["t_train"] for x in reps]), _median([x["t_sample"] for x in reps])
+                r["cpu_baseline"] = dict(value=B / (tt + tsm), unit="waveforms/s", cores=nth, kind="port", train_s=tt, sample_s=tsm,
+                                         sample=f"tiny UNet, B={B}, 3x{T} in full: warm-up, then median of {len(reps)} x (1 train "
+                                                f"step + 1 x {args.sample_steps}-step sample), CPU oracle, {nth} threads")
+        res.append(r)
+        del edm, tr
+    except Exception as e:   # (a reported extra: never takes the headline line down)
+        res.append(dict(config="cfg0", error=repr(e)))
+    # ---- cfg3
+    try:
+        torch.manual_seed(args.seed)
+        base = dict(model_channels=64, channel_mult=(1, 2, 4), attention_resolutions=(), num_res_blocks=2, dims=1, conv_kernel_size=5,
+                    dropout=0.1)
+        ae = LightningAutoencoder(dict(base, in_channels=3, out_channels=32), dict(base, in_channels=16, out_channels=3),
+                                  {"learning_rate": 1e-4, "max_steps": 1000, "eta_min": 0.0})
+        ae.load_state_dict(perturbed_state(ae, 19))
+        ae = ae.to(dev).eval()
+        edm = LightningEDM(paper_1d_unet_config(in_channels=16, out_channels=16), {"learning_rate": 1e-4, "max_steps": 100000, "eta_min": 0.0},
+                           num_sampling_steps=args.sample_steps, autoencoder=ae)
+        edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
+        edm = edm.to(dev)
+        B, T = 16, 16384
+        g = torch.Generator().manual_seed(4322)
+        batch = {"signal": (0.5 * torch.randn(B, 3, T, generator=g)).to(dev), "cond": torch.randn(B, 5, generator=g).to(dev)}
+        tr = DataParallelTrainer(edm, world_size=1)
+
+        def step3():
+            edm.train()
+            tr.train_step(batch)
+            edm.eval()
+            edm.sample((B, 3, T), cond=batch["cond"])
+
+        def train3():
+            edm.train()
+            tr.train_step(batch)
+
+        ms, ms_train = med(step3, 3), med(train3, 3)
+        res.append(dict(config="cfg3: 1-D latent EDM: frozen autoencoder 3x16384 <-> 16x4096 + paper-shape latent UNet, B=16: 1 train step "
+                               f"(encode + latent UNet fwd/bwd + Adam) + {args.sample_steps}-step latent Heun sample + decode",
+                        value=B / (ms * 1e-3), unit="waveforms/s (3x16384)", ms_per_step=ms,
+                        parts=dict(train_ms=ms_train, sample_ms=ms - ms_train)))
+        del edm, ae, tr
+    except Exception as e:
+        res.append(dict(config="cfg3", error=repr(e)))
+    torch.cuda.empty_cache()
+    return res
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -329,9 +433,12 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the same-run parity gate (it rides in the CPU-baseline child)")
     ap.add_argument("--no-tables", action="store_true", help="skip the per-class traced passes after the timed region")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gradient all-reduce after the backward instead of under it")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg0 / cfg3 extras of the headline run")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--graph", action="store_true", help="replay the UNet forward of the sampler from a HIP graph (neutral at B=64: GPU-bound)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole sampler integration from one HIP graph (neutral at B=64: GPU-bound)")
+    ap.add_argument("--no-auto-graph", dest="auto_graph", action="store_false",
+                    help="never graph-replay the sampler (default: the sampler's own choice, a whole-loop graph for B <= 16)")
     args = ap.parse_args()
     if args.no_train:
         args.mode = "sample"
@@ -409,7 +516,7 @@ def main():
     sigmas = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
     eps0 = start_noise * sigmas[0]
     eps32 = start_noise.float()
-    use_graph = args.graph
+    use_graph = True if args.graph else (None if args.auto_graph else False)   # None: the sampler's own choice (graph for B <= 16)
 
     # HIP-event probe around the dominant kernel (the heaviest k=5 conv launch of the forward)
     eng = edm.unet._engine(B, T, dev)
@@ -614,7 +721,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (contractions on MFMA with fp32 accumulate: bf16x3, and fp16 + block-scaled-fp6 corrections on the 128/256-channel forward convs; sampler state f64)", "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}",
-                       "hip_graph": use_graph, "sampler_lanes": 1 if use_graph else sampler_lanes(B), "mode": args.mode},
+                       "hip_graph": bool(use_graph) or (use_graph is None and B <= 16),
+                       "sampler_lanes": 1 if (use_graph or (use_graph is None and B <= 16)) else sampler_lanes(B), "mode": args.mode},
             "parts": parts,
             "rccl_ranks": rccl_ranks, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "gradient_exchange": exchange,
@@ -638,6 +746,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, T, args.sample_steps, 99, parity_path=ppath)
             if gpu_parity is not None:
                 out["parity"] = parity_block(gpu_parity, ppath, args)
+        if (world == 1 and cm is None and args.mode == "step" and args.config == "paper" and B == 64 and T == 4096
+                and not args.no_other_configs):
+            log("other BASELINE configurations (cfg0 tiny B=4, cfg3 latent B=16) ...")
+            out["other_configs"] = other_configs(dev, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

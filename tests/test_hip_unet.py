@@ -418,10 +418,20 @@ def test_graph_replayed_sampler_matches_eager():
     eps = (torch.from_numpy(d["sample:start"]) * sig[0].cpu()).to(dev())
     cond = torch.from_numpy(d["cond"]).to(dev())
     a = edm.sample_deterministically(eps, sig, None, cond, use_graph=False)
-    b = edm.sample_deterministically(eps, sig, None, cond, use_graph=True)
-    c = edm.sample_deterministically(eps, sig, None, cond, use_graph=True)  # cached graph
+    b = edm.sample_deterministically(eps, sig, None, cond, use_graph=True)   # the whole 18-step integration as one HIP graph
+    c = edm.sample_deterministically(eps, sig, None, cond, use_graph=True)   # cached graph
     assert torch.equal(a, b) and torch.equal(a, c)
     assert rel_err(a.float().cpu(), d["sample:out"]) < TOL
+    # new inputs through the cached graph (start state and conditioning are copied into the graph's static buffers)
+    g = torch.Generator().manual_seed(77)
+    eps2 = (torch.randn(eps.shape, generator=g, dtype=torch.float64) * float(sig[0])).to(dev())
+    cond2 = torch.randn(cond.shape, generator=g).to(dev())
+    a2 = edm.sample_deterministically(eps2, sig, None, cond2, use_graph=False)
+    b2 = edm.sample_deterministically(eps2, sig, None, cond2, use_graph=True)
+    assert torch.equal(a2, b2) and not torch.equal(a2, a)
+    e = edm.sample_deterministically(eps, sig, None, cond, use_graph="denoiser")   # round 1's form: one captured evaluation per NFE
+    f = edm.sample_deterministically(eps, sig, None, cond)                          # default at this batch size: the whole-loop graph
+    assert torch.equal(a, e) and torch.equal(a, f)
 
 
 def test_consistency_training_step_vs_reference():

@@ -267,7 +267,7 @@ class LightningEDM(LightningModule):
         return bufs
 
     @th.no_grad()
-    def sample_deterministically(self, eps, sigmas, cond_sample=None, cond=None, use_graph=False, lanes=None):
+    def sample_deterministically(self, eps, sigmas, cond_sample=None, cond=None, use_graph=None, lanes=None):
         """Deterministic Heun sampler (edm.py:171-196): ``eps`` is the fp64 start state (already scaled by sigmas[0]),
         ``sigmas`` the fp32 schedule ending in 0.  NFE = 2*len(sigmas) - 3 when the last sigma is the appended 0.
 
@@ -276,9 +276,19 @@ class LightningEDM(LightningModule):
         then all in their store epilogue); streams drift out of phase, so one lane's prologue / epilogue bursts overlap another
         lane's matrix work (measured on single layers: 1.0-1.17x, tools/desync_bench.py; 18-step sample at B = 64: 2 lanes
         -5.5 %, 4 lanes -9 %, 8 lanes +16 %: launches too small and too many).  Results are bit-identical to one lane.
-        Default: ``sampler_lanes(B)``; 1 under graph replay."""
+        Default: ``sampler_lanes(B)``; 1 under graph replay.
+
+        ``use_graph``: True replays the WHOLE integration (every network evaluation and every fp64 update of all steps) from one
+        HIP graph captured on first use -- one host call per sample instead of ~100 launches per network evaluation; "denoiser" is
+        round 1's form (one captured network evaluation, replayed per NFE); False launches eagerly.  Default (None): the whole-loop
+        graph for launch-bound batches (B <= 16: a tiny-UNet evaluation at B = 4 is ~90 launches of a few microseconds each, the
+        host cannot issue them as fast as the GPU retires them), eager otherwise (TQDNE_SAMPLER_GRAPH=0 / 1 overrides)."""
         if not eps.is_cuda:
             raise RuntimeError("tqdne_amd samples on MI355X HIP kernels only; got a CPU start state")
+        if use_graph is None:
+            env = os.environ.get("TQDNE_SAMPLER_GRAPH")
+            use_graph = (env == "1") if env in ("0", "1") else (eps.shape[0] <= 16 and lanes is None
+                                                                 and not th.cuda.is_current_stream_capturing())
         out = self._sample_det(eps, sigmas, cond_sample, cond, use_graph, lanes)
         # range guard of the fp16-range conv scheme: one flag read per sample call; if a tensor came near the fp16 range the plans
         # have been moved to bf16x3 and the integration is repeated
@@ -294,6 +304,9 @@ class LightningEDM(LightningModule):
             lanes = sampler_lanes(B)
         if use_graph:
             lanes = 1  # one captured denoiser per buffer set; replay is for launch-bound (small) batches, where lanes do not pay
+        if use_graph is True:
+            return self._graph_sample(eps, sigmas, cond_sample, cond)
+        use_graph = bool(use_graph)   # ("denoiser": the per-evaluation graph below)
         if lanes < 2 or B % lanes or B // lanes < 8:
             run = self._heun_lane(eps, sigmas, cond_sample, cond, use_graph)
             for _ in run:
@@ -398,6 +411,51 @@ class LightningEDM(LightningModule):
         run = _Run(eps)
         del eps
         return run
+
+    def _graph_sample(self, eps, sigmas, cond_sample, cond):
+        """The whole Heun integration as ONE HIP graph.  Everything the captured launches read lives in static buffers of the sampler
+        (start state, sigma schedule, conditioning), refreshed by device-to-device copies before each replay; the graph is re-captured
+        when the shapes, the number of steps or the plan (weights format, see the range guard) change."""
+        dev = eps.device
+        B = eps.shape[0]
+        bufs = self._sampler_buffers(eps)
+        eng = self.unet._engine(B, eps.shape[2], dev, self._lane)
+        nsig = int(sigmas.numel())
+        key = (nsig, None if cond is None else tuple(cond.shape), None if cond_sample is None else tuple(cond_sample.shape),
+               eng.plan_epoch, self.num_sampling_steps)
+        g = bufs.get("loop_graph")
+        if g is None or g["key"] != key:
+            st = dict(key=key, sig=th.empty(nsig, dtype=th.float32, device=dev), start=th.empty_like(bufs["x"]),
+                      cond=None if cond is None else th.empty(cond.shape, dtype=th.float32, device=dev),
+                      cs=None if cond_sample is None else th.empty(cond_sample.shape, dtype=th.float32, device=dev))
+            st["sig"].copy_(sigmas)
+            st["start"].copy_(eps)
+            if cond is not None:
+                st["cond"].copy_(cond)
+            if cond_sample is not None:
+                st["cs"].copy_(cond_sample)
+            # warm-up outside capture: plan build, weight packing, allocator state
+            run = self._heun_lane(st["start"], st["sig"], st["cs"], st["cond"], False)
+            run.advance()
+            run.release()
+            th.cuda.synchronize(dev)
+            graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(graph):
+                run = self._heun_lane(st["start"], st["sig"], st["cs"], st["cond"], False)
+                for _ in run:
+                    pass
+                st["out"] = run.result
+                run.release()
+            st["graph"] = graph
+            bufs["loop_graph"] = g = st
+        g["sig"].copy_(sigmas)
+        g["start"].copy_(eps)
+        if cond is not None:
+            g["cond"].copy_(cond)
+        if cond_sample is not None:
+            g["cs"].copy_(cond_sample)
+        g["graph"].replay()
+        return g["out"].clone()
 
     def _graph_denoiser(self, bufs, x32, cond, cond_sample=None):
         """One preconditioned UNet evaluation (~160 launches) captured once in a HIP graph and replayed per NFE; sigma is fed

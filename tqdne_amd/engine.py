@@ -85,6 +85,26 @@ def side_stream(dev, i: int = 1) -> "torch.cuda.Stream":
     return s
 
 
+def reserve_side_streams(dev, n: int = 3):
+    """Create the pool's first ``n`` streams NOW (called when the first plan of a device is built).  Stream creation order decides
+    how ROCm spreads streams over hardware queues: with the three lane streams created AFTER anything had captured a HIP graph
+    (torch's capture stream, even for a one-kernel graph), the 4-lane sampler ran at 250 instead of 160 ms per 18-step sample at
+    B = 64 -- also with 16 hardware queues -- while the same graph captured after the lanes existed cost nothing
+    (tools/graph_side_effect.py, round 3).  Reserving them up front makes the good order the only one."""
+    if torch.device(dev).type != "cuda" or (str(dev), "reserved") in _SIDE_STREAMS or torch.cuda.is_current_stream_capturing():
+        return
+    _SIDE_STREAMS[(str(dev), "reserved")] = True
+    # (a stream is bound to its hardware queue by its first submission, not by its creation: one tiny launch on each)
+    main = torch.cuda.current_stream(dev)
+    z = torch.zeros(1, device=dev)
+    for i in range(1, n + 1):
+        s = side_stream(dev, i)
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            z.add_(0)
+        main.wait_stream(s)
+
+
 _PACK_TABLES: dict = {}
 PACK_BATCH = os.environ.get("TQDNE_PACK_BATCH", "1") != "0"   # A/B switch: 0 = one launch per tensor (rounds 1-2 behaviour)
 
@@ -240,6 +260,7 @@ class UNetEngine:
         self.lib = _lib.load()
         self.m = model
         self.B, self.T, self.dev = B, T, device
+        reserve_side_streams(device)
         self.store = get_store(model, device)
         self._seen_pack = {}
         self._clean_tag = None
