@@ -4,6 +4,15 @@
 # short bench.py run (kernels are serialised by the counter collection: standalone behaviour of every launch)
 tag=$1; shift
 repo=$GRAFT_REPO_ROOT
+# the profiled program must stay ONE process that nothing re-launches: bench.py --gpus N > 1 starts torch.distributed.run and that
+# launcher its rank workers, all from a process the profiler's preloaded library has already GPU-initialised (forbidden on this pool)
+for a in "$@"; do
+  if [ "$prev" = "--gpus" ] && [ "$a" != "1" ]; then echo "pmc_step.sh: --gpus $a refused (single process only under rocprofv3 --pmc)"; exit 2; fi
+  case "$a" in --gpus=1) ;; --gpus=*) echo "pmc_step.sh: $a refused (single process only under rocprofv3 --pmc)"; exit 2;; esac
+  prev=$a
+done
+# build BEFORE entering rocprofv3: a stale library would make __graft_entry__.build() start hipcc children inside the profiled process
+python3 -m tqdne_amd._build > /dev/null || exit 1
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $repo/gpurun_out/pmcs_$tag -- python3 $repo/bench.py "$@" --no-tables --no-cpu-baseline > /dev/null 2>&1

@@ -3,6 +3,7 @@
 tag=$1
 repo=$GRAFT_REPO_ROOT
 mkdir -p $repo/gpurun_out
+(cd $repo && python3 -m tqdne_amd._build > /dev/null) || exit 1   # never build inside a profiled process
 bash $repo/tools/profile.sh ${tag}_full_step --steps 5 --warmup 2 --no-tables > $repo/gpurun_out/${tag}_full_step_summary.txt 2>&1
 TQDNE_SAMPLER_LANES=1 bash $repo/tools/profile.sh ${tag}_sample_only_1lane --mode sample --steps 3 --warmup 1 --no-tables > $repo/gpurun_out/${tag}_sample_only_1lane_summary.txt 2>&1
 bash $repo/tools/profile.sh ${tag}_train_only --mode train --steps 10 --warmup 3 --no-tables > $repo/gpurun_out/${tag}_train_only_summary.txt 2>&1

@@ -216,62 +216,78 @@ __global__ __launch_bounds__(256, 1) void conv1d_w4_kernel(const ConvArgs p) {
     const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * 4) * 64 + lane;
     const size_t wstep = (size_t)p.ncob_pad * 4 * 64;   // uint4 per (chunk, tap)
     const int last_step = nchunks * KT + nskip - 1;
-    // weight fragments of one tap, per 16-channel block: fp16 (channels 0..31), fp16 (32..63), fp6 dwords 0..3 -- and, in a
-    // 3-register value of its own, {fp6 dwords 4, 5, E8M0 byte} from a 12-byte load.  (As the first three components of a
-    // 4-register fragment, the fourth register is either dead at once -- hipcc reuses it and must wait for the load first, write
-    // after write -- or carried around the loop and merged back in with a v_mov behind every load: either way an s_waitcnt right
-    // behind the prefetch.)
-    struct WBuf { Frag f[8]; i32x8 c6[4]; };
+    // Weight fragments of one tap, per 16-channel block: fp16 (channels 0..31), fp16 (32..63), the 6-dword e2m3 block and its E8M0
+    // byte.  The MFMAs are issued from inline asm with register-class constraints (below): accumulators and weight fragments live
+    // in AccVGPRs ("a"), activation fragments and the two scale words in VGPRs ("v").  Hence the load shapes: the fp6 block as a
+    // 16-byte + an 8-byte load that together ARE its 6-register tuple (no spare component the allocator could treat as dead and
+    // reuse, no component that has to live in the other register file), the scale word as a load of its own.
+    struct WBuf { f16x8 h0[4], h1[4]; u32x6 c6[4]; int sc[4]; };
     WBuf wa, wb;
     auto load_w = [&](int step, WBuf& w) __attribute__((always_inline)) {
+#ifdef TQ_W4_ABL_NOW   // (diagnostic build: weights stay L1-resident; wrong results)
+        const int st = step & 1;
+#else
         const int st = step < last_step ? step : last_step;   // (past the end: a harmless re-read)
+#endif
         const uint4* wp = wbase + (size_t)st * wstep;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            w.f[cb * 2 + 0].u = wp[(cb * 4 + 0) * 64];
-            w.f[cb * 2 + 1].u = wp[(cb * 4 + 1) * 64];
-            const uint4 lo = wp[(cb * 4 + 2) * 64], hi = wp[(cb * 4 + 3) * 64];
-            w.c6[cb] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            w.h0[cb] = __builtin_bit_cast(f16x8, wp[(cb * 4 + 0) * 64]);
+            w.h1[cb] = __builtin_bit_cast(f16x8, wp[(cb * 4 + 1) * 64]);
+            const uint4 lo = wp[(cb * 4 + 2) * 64];
+            const uint2 hi = *reinterpret_cast<const uint2*>(wp + (cb * 4 + 3) * 64);
+            w.c6[cb] = u32x6{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+            w.sc[cb] = reinterpret_cast<const int*>(wp + (cb * 4 + 3) * 64)[2];
         }
-    };
-    // Weight fragments belong in the AccVGPR half of the register file: MFMA reads its A operand from there directly, and the
-    // VGPR half is what the conversion's VALU work needs.  Left alone, hipcc fills VGPRs with them first and then shuttles the
-    // VALU operands through AccVGPRs (v_accvgpr_write / read pairs, and copies of freshly loaded fragments that wait for the load).
-    // An empty asm with "a" operands at the tap's first step says where they must be when they are first used.
-    auto pin_w = [&](WBuf& w) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) asm volatile("" : "+a"(w.f[q].v));
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) asm volatile("" : "+a"(w.c6[cb]));
     };
     auto tap_base = [&](int k) -> int __attribute__((always_inline)) {
         const int rowk = tl_lane + k;
         return rowk * 128 + ((kq ^ (rowk & 7)) << 4);
     };
-    auto read_b = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int b0, int tb, Frag (&f)[4]) __attribute__((always_inline)) {
+    struct BFrag { f16x8 h0, h1; uint4 lo, hi; };
+    auto read_b = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int b0, int tb, BFrag& f) __attribute__((always_inline)) {
+#ifdef TQ_W4_ABL_NOLDSMOVE   // (diagnostic build: every t-block reads the same LDS rows; wrong results)
+        const int toff = 0;
+        (void)tb;
+#else
         const int toff = tb * 16 * 128;
-        f[0].u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);          // fp16, channels 8 kq ...
-        f[1].u = *reinterpret_cast<const uint4*>(hi_plane + (b0 ^ 64) + toff);   // fp16, channels 32 + 8 kq ...
-        f[2].u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);          // fp6 block, dwords 0..3
-        f[3].u = *reinterpret_cast<const uint4*>(lo_plane + (b0 ^ 64) + toff);   // dwords 4, 5, E8M0 byte
+#endif
+        f.h0 = *reinterpret_cast<const f16x8*>(hi_plane + b0 + toff);          // fp16, channels 8 kq ...
+        f.h1 = *reinterpret_cast<const f16x8*>(hi_plane + (b0 ^ 64) + toff);   // fp16, channels 32 + 8 kq ...
+        f.lo = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);          // fp6 block, dwords 0..3
+        f.hi = *reinterpret_cast<const uint4*>(lo_plane + (b0 ^ 64) + toff);   // dwords 4, 5, E8M0 byte
     };
-    auto mma_step = [&](const WBuf& w, const Frag (&f)[4], auto tb_c) __attribute__((always_inline)) {
+    // The twelve MFMAs of a (tap, t-block) step as three asm statements of four (one per channel block).  Why asm: with the
+    // builtins hipcc renamed accumulators between MFMAs (destination != addend register), moved them through VGPRs
+    // (v_accvgpr_read behind an s_nop 7) and kept weight fragments in VGPRs while VALU operands commuted through AccVGPRs -- the
+    // bare MFMA / weight / LDS stream ran at 2.4x its matrix-pipe time (tools/w4_time.py, -DTQ_W4_ABL_NOCONV).  An in/out "+a"
+    // operand cannot be renamed, and "a" puts the weights where MFMA reads them for free.  Per accumulator the order is that of
+    // conv1d_mfma.hip: fp16 (channels 0..31), fp16 (32..63), block-scaled corrections.  hipcc inserts the s_waitcnt for operands
+    // that are pending loads; wait states it does not insert for asm: VALU-written operand -> MFMA (the two v_mov that complete
+    // the activation side's 6-register tuple): s_nop 1 in front of the third statement.
+    auto mma_f16 = [&](const f16x8 (&w)[4], const f16x8& bv, auto tb_c) __attribute__((always_inline)) {
         constexpr int tb = decltype(tb_c)::value;
-        asm volatile("" ::"v"(f[3].u.w));   // (keeps the fourth register of that LDS read alive until here: same hazard as in load_w)
-        const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
-                          (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, 0};
-        const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
-        // per accumulator: fp16 (channels 0..31), fp16 (32..63), block-scaled corrections -- the order of conv1d_mfma.hip
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-            acc[cb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w.f[cb * 2 + 0].u), b0v, acc[cb][tb], 0, 0, 0);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-            acc[cb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w.f[cb * 2 + 1].u), b1v, acc[cb][tb], 0, 0, 0);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            acc[cb][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w.c6[cb], bc, acc[cb][tb], 2, 2, 0, w.c6[cb][6], 0, (int)f[3].u.z);
-        }
+        f32x4 &a0 = acc[0][tb], &a1 = acc[1][tb], &a2 = acc[2][tb], &a3 = acc[3][tb];   // (asm operands alone do not capture)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"
+                     "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"
+                     "v_mfma_f32_16x16x32_f16 %3, %7, %8, %3"
+                     : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3)
+                     : "a"(w[0]), "a"(w[1]), "a"(w[2]), "a"(w[3]), "v"(bv));
+    };
+    auto mma_fp6 = [&](const WBuf& w, const BFrag& f, auto tb_c) __attribute__((always_inline)) {
+        constexpr int tb = decltype(tb_c)::value;
+        const u32x6 bc = {f.lo.x, f.lo.y, f.lo.z, f.lo.w, f.hi.x, f.hi.y};
+        const int sb = (int)f.hi.z;
+        f32x4 &a0 = acc[0][tb], &a1 = acc[1][tb], &a2 = acc[2][tb], &a3 = acc[3][tb];
+        asm volatile("s_nop 1\n\t"
+                     "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %4, %8, %0, %9, %13 op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\t"
+                     "v_mfma_scale_f32_16x16x128_f8f6f4 %1, %5, %8, %1, %10, %13 op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\t"
+                     "v_mfma_scale_f32_16x16x128_f8f6f4 %2, %6, %8, %2, %11, %13 op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\t"
+                     "v_mfma_scale_f32_16x16x128_f8f6f4 %3, %7, %8, %3, %12, %13 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
+                     : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3)
+                     : "a"(w.c6[0]), "a"(w.c6[1]), "a"(w.c6[2]), "a"(w.c6[3]), "v"(bc), "v"(w.sc[0]), "v"(w.sc[1]), "v"(w.sc[2]),
+                       "v"(w.sc[3]), "v"(sb));
     };
 
     // One chunk phase on LDS buffer `buf`: NTAPS x 8 (tap, t-block) steps; with STAGE the conversion of chunk `stage + 1` into the
@@ -283,41 +299,42 @@ __global__ __launch_bounds__(256, 1) void conv1d_w4_kernel(const ConvArgs p) {
         constexpr int NTAPS = decltype(ntaps_c)::value, K0 = decltype(first_tap_c)::value;
         constexpr bool STAGE = decltype(stage_c)::value;
         constexpr int NU = NTAPS * 8;
+        constexpr int NG = NU * 3;   // MFMA groups of four: the conversion's micro-operations are dealt out behind them
         const unsigned char* hi_plane = lds + buf * C::BUF;
         const unsigned char* lo_plane = hi_plane + C::PLANE;
-        Frag bf[2][4];
+        BFrag bf[2];
         int b0 = tap_base(K0), b0n = b0;
         read_b(hi_plane, lo_plane, b0, 0, bf[0]);
         static_for<0, NU>([&](auto u_c) __attribute__((always_inline)) {
             constexpr int u = decltype(u_c)::value;
             constexpr int kk = u >> 3, tb = u & 7;
+            const auto TB = std::integral_constant<int, tb>{};
             if constexpr (tb == 0 && kk + 1 < NTAPS) b0n = tap_base(K0 + kk + 1);
             if constexpr (u + 1 < NU) read_b(hi_plane, lo_plane, ((u + 1) >> 3) == kk ? b0 : b0n, (u + 1) & 7, bf[(u + 1) & 1]);
-            if constexpr (tb == 0) { if constexpr (kk & 1) pin_w(wb); else pin_w(wa); }
-            if constexpr (kk & 1) mma_step(wb, bf[u & 1], std::integral_constant<int, tb>{});
-            else mma_step(wa, bf[u & 1], std::integral_constant<int, tb>{});
+            auto ops = [&](auto g_c) __attribute__((always_inline)) {
 #ifndef TQ_W4_ABL_NOCONV   // (diagnostic build: the MFMA / weight / LDS-read stream alone; wrong results)
-            if constexpr (STAGE) {
-                constexpr int lo = u * C::NOPS / NU, hi = (u + 1) * C::NOPS / NU;
-                static_for<lo, hi>([&](auto m_c) __attribute__((always_inline)) { conv_op(stage + 1, buf ^ 1, m_c); });
-            }
+                if constexpr (STAGE) {
+                    constexpr int g = 3 * u + decltype(g_c)::value;
+                    constexpr int lo = g * C::NOPS / NG, hi = (g + 1) * C::NOPS / NG;
+                    static_for<lo, hi>([&](auto m_c) __attribute__((always_inline)) { conv_op(stage + 1, buf ^ 1, m_c); });
+                }
 #endif
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (kk & 1) mma_f16(wb.h0, bf[u & 1].h0, TB); else mma_f16(wa.h0, bf[u & 1].h0, TB);
+            ops(std::integral_constant<int, 0>{});
+            if constexpr (kk & 1) mma_f16(wb.h1, bf[u & 1].h1, TB); else mma_f16(wa.h1, bf[u & 1].h1, TB);
+            ops(std::integral_constant<int, 1>{});
+            if constexpr (kk & 1) mma_fp6(wb, bf[u & 1], TB); else mma_fp6(wa, bf[u & 1], TB);
+            ops(std::integral_constant<int, 2>{});
             if constexpr (tb == 7) {   // tap done: its buffer takes the weights of the step two ahead
                 if constexpr (NTAPS > 1) {
                     const int nxt = (kk + 2 < NTAPS) ? (g0 + kk + 2) : ((kk & 1) ? (g0 + NTAPS + 1) : (g0 + NTAPS));
                     if constexpr (kk & 1) load_w(nxt, wb); else load_w(nxt, wa);
                 }
                 b0 = b0n;
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // interleave: one MFMA, then up to two vector instructions (the SIMD issues VALU in 8 of an MFMA's 16 cycles)
-#ifndef TQ_W4_ABL_NOHINT
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
-            }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
         });
     };
 
@@ -376,6 +393,7 @@ __global__ __launch_bounds__(256, 1) void conv1d_w4_kernel(const ConvArgs p) {
         }
     }
 
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results: hipcc pads nothing behind asm)
     // ---- epilogue (as conv1d_mfma.hip, EPI == 0): + bias + emb (+ skip bias), store, GroupNorm partial sums, range guard
     const bool poly = p.flags & TQ_CONV_POLY2;
     const int Cr = poly ? (p.C_out >> 1) : p.C_out;
