@@ -57,6 +57,25 @@ typedef struct ihipStream_t* hipStream_t;
  * mode 3). */
 #define TQ_WFMT_F16_MX6 2
 
+/* GroupNorm finalisation fused into the launch that completes a tensor's statistics (ABI 3; TqConvDesc.gn_fuse, NULL = off).
+ * With TQ_CONV_STATS the launch's workgroups publish their partial sums, take an arrival ticket per sample, and the workgroup whose
+ * ticket completes sample b folds the statistics of that sample into the scale / shift of the GroupNorm that CONSUMES the produced
+ * tensor (what tq_gn_finalize would do in a launch of its own: bit-identical coefficients).  The consumer may normalise the
+ * concatenation of the produced tensor with a second, older one (`partner_stats`, complete before this launch).
+ * `counters`: device, one uint64 per sample, zero-initialised ONCE by the caller and owned by this (launch site, consumer) pair:
+ * tickets count up monotonically, nothing is reset between launches.  Launches using the same TqGnFuse must not overlap. */
+typedef struct TqGnFuse {
+    unsigned long long* counters; /* (B) arrival tickets */
+    const float* partner_stats;   /* (B, nslots, C_partner, 2) or NULL */
+    int32_t C_partner;
+    int32_t partner_first;        /* 1: the consumer's channels are [partner | produced], 0: [produced | partner] */
+    const float* gamma;           /* (C_total) affine parameters of the consuming GroupNorm */
+    const float* beta;
+    float* gscale;                /* (B, C_total) out */
+    float* gshift;                /* (B, C_total) out */
+    float* mean_rstd;             /* (B, 32, 2) out, nullable */
+} TqGnFuse;
+
 typedef struct TqConvDesc {
     int32_t B, T_in, T_out;
     int32_t C_in0, C_in1; /* channels of the two concatenated sources (C_in1 = 0: single source) */
@@ -76,6 +95,7 @@ typedef struct TqConvDesc {
      * read such a tensor un-normalised (fused 1x1 skip convs, up-sampling convs) to TQ_WFMT_BF16X3.  Device pointer, never reset
      * by the library. */
     int32_t* range_flag;
+    const TqGnFuse* gn_fuse; /* host pointer, read at launch; NULL: statistics are finalised by a tq_gn_finalize launch */
 } TqConvDesc;
 
 /* flags of TqConvBwdDesc.flags: which stages the FORWARD conv applied to its input */

@@ -183,3 +183,88 @@ def test_training_step_next_to_other_streams():
             else:
                 assert torch.equal(a, b), f"round {rep}: gradient of {name} changed next to foreign kernels"
         assert worst < 1e-4, worst
+
+
+def test_fused_groupnorm_fold_poisoned_buffers_and_equals_separate_launches():
+    """GroupNorm finalisation rides in the launch that completes the statistics (TqGnFuse: the last-arriving workgroup of a sample
+    folds them).  (i) With every coefficient buffer poisoned with NaN before each forward, outputs are finite and bit-identical
+    to the un-poisoned run: every fold happens, every call.  (ii) Bit-identical to the plan with one tq_gn_finalize launch per
+    GroupNorm (same arithmetic, shared code).  (iii) The protocol under concurrency: four lanes' plans running at once, repeated,
+    against the one-lane result.  (iv) A sabotaged ticket counter makes the output NaN -- a missed fold is loud."""
+    import tqdne_amd.engine as E
+    from tqdne_amd import UNetModel, paper_1d_unet_config
+    from test_hip_unet import perturbed_state
+    dev = torch.device("cuda:0")
+    cfg = paper_1d_unet_config()
+    torch.manual_seed(0)
+    m = UNetModel(**cfg)
+    m.load_state_dict(perturbed_state(m, 41))
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(9)
+    B, T = 8, 1024
+    x, t, c = torch.randn(B, 3, T, generator=g).to(dev), (torch.randn(B, generator=g) * 0.5).to(dev), torch.randn(B, 5, generator=g).to(dev)
+    fuse_default = E.GN_FUSE
+    E.GN_FUSE = True   # (the switch is read when a plan is built; off by default: measured neutral, DESIGN.md section 5)
+    eng = m._engine(B, T, dev)
+    engs = [m._engine(B // 4, T, dev, lane=i) for i in range(4)]
+    E.GN_FUSE = fuse_default
+    n_gn = len(eng.gn_bufs) // 3
+    assert eng.gn_fused >= n_gn - 2, (eng.gn_fused, n_gn)   # all but the stem's consumer (and at most one shared source)
+    assert sum(1 for op in eng.ops_infer if op[2] == "gn_finalize") == n_gn - eng.gn_fused
+    with torch.no_grad():
+        y0 = eng.forward(x, t, c, infer=True).clone()
+        eng.poison_gn = True
+        y1 = eng.forward(x, t, c, infer=True).clone()
+        y2 = eng.forward(x, t, c, infer=True).clone()
+        y3 = eng.forward(x, t, c, train=False).clone()      # the backward-capable launch list
+        eng.poison_gn = False
+    assert torch.isfinite(y1).all() and torch.equal(y0, y1) and torch.equal(y0, y2)
+    # (the backward-capable list runs the k = 5 up-sampling convs where inference runs their two-phase k = 3 form: equal to rounding)
+    assert torch.isfinite(y3).all() and float((y3 - y0).abs().max() / y0.abs().max()) < 1e-4
+    # (ii) separate launches: a second model object with fusion off (plans are cached per model)
+    old = E.GN_FUSE
+    try:
+        E.GN_FUSE = False
+        m2 = UNetModel(**cfg)
+        m2.load_state_dict(m.state_dict())
+        m2 = m2.to(dev).eval()
+        e2 = m2._engine(B, T, dev)
+        assert e2.gn_fused == 0
+        with torch.no_grad():
+            ys = e2.forward(x, t, c, infer=True).clone()
+    finally:
+        E.GN_FUSE = old
+    assert torch.equal(y0, ys), "the fused fold must give the coefficients of tq_gn_finalize bit for bit"
+    # (iii) concurrency: 4 lanes x 2 samples at once, three times
+    h = B // 4
+    for e in engs:
+        e.poison_gn = True
+    main = torch.cuda.current_stream(dev)
+    streams = [main] + [E.side_stream(dev, i) for i in range(1, 4)]
+    for rep in range(3):
+        outs = []
+        for s in streams[1:]:
+            s.wait_stream(main)
+        with torch.no_grad():
+            for i, (e, s) in enumerate(zip(engs, streams)):
+                with torch.cuda.stream(s):
+                    outs.append(e.forward(x[i * h:(i + 1) * h].contiguous(), t[i * h:(i + 1) * h].contiguous(),
+                                          c[i * h:(i + 1) * h].contiguous(), infer=True).clone())
+        for s in streams[1:]:
+            main.wait_stream(s)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat(outs), y0), f"repetition {rep}"
+    # (iv) sabotage: one fold's output redirected to a scratch buffer = "this GroupNorm was not finalised": with the poison the
+    # consumer reads NaN coefficients -> NaN output, instead of silently reusing the previous evaluation's numbers
+    from tqdne_amd import _lib
+    eng.poison_gn = True
+    fuse = next(k for k in eng._keep if isinstance(k, _lib.TqGnFuse))
+    real, scratch = fuse.gscale, torch.zeros(B, 1024, device=dev)
+    fuse.gscale = scratch.data_ptr()
+    with torch.no_grad():
+        yb = eng.forward(x, t, c, infer=True).clone()
+    assert not torch.isfinite(yb).all(), "a fold that did not reach its buffer must be visible"
+    fuse.gscale = real
+    with torch.no_grad():
+        yr = eng.forward(x, t, c, infer=True).clone()
+    assert torch.equal(yr, y0)

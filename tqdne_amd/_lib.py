@@ -44,6 +44,12 @@ TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_DROPOUT, TQ_BWD_ACCUM, TQ_BWD_STATS = 1, 2, 4, 8,
 STAT_SLOT = 128
 
 
+class TqGnFuse(C.Structure):
+    _fields_ = [("counters", C.c_void_p), ("partner_stats", C.c_void_p), ("C_partner", C.c_int32), ("partner_first", C.c_int32),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("gscale", C.c_void_p), ("gshift", C.c_void_p),
+                ("mean_rstd", C.c_void_p)]
+
+
 class TqConvDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T_in", C.c_int32), ("T_out", C.c_int32),
@@ -52,7 +58,7 @@ class TqConvDesc(C.Structure):
         ("upsample", C.c_int32), ("flags", C.c_int32), ("emb_stride", C.c_int32),
         ("dropout_site", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("C_skip0", C.c_int32), ("C_skip1", C.c_int32), ("wfmt", C.c_int32),
-        ("range_flag", C.c_void_p),
+        ("range_flag", C.c_void_p), ("gn_fuse", C.POINTER(TqGnFuse)),
     ]
 
 

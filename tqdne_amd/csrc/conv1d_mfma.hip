@@ -28,6 +28,7 @@
 
 #include "common.hpp"
 #include "conv_args.hpp"
+#include "gn_fold.hpp"
 #include <atomic>
 #include "../../include/tqdne_hip.h"
 
@@ -911,11 +912,50 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             }
             if ((lane & 15) == 0 && slot < p.nslots) {
                 float* st = p.stats + (((size_t)b * p.nslots + slot) * Cr + co) * 2;
-                *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
-                *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
+                if (p.gf_counters) {
+                    // fused finalisation: the last-arriving workgroup of sample b reads these pairs in THIS launch -- 8-byte
+                    // agent-scope atomic stores (write-through, global_store_dwordx2 sc1), read back with the matching loads
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned long long u = (unsigned long long)__float_as_uint(s1[cbk][j]) |
+                                                     ((unsigned long long)__float_as_uint(s2[cbk][j]) << 32);
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(st + 2 * j), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
+                    *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
+                }
                 // range guard: max|y| <= sqrt(sum of squares); (65504 / 2)^2 = 1.0727e9.  NaN / inf fail the comparison too
                 const float q = fmaxf(fmaxf(s2[cbk][0], s2[cbk][1]), fmaxf(s2[cbk][2], s2[cbk][3]));
                 if (p.range_flag && !(q < 1.0727e9f)) *p.range_flag = 1;
+            }
+        }
+    }
+    if constexpr (!PW) {
+        if (p.gf_counters) {   // (uniform over the launch; every wave of the workgroup is here: the host refuses ragged channel tiles)
+            // GroupNorm finalisation by the last arriver (TqGnFuse): every storing wave drains its stores, the workgroup meets, ONE
+            // lane takes the sample's ticket (agent-scope atomic add, returning); the workgroup whose ticket completes the sample
+            // -- tickets count up for ever: (ticket + 1) % workgroups-per-sample == 0 -- folds the statistics of that sample.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(lds);
+            if (tid == 0) {
+                const unsigned long long t = __hip_atomic_fetch_add(p.gf_counters + b, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = ((t + 1ull) % (unsigned long long)p.gf_narrive) == 0ull ? 1 : 0;
+            }
+            __syncthreads();
+            const bool last = *flag != 0;
+            __syncthreads();   // (the flag word is part of the fold's scratch)
+            if (last) {
+                const int Cown = poly ? Cr : p.C_out;
+                const int ns = p.nslots;
+                double* sh = reinterpret_cast<double*>(lds);
+                if (p.gf_partner_first)
+                    gn_fold_sample<false, true>(sh, b, p.gf_partner, p.gf_Cp, p.stats, Cown, poly ? 2 * p.T_out : p.T_out, ns, p.gf_gamma,
+                                                p.gf_beta, p.gf_gscale, p.gf_gshift, p.gf_mean_rstd);
+                else
+                    gn_fold_sample<true, false>(sh, b, p.stats, Cown, p.gf_partner, p.gf_Cp, poly ? 2 * p.T_out : p.T_out, ns, p.gf_gamma,
+                                                p.gf_beta, p.gf_gscale, p.gf_gshift, p.gf_mean_rstd);
             }
         }
     }
@@ -1033,6 +1073,17 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     const int n_ttiles = (a.T_out + C::NT - 1) / C::NT;
     const int n_ctiles = (a.C_out + C::MT - 1) / C::MT;
     const unsigned grid = (unsigned)(a.B * n_ttiles * (PW ? 1 : n_ctiles));
+    if (a.gf_counters) {
+        // fused GroupNorm finalisation: every workgroup of a sample takes a ticket -- all its waves must reach the epilogue (no ragged
+        // channel tile) and the fold's scratch (2 C + 64 doubles) must fit the staging buffers it reuses
+        const int Ctot = ((a.flags & TQ_CONV_POLY2) ? a.C_out / 2 : a.C_out) + a.gf_Cp;
+        if (PW || EPI != 0 || (a.C_out % C::MT) || (size_t)(2 * Ctot + 64) * sizeof(double) > (size_t)LDS_BYTES) return TQ_ERR_SHAPE;
+        ConvArgs a2 = a;
+        a2.gf_narrive = n_ttiles * n_ctiles;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), LDS_BYTES, stream, a2);
+        TQ_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), LDS_BYTES, stream, a);
     TQ_CHECK_LAUNCH();
     return 0;
@@ -1194,6 +1245,17 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.wfmt = d->wfmt;
     a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale;
     a.range_flag = d->range_flag;
+    a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
+    a.gf_gamma = a.gf_beta = nullptr; a.gf_gscale = a.gf_gshift = a.gf_mean_rstd = nullptr;
+    if (d->gn_fuse) {
+        const TqGnFuse* g = d->gn_fuse;
+        if (!(d->flags & TQ_CONV_STATS) || kv_planes || !g->counters || !g->gamma || !g->beta || !g->gscale || !g->gshift) return TQ_ERR_ARG;
+        if (g->C_partner < 0 || (g->C_partner > 0 && !g->partner_stats)) return TQ_ERR_ARG;
+        const int Cown = (d->flags & TQ_CONV_POLY2) ? d->C_out / 2 : d->C_out;
+        if ((Cown + g->C_partner) % GN_GROUPS) return TQ_ERR_SHAPE;
+        a.gf_counters = g->counters; a.gf_partner = g->partner_stats; a.gf_Cp = g->C_partner; a.gf_partner_first = g->partner_first;
+        a.gf_gamma = g->gamma; a.gf_beta = g->beta; a.gf_gscale = g->gscale; a.gf_gshift = g->gshift; a.gf_mean_rstd = g->mean_rstd;
+    }
 
     if (d->stride == 2 || d->upsample) {
         if (a.flags & (TQ_CONV_GN | TQ_CONV_SILU | TQ_CONV_DROPOUT)) return TQ_ERR_SHAPE;  // resampling convs take raw inputs
@@ -1253,6 +1315,8 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.wfmt = TQ_WFMT_BF16X3;  // gradients keep fp32 range
     a.kv = nullptr; a.kvH = a.kvD = a.kvTp = 0; a.kvscale = 1.f;
     a.range_flag = nullptr;
+    a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
+    a.gf_gamma = a.gf_beta = nullptr; a.gf_gscale = a.gf_gshift = a.gf_mean_rstd = nullptr;
     switch (d->ktaps) {
         case 1: return dispatch_tile<1, 1, 0, 1, 0>(a, stream);
         case 3: return dispatch_tile<3, 1, 0, 1, 0>(a, stream);

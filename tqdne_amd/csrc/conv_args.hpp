@@ -41,6 +41,15 @@ struct ConvArgs {
     int kvH, kvD, kvTp;
     float kvscale;
     int* range_flag;  // see TqConvDesc.range_flag
+    // fused GroupNorm finalisation (TqConvDesc.gn_fuse): the workgroup that completes a sample's statistics folds them
+    unsigned long long* gf_counters;   // nullptr: off
+    const float* gf_partner;
+    int gf_Cp, gf_partner_first, gf_narrive;
+    const float* gf_gamma;
+    const float* gf_beta;
+    float* gf_gscale;
+    float* gf_gshift;
+    float* gf_mean_rstd;
 };
 
 

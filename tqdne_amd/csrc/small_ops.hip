@@ -3,6 +3,7 @@
 // noise injection / loss, and the fp64 Heun state updates.  All are plain wave64 VALU kernels with
 // 16-byte coalesced accesses; none is GEMM-shaped enough to be worth MFMA.
 #include "common.hpp"
+#include "gn_fold.hpp"
 #include "../../include/tqdne_hip.h"
 
 using namespace tq;
@@ -20,92 +21,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ gscale, float* __restrict__ gshift,
                                                           float* __restrict__ mean_rstd) {
-    // Latency-bound (a few KB per sample): the kernel is three dependent steps, so every global load is issued as early as
-    // possible -- gamma / beta before anything else, a thread's slot loads all together before the first add.
     extern __shared__ double sh[];  // [C][2] channel sums, then [32][2] group mean/rstd
-    const int C = C0 + C1;
-    const int b = blockIdx.x;
-    double* csum = sh;
-    double* gstat = sh + 2 * C;
-    // folded-affine inputs of the last step (<= 2 channels per thread for C <= 512)
-    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int c = threadIdx.x + k * 256;
-        if (c < C) { gam[k] = gamma[c]; bet[k] = beta[c]; }
-    }
-    // thread = (channel, slot part): PARTS threads share one channel's slots so the dependent-load chain is short
-    const int PARTS = (C <= 64) ? 4 : ((C <= 128) ? 2 : 1);
-    for (int idx = threadIdx.x; idx < C * PARTS; idx += blockDim.x) {
-        const int c = idx / PARTS, part = idx % PARTS;
-        const float* st;
-        int cs, cc;
-        if (c < C0) { st = st0; cs = C0; cc = c; } else { st = st1; cs = C1; cc = c - C0; }
-        const float* pp = st + ((size_t)b * nslots * cs + cc) * 2;
-        double s1 = 0.0, s2 = 0.0;
-        int s = part;
-        for (; s + 7 * PARTS < nslots; s += 8 * PARTS) {   // 8 loads in flight
-            float2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(pp + (size_t)(s + u * PARTS) * cs * 2);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
-        }
-        {   // up to 7 left: again all loads first (clamped index, masked add)
-            float2 v[7];
-#pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                const int su = s + u * PARTS;
-                v[u] = *reinterpret_cast<const float2*>(pp + (size_t)(su < nslots ? su : (nslots - 1)) * cs * 2);
-            }
-#pragma unroll
-            for (int u = 0; u < 7; ++u)
-                if (s + u * PARTS < nslots) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
-        }
-        if (PARTS == 1) { csum[2 * c] = s1; csum[2 * c + 1] = s2; }
-        else {
-            // combine the parts of one channel (adjacent lanes)
-            for (int o = 1; o < PARTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            if (part == 0) { csum[2 * c] = s1; csum[2 * c + 1] = s2; }
-        }
-    }
-    __syncthreads();
-    const int G = C / GN_GROUPS;
-    if (threadIdx.x < GN_GROUPS) {
-        const int g = threadIdx.x;
-        double s1 = 0.0, s2 = 0.0;
-        for (int j = 0; j < G; ++j) { s1 += csum[2 * (g * G + j)]; s2 += csum[2 * (g * G + j) + 1]; }
-        const double n = (double)G * (double)T;
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const double rstd = 1.0 / sqrt(var + (double)GN_EPS);
-        gstat[2 * g] = mean;
-        gstat[2 * g + 1] = rstd;
-        if (mean_rstd) {
-            mean_rstd[((size_t)b * GN_GROUPS + g) * 2] = (float)mean;
-            mean_rstd[((size_t)b * GN_GROUPS + g) * 2 + 1] = (float)rstd;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int c = threadIdx.x + k * 256;
-        if (c < C) {
-            const int g = c / G;
-            const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
-            const float a = gam[k] * rstd;
-            gscale[(size_t)b * C + c] = a;
-            gshift[(size_t)b * C + c] = bet[k] - mean * a;
-        }
-    }
-    for (int c = threadIdx.x + 512; c < C; c += 256) {   // wider (concatenated) tensors than the paper configs have: plain loop
-        const int g = c / G;
-        const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
-        const float a = gamma[c] * rstd;
-        gscale[(size_t)b * C + c] = a;
-        gshift[(size_t)b * C + c] = beta[c] - mean * a;
-    }
+    gn_fold_sample<false, false>(sh, blockIdx.x, st0, C0, st1, C1, T, nslots, gamma, beta, gscale, gshift, mean_rstd);
 }
 }  // namespace
 

@@ -48,15 +48,21 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 class Act:
     """A channels-last activation (B, T, C) and, optionally, its per-channel partial statistics."""
 
-    __slots__ = ("buf", "stats", "C", "T", "grad", "gw")
+    __slots__ = ("buf", "stats", "C", "T", "grad", "gw", "prod")
 
     def __init__(self, buf, stats, C, T):
         self.buf, self.stats, self.C, self.T = buf, stats, C, T
+        self.prod = None   # descriptors (TqConvDesc) of the launches that write this tensor and its statistics, if they can fold them
         self.grad = None   # gradient buffer (training plans only)
         self.gw = False    # backward-plan construction: has some op already written the gradient?
 
 
 FUSE_SKIP = os.environ.get("TQDNE_FUSE_SKIP", "1") != "0"  # A/B switch for the fused skip-conv launch
+# GroupNorm finalisation inside the launch that completes the statistics (TqConvDesc.gn_fuse, "last arriver") instead of a
+# tq_gn_finalize launch per GroupNorm: TQDNE_GN_FUSE=1.  Built, parity- and concurrency-tested (tests/test_concurrency.py), and
+# measured NEUTRAL (18-step sample at B = 64, 4 lanes: 165.7 vs 166.0 ms; 1 lane 174.5 vs 172.8; tiny UNet B = 4: 41.9 vs 41.6 ms):
+# what the 49 launches cost comes back as the fold's dependent-load chain on the tail of the producing launch -> off by default
+GN_FUSE = os.environ.get("TQDNE_GN_FUSE", "0") == "1"
 FUSE_SKIP_CO = 32  # smallest output-channel multiple fused (measured: 128 -> +3.9 %, 64 -> +1.3 % more on the bench step)
 
 
@@ -285,6 +291,9 @@ class UNetEngine:
         self.poly_sites: List[Tuple[ConvSite, ConvSite]] = []   # (derived two-phase k = 3 site, the Upsample conv it restates)
         self.dropout_descs: List[TqConvDesc] = []
         self.acts: List[Act] = []
+        self.gn_bufs: List[torch.Tensor] = []   # every GroupNorm's folded coefficients (see poison_gn)
+        self.gn_fused = 0                         # GroupNorms folded inside their producer's launch
+        self.poison_gn = os.environ.get("TQDNE_POISON_GN") == "1"
         self._probe = None
         self.tape = []
         self.last_rec = None
@@ -334,11 +343,30 @@ class UNetEngine:
         self.op_bytes.append(nbytes)
 
     def _gn(self, srcs: Sequence[Act], norm: torch.nn.GroupNorm):
+        """Folded scale / shift (B, C) of a GroupNorm over the (concatenated) sources.  Where the most recent source is written by a
+        conv launch that can do it, the fold rides in that launch (TqGnFuse: the workgroup completing a sample's statistics folds
+        them); otherwise -- the stem's output, a tensor that is already the last source of another GroupNorm -- a tq_gn_finalize
+        launch.  The coefficient buffers are registered in ``gn_bufs`` so that tests can poison them (``poison_gn``): a fold that
+        did not happen then surfaces as NaN instead of as the previous evaluation's (nearly right) coefficients."""
         C_ = sum(s.C for s in srcs)
         gscale, gshift = self._empty(self.B, C_), self._empty(self.B, C_)
         mean_rstd = self._empty(self.B, 32, 2)
+        self.gn_bufs += [gscale, gshift, mean_rstd]
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) > 1 else None
+        prod = s0.prod if GN_FUSE else None
+        if prod and all(not d.gn_fuse for d in prod):
+            for d in prod:   # (one TqGnFuse and one ticket counter per launch form: the forms tile the tensor differently)
+                f = _lib.TqGnFuse()
+                counters = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
+                self._keep += [f, counters]
+                f.counters = counters.data_ptr()
+                f.partner_stats, f.C_partner, f.partner_first = (_p(s1.stats), s1.C, 0) if s1 is not None else (None, 0, 0)
+                f.gamma, f.beta = _p(norm.weight), _p(norm.bias)
+                f.gscale, f.gshift, f.mean_rstd = _p(gscale), _p(gshift), _p(mean_rstd)
+                d.gn_fuse = C.pointer(f)
+            self.gn_fused += 1
+            return gscale, gshift, mean_rstd
         for _ in range(2 if os.environ.get("TQDNE_DUP_GN") == "1" else 1):   # (measurement switch: what do these launches cost?)
             self._emit((self.lib.tq_gn_finalize, (
                 _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
@@ -420,6 +448,7 @@ class UNetEngine:
             infer_op = None
             if (upsample and site.K == 5 and T_in % STAT_SLOT == 0 and site.C_out % 32 == 0 and gn is None and res is None
                     and emb_ptr is None and os.environ.get("TQDNE_POLYPHASE_UPSAMPLE", "1") != "0"):
+                self._poly_desc = None
                 infer_op = self._polyphase_op(site, d, s0, s1, out, flops)
             if qkv_planes is not None:  # (ws, H, D): K / V straight into the attention kernel's pre-split planes
                 ws, H_, D_ = qkv_planes
@@ -427,6 +456,12 @@ class UNetEngine:
                     C.byref(d), _p(s0.buf), _p(gn[0]) if gn else None, _p(gn[1]) if gn else None, _p(site.packed), _p(site.bias),
                     _p(out.buf), _p(ws), H_, D_), "conv:" + site.name + "+split", flops)
             self._emit(op, infer_op, nbytes=nbytes)
+            if stats and qkv_planes is None:   # (its inference form, the two-phase up-sampling conv, is a launch of its own shape)
+                poly = getattr(self, "_poly_desc", None)
+                out.prod = [d] + ([poly] if (infer_op is not None and poly is not None) else [])
+                self._poly_desc = None
+        if launch and skip is not None and stats:
+            out.prod = [d]
         self.last_rec = ConvRec(site, d, list(srcs), gn, out, stride, upsample, silu, dropout_site is not None)
         return out
 
@@ -451,6 +486,7 @@ class UNetEngine:
         if d2.flags & TQ_CONV_STATS:
             d2.range_flag = self.range_flag.data_ptr()
         self._keep.append(d2)
+        self._poly_desc = d2
         return (self.lib.tq_conv1d_fwd, (
             C.byref(d2), _p(s0.buf), _p(s1.buf) if s1 else None, None, None, _p(ps.packed), _p(site.bias), None, None,
             _p(out.buf), _p(out.stats)), "conv:" + site.name + "+polyphase", flops)
@@ -604,6 +640,16 @@ class UNetEngine:
         idx = max((i for i, op in enumerate(self.ops) if op[2].startswith(name_prefix)), key=lambda i: self.ops[i][3])
         self._probe = Probe(idx, self.ops[idx][2], self.ops[idx][3])
         return self._probe
+
+    def _poison(self):
+        """test mode (``poison_gn`` / TQDNE_POISON_GN=1): NaN into every GroupNorm coefficient buffer before a forward, so that a
+        fold that is skipped, raced or mis-addressed is a loud NaN in the output instead of the previous call's coefficients"""
+        if self.poison_gn and not torch.cuda.is_current_stream_capturing():
+            for t in self.gn_bufs:
+                t.fill_(float("nan"))
+            for a in self.acts:   # (the partial statistics too: a fold that ran before its sample was complete reads NaN)
+                if a.stats is not None:
+                    a.stats.fill_(float("nan"))
 
     # ------------------------------------------------------------------ range guard of the fp16-range scheme
     def _set_scheme_bf16x3(self):
@@ -782,6 +828,7 @@ class UNetEngine:
             ncond = cond.shape[1]
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         self._range_poll(True)
+        self._poison()
         self.repack(stream)
         p = float(m.dropout) if train else 0.0
         for d in self.dropout_descs:
@@ -920,6 +967,7 @@ class SeqEngine(UNetEngine):
             raise ValueError(f"plan was built for {(B, m.in_channels, T)}, got {tuple(x.shape)}")
         x = x.contiguous()
         stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self._poison()
         self.repack(stream)
         p = float(getattr(m, "dropout", 0.0)) if train else 0.0
         for d in self.dropout_descs:
