@@ -75,7 +75,9 @@ namespace {
 //      instead of 16 per 64 channels) and the corrections no longer clamp (fp8 with uniform scales saturates beyond |x| = 448 and
 //      |x_l| = 0.109): measured 5e-5 against 7e-4 of the output scale on heavy-tailed data (tools/micro/fp6_scheme_probe.hip).
 //      Staging layout: a thread owns 16 consecutive channels of a row (= exactly one lane fragment of the correction operand).
-template <int KT, int STRIDE, int UPS, int WM, int WN, int SCH = 0>
+// TBW: 16-position blocks per wave along t (8, or 4 for the "slim" 64-channel tile: half the accumulators, so that three or four
+// workgroups share a CU and their load / MFMA / store phases interleave -- see dispatch_tile)
+template <int KT, int STRIDE, int UPS, int WM, int WN, int SCH = 0, int TBW = 8>
 struct Cfg {
     static constexpr int CH = SCH ? 64 : 32;     // channels per chunk
     static constexpr int ROWB = 2 * CH;          // bytes per row of one LDS plane
@@ -83,7 +85,8 @@ struct Cfg {
     static constexpr int NW = SCH ? 8 : 4;       // 16-byte weight fragments per lane and (chunk, tap): 2 co blocks x NW/2
     static constexpr int NBF = SCH ? 4 : 2;      // 16-byte activation fragments per lane and (tap, t-block)
     static constexpr int NTHR = 64 * WM * WN;
-    static constexpr int NT = 128 * WN;  // output positions per workgroup
+    static constexpr int WT = 16 * TBW;  // output positions per wave
+    static constexpr int NT = WT * WN;   // output positions per workgroup
     static constexpr int MT = 32 * WM;   // output channels per workgroup
     static constexpr int ROWS = (STRIDE == 1) ? (NT + KT - 1) : (2 * NT + 1);
     static constexpr int NIT = (ROWS * TPR + NTHR - 1) / NTHR;
@@ -111,12 +114,13 @@ struct Cfg {
 // is staged ONCE into its own LDS buffers with every load in flight together, then the workgroup runs over all output-channel
 // tiles: no per-chunk barrier / load round trip (a 1x1 chunk has 1/5 of the MFMA work to hide one under) and no re-staging of
 // the same rows by 3 channel-tile workgroups (qkv).
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const ConvArgs p) {
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false, int TBW = 8>
+__global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_kernel(const ConvArgs p) {
     static_assert(SCH == 0 || (EPI != 1 && STRIDE == 1), "the fp16-range scheme serves stride-1 forward launches");
+    static_assert(TBW == 8 || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW), "slim tile: bf16x3 forward, 2 x 2 waves");
     static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH >= 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, fp16-range schemes");
     static_assert(SCH != 2 || WN == 1, "scheme 2 tiles are 128 positions wide");
-    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
+    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef TQ_STAMP
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -439,17 +443,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
         }
     };
 
-    f32x4 acc[2][8];
+    f32x4 acc[2][TBW];
     if constexpr (!PW) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     int pw_c0 = 0;  // PW: first chunk of the pair the MFMA stream works on ("taps" of that stream = chunks = LDS buffers)
 
     const int kq = lane >> 4;
-    const int tl_lane = wn * 128 + (lane & 15);
+    const int tl_lane = wn * C::WT + (lane & 15);
     const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * (C::NW / 2)) * 64 + lane;  // (PW: advanced per channel tile)
     const size_t wstep = (size_t)p.ncob_pad * (C::NW / 2) * 64;  // uint4 per (chunk, tap)
 
@@ -580,21 +584,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
     auto mma_stream = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int s0, auto ntaps_c, auto first_tap_c)
         __attribute__((always_inline)) {
         constexpr int NTAPS = decltype(ntaps_c)::value, K0 = decltype(first_tap_c)::value;
-        constexpr int DEP = LDS_DEP, NB = LDS_DEP + 1, NS = NTAPS * 8;
+        constexpr int DEP = LDS_DEP, NB = LDS_DEP + 1, NS = NTAPS * TBW;
         Frag bf[NB][C::NBF];
         int b0 = tap_base(K0), b0n = b0;
 #pragma unroll
         for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bf[t]);
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
-            const int kk = st >> 3, tb = st & 7;
+            const int kk = st / TBW, tb = st % TBW;
             if (tb == 0 && kk + 1 < NTAPS) b0n = tap_base(K0 + kk + 1);
             const int sn = st + DEP;  // step whose fragments are requested now
-            if (sn < NS) read_b(hi_plane, lo_plane, (sn >> 3) == kk ? b0 : b0n, sn & 7, bf[sn % NB]);
+            if (sn < NS) read_b(hi_plane, lo_plane, (sn / TBW) == kk ? b0 : b0n, sn % TBW, bf[sn % NB]);
             __builtin_amdgcn_sched_barrier(0);
             if (kk & 1) mma_step(wb, bf[st % NB], tb); else mma_step(wa, bf[st % NB], tb);
             __builtin_amdgcn_sched_barrier(0);
-            if (tb == 7) {  // tap done: refill its weight buffer two steps of the (chunk, tap) sequence ahead
+            if (tb == TBW - 1) {  // tap done: refill its weight buffer two steps of the (chunk, tap) sequence ahead
                 const int nxt = (NTAPS == 1) ? (s0 + 1) : ((kk + 2 < NTAPS) ? (s0 + kk + 2) : ((kk & 1) ? (s0 + NTAPS + 1) : (s0 + NTAPS)));
                 if (kk & 1) load_w(nxt, wb); else load_w(nxt, wa);
                 b0 = b0n;
@@ -620,8 +624,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_kernel(const Conv
 #pragma unroll
         for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bf[t]);
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
-            if (tb + DEP < 8) read_b(hi_plane, lo_plane, b0, tb + DEP, bf[(tb + DEP) % NB]);
+        for (int tb = 0; tb < TBW; ++tb) {
+            if (tb + DEP < TBW) read_b(hi_plane, lo_plane, b0, tb + DEP, bf[(tb + DEP) % NB]);
             __builtin_amdgcn_sched_barrier(0);
             mma_step(wa, bf[tb % NB], tb);
             __builtin_amdgcn_sched_barrier(0);
@@ -817,8 +821,8 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             add[cbk] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
-            const int t = t0 + wn * 128 + tb * 16 + (lane & 15);
+        for (int tb = 0; tb < TBW; ++tb) {
+            const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
             if (t < p.T_out) {
 #pragma unroll
                 for (int cbk = 0; cbk < 2; ++cbk) {
@@ -852,7 +856,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
     const int Cr = poly ? (p.C_out >> 1) : p.C_out;
     const int ph = (poly && co_wave >= Cr) ? 1 : 0;
     const int co_real = co_wave - ph * Cr;
-    const int slot = poly ? 2 * ((t0 >> 7) + wn) + ph : (t0 >> 7) + wn;
+    const int slot = poly ? 2 * ((t0 >> 7) + wn) + ph : (t0 >> 7) + (TBW == 8 ? wn : 0);
     const float* emb_b = (p.flags & TQ_CONV_EMB) ? p.emb + (size_t)b * p.emb_stride : nullptr;
     // The two 16-channel blocks of a wave are the two 64-byte halves of one 128-byte output line: they are stored back to back
     // (t-block outer, channel block inner).  With the channel block as the outer loop the halves reached L2 microseconds apart
@@ -876,8 +880,8 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
         for (int j = 0; j < 4; ++j) { s1[cbk][j] = 0.f; s2[cbk][j] = 0.f; }
     }
 #pragma unroll
-    for (int tb = 0; tb < 8; ++tb) {
-        const int t = t0 + wn * 128 + tb * 16 + (lane & 15);
+    for (int tb = 0; tb < TBW; ++tb) {
+        const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
         if (t < p.T_out) {
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk) {
@@ -901,7 +905,6 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
     if (p.flags & TQ_CONV_STATS) {
 #pragma unroll
         for (int cbk = 0; cbk < 2; ++cbk) {
-            const int co = co_real + cbk * 16 + 4 * (lane >> 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -910,7 +913,30 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                     s2[cbk][j] += __shfl_xor(s2[cbk][j], o);
                 }
             }
-            if ((lane & 15) == 0 && slot < p.nslots) {
+        }
+        if constexpr (TBW == 4) {
+            // slim tile: the two waves of a channel half cover the two 64-position halves of ONE 128-position statistics slot; the
+            // second one hands its sums over through LDS (the staging buffers are idle) and the first one stores the slot's total
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(lds) + (wm * 4 + (lane >> 4)) * 16;   // [wm][kq][cbk][j][2]
+            if (wn == 1 && (lane & 15) == 0) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { red[(cbk * 4 + j) * 2] = s1[cbk][j]; red[(cbk * 4 + j) * 2 + 1] = s2[cbk][j]; }
+            }
+            __syncthreads();
+            if (wn == 0 && (lane & 15) == 0) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s1[cbk][j] += red[(cbk * 4 + j) * 2]; s2[cbk][j] += red[(cbk * 4 + j) * 2 + 1]; }
+            }
+        }
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+            const int co = co_real + cbk * 16 + 4 * (lane >> 4);
+            if ((lane & 15) == 0 && slot < p.nslots && (TBW == 8 || wn == 0)) {
                 float* st = p.stats + (((size_t)b * p.nslots + slot) * Cr + co) * 2;
                 if (p.gf_counters) {
                     // fused finalisation: the last-arriving workgroup of sample b reads these pairs in THIS launch -- 8-byte
@@ -983,8 +1009,8 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             for (int j = 0; j < 4; ++j) { s1[cbk][j] = 0.f; s2[cbk][j] = 0.f; }
         }
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
-            const int t = t0 + wn * 128 + tb * 16 + (lane & 15);
+        for (int tb = 0; tb < TBW; ++tb) {
+            const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
             if (t < p.T_out) {
 #pragma unroll
                 for (int cbk = 0; cbk < 2; ++cbk) {
@@ -1050,10 +1076,10 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
 #endif
 }
 
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH = 0, bool PW = false>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH = 0, bool PW = false, int TBW = 8>
 int launch(const ConvArgs& a, hipStream_t stream) {
-    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH>;
-    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW>;
+    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW, TBW>;
     // scheme 2 keeps the folded GroupNorm coefficients of the workgroup's sample behind the staging buffers (2 x C_in floats)
     constexpr int GTAB_MAX = (SCH == 2 && ACT >= 1) ? 2 * 4 * 1024 : 0;   // room for C_in <= 1024
     constexpr int LDS_BYTES = (PW ? 4 * C::BUF : C::LDS_BYTES) + GTAB_MAX;
@@ -1130,6 +1156,17 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     }
     if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE>(a, s);
     if constexpr (STRIDE == 1) {
+        if constexpr (UPS == 0 && EPI == 0 && KT == 5 && ACT != 3) {   // (the dropout prologue spills in this tile: training keeps 64 x 256)
+            // 64-channel outputs at T = 4096 are bound by their load / store bursts, not by MFMA cycles (section 5 of DESIGN.md).
+            // The slim tile (64 channels x 128 positions, 32 accumulator registers per wave, 152-168 registers) lets three
+            // workgroups share a CU instead of two.  Measured (tools/slim_ab.py, B = 64, same box, bit-identical outputs): SLOWER --
+            // 64 -> 64: 52-55 vs 50 us, 64+64 -> 64: 90 vs 82, 128+64 -> 64: 118-123 vs 115: 2048 tiles on 768 slots are 2.7 rounds
+            // where 1024 tiles on 512 slots are exactly 2, and every tile re-streams the weights and 4 halo rows for half the
+            // positions.  Off by default; TQDNE_CONV_SLIM=1 selects it.
+            static const int slim = [] { const char* e = getenv("TQDNE_CONV_SLIM"); return (e && e[0] == '1') ? 1 : 0; }();
+            if (slim && a.C_out % 64 == 0 && !(a.flags & TQ_CONV_POLY2))
+                return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT, FUSE, 0, false, 4>(a, s);
+        }
         if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT, FUSE>(a, s);
         return launch<KT, STRIDE, UPS, 1, 2, EPI, ACT, FUSE>(a, s);
     } else {
