@@ -179,3 +179,33 @@ def test_range_guard_in_a_training_loop_drops_the_offending_step():
     assert torch.isfinite(w_after).all(), "no inf / NaN may reach the weights"
     assert not torch.equal(w_after, w_before), "training continues once the plans are on bf16x3"
     assert all(d.wfmt == 0 for d, _, _ in eng._wfmt_sites)
+
+
+def test_graph_replayed_sampler_follows_weight_updates():
+    """the sampler's HIP graphs read the packed weight fragments at fixed addresses: after optimizer steps a replay must run on the
+    NEW weights (re-packed before the replay), i.e. equal the eager sampler bit for bit"""
+    from tqdne_amd import LightningEDM, rng
+    from tqdne_amd.trainer import DataParallelTrainer
+    sd, d = load_golden("micro_unet.npz")
+    cfg = cfg_of(d)
+    dev = torch.device("cuda:0")
+    edm = LightningEDM(cfg, {"learning_rate": 5e-3, "max_steps": 50, "eta_min": 0.0}, num_sampling_steps=6)
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev)
+    rng.seed_rank(3, 0)
+    tr = DataParallelTrainer(edm, world_size=1, fused_optimizer=True)
+    g = torch.Generator().manual_seed(7)
+    batch = {"signal": (0.5 * torch.randn(2, 3, 256, generator=g)).to(dev), "cond": torch.randn(2, 5, generator=g).to(dev)}
+    sig = edm.edm.sampling_sigmas(6).to(dev)
+    eps = (torch.randn(2, 3, 256, generator=g, dtype=torch.float64) * float(sig[0])).to(dev)
+    edm.eval()
+    first = {m: edm.sample_deterministically(eps, sig, None, batch["cond"], use_graph=m).clone() for m in (True, "denoiser")}   # capture
+    for _ in range(3):
+        edm.train()
+        tr.train_step(batch)
+    edm.eval()
+    eager = edm.sample_deterministically(eps, sig, None, batch["cond"], use_graph=False)
+    for mode in (True, "denoiser"):
+        again = edm.sample_deterministically(eps, sig, None, batch["cond"], use_graph=mode)
+        assert not torch.equal(again, first[mode]), "three optimizer steps at lr 5e-3 must move the sample"
+        assert torch.equal(again, eager), f"graph mode {mode!r} replayed stale packed weights"

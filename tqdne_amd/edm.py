@@ -448,6 +448,9 @@ class LightningEDM(LightningModule):
                 run.release()
             st["graph"] = graph
             bufs["loop_graph"] = g = st
+        # the captured launches read the model's packed weight fragments at fixed addresses: bring them up to date with the parameters
+        # (an optimizer step since the last call) BEFORE the replay -- inside a forward this is the first thing eng.forward does
+        eng.repack(th.cuda.current_stream(dev).cuda_stream)
         g["sig"].copy_(sigmas)
         g["start"].copy_(eps)
         if cond is not None:
@@ -477,7 +480,8 @@ class LightningEDM(LightningModule):
         elem = slot.element_size()
 
         def run(sig_ptr):
-            # device-to-device copy of the 4-byte sigma into the captured slot, then replay
+            # (packed weights first: see _graph_sample) device-to-device copy of the 4-byte sigma into the captured slot, then replay
+            eng.repack(th.cuda.current_stream(slot.device).cuda_stream)
             _lib_memcpy_d2d(slot.data_ptr(), sig_ptr, elem, th.cuda.current_stream(slot.device).cuda_stream)
             graph.replay()
             return out
