@@ -377,3 +377,44 @@ def test_pack_jobs_equals_one_pack_per_tensor():
     for (shape, mode), r, o in zip(shapes, refs, outs):
         assert torch.equal(r, o), (shape, mode)
     assert torch.equal(dst[3:], src) and float(dst[:3].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("switch", ["TQDNE_CONV_W4", "TQDNE_CONV_SLIM"])
+def test_opt_in_conv_kernels_in_a_child_process(switch):
+    """The two conv kernels of round 3 that stay behind switches (read once per process): the one-wave-per-SIMD kernel
+    (csrc/conv1d_w4.hip, inline-asm MFMA blocks) and the slim 64-channel tile -- each against fp64 PyTorch on the CPU in a child
+    process with its switch on, ragged length, concat sources, GroupNorm + SiLU prologue, emb add, statistics."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tqdne_amd import ops, _lib
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(5)
+worst = 0.0
+for (C0, C1, Co, T, wf) in [(256, 0, 256, 300, 2), (128, 128, 128, 520, 2), (256, 128, 256, 128, 2), (64, 0, 64, 300, 0), (128, 64, 64, 257, 0)]:
+    B, K = 3, 5
+    x0 = torch.randn(B, T, C0, generator=g); x1 = torch.randn(B, T, C1, generator=g) if C1 else None
+    w = torch.randn(Co, C0 + C1, K, generator=g) / (K * (C0 + C1)) ** 0.5
+    bias = torch.randn(Co, generator=g); emb = torch.randn(B, Co, generator=g)
+    gs = torch.rand(B, C0 + C1, generator=g) + 0.5; gh = torch.randn(B, C0 + C1, generator=g)
+    y, st = ops.conv1d(x0.to(dev), w.to(dev), bias.to(dev), x1=None if x1 is None else x1.to(dev), gscale=gs.to(dev), gshift=gh.to(dev),
+                       silu=True, emb=emb.to(dev), stats=True, wfmt=wf)
+    xin = torch.cat([x0] + ([x1] if x1 is not None else []), dim=2).double()
+    a = torch.nn.functional.silu(xin * gs[:, None, :].double() + gh[:, None, :].double())
+    ref = torch.nn.functional.conv1d(a.permute(0, 2, 1), w.double(), bias.double(), padding=K // 2) + emb.double()[:, :, None]
+    e = float((y.cpu().double().permute(0, 2, 1) - ref).abs().max() / ref.abs().max())
+    s_ref = ref.permute(0, 2, 1)
+    s1 = torch.stack([s_ref[:, i:i + 128].sum(1) for i in range(0, T, 128)], 1)
+    es = float((st.cpu().double()[..., 0] - s1).abs().max() / s1.abs().max())
+    worst = max(worst, e, es)
+    print(C0, C1, Co, T, "rel err", e, "stats", es)
+assert worst < 1e-4, worst
+print("OK")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{switch: "1"}), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-3000:]

@@ -92,7 +92,9 @@ for k in res[("check", "1")]:
     y0, s0 = res[("check", "0")][k]
     same = torch.equal(y1, y0) and torch.equal(s1, s0)
     err = float((y1 - y0).abs().max() / y0.abs().max())
-    print(f"check {k}: bit-identical {same}; max rel diff {err:.2e}; finite {bool(torch.isfinite(y1).all())}")
+    serr = float((s1 - s0).abs().max() / s0.abs().max())
+    print(f"check {k}: bit-identical {same} (outputs {torch.equal(y1, y0)}, statistics {torch.equal(s1, s0)}); max rel diff outputs {err:.2e}, "
+          f"statistics {serr:.2e}; finite {bool(torch.isfinite(y1).all())}")
     ok = ok and same
 for k in res[("time", "1")]:
     t1, t0 = res[("time", "1")][k], res[("time", "0")][k]

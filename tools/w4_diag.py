@@ -1,0 +1,50 @@
+import sys, os, torch
+sys.path.insert(0, "/root/repo")
+from tqdne_amd import ops, _lib
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(5)
+B, T, C0, Co, K = 2, 384, 256, 256, 5
+x0 = torch.randn(B, T, C0, generator=g); w = torch.randn(Co, C0, K, generator=g) / (K * C0) ** 0.5
+bias = torch.randn(Co, generator=g); gs = torch.rand(B, C0, generator=g) + 0.5; gh = torch.randn(B, C0, generator=g)
+y, st = ops.conv1d(x0.to(dev), w.to(dev), bias.to(dev), gscale=gs.to(dev), gshift=gh.to(dev), silu=True, stats=True, wfmt=2)
+a = torch.nn.functional.silu(x0.double() * gs[:, None, :].double() + gh[:, None, :].double())
+ref = torch.nn.functional.conv1d(a.permute(0, 2, 1), w.double(), bias.double(), padding=2).permute(0, 2, 1)
+err = (y.cpu().double() - ref).abs() / ref.abs().max()
+print("W4=", os.environ.get("TQDNE_CONV_W4"), "max", float(err.max()), "rms", float(err.pow(2).mean().sqrt()))
+et = err.amax(dim=(0, 2))   # per position
+print("per-position max err, first 12:", [f"{v:.1e}" for v in et[:12].tolist()], " around 126..134:", [f"{v:.1e}" for v in et[124:136].tolist()])
+ec = err.amax(dim=(0, 1))
+print("per-channel max err: min %.1e max %.1e" % (float(ec.min()), float(ec.max())))
+tm = err.amax(dim=(0, 2))
+big = (tm > 1.2e-5).nonzero().flatten().tolist()
+print("positions with err > 1.2e-5:", big[:60], "count", len(big))
+b_, t_, c_ = [int(v) for v in (err == err.max()).nonzero()[0]]
+print("argmax at b, t, co =", b_, t_, c_, " y", float(y[b_, t_, c_]), "ref", float(ref[b_, t_, c_]))
+# which input rows could be off: recompute with one input row zeroed? cheaper: error by input-row parity via finite difference is overkill
+torch.save(y.cpu(), f"/tmp/w4diag_{os.environ.get('TQDNE_CONV_W4')}.pt")
+rowmax = a.abs().amax(dim=2)   # (B, T)
+print("row max |a| overall: median %.2f, max %.2f" % (float(rowmax.median()), float(rowmax.max())))
+for t_in in (240, 277, 349):
+    blk = a[0, t_in].abs().reshape(-1, 16).amax(1)
+    print("input row", t_in, "block maxima (16 blocks):", [f"{v:.1f}" for v in blk.tolist()])
+if os.path.exists("/tmp/w4diag_1.pt") and os.path.exists("/tmp/w4diag_0.pt"):
+    y1, y0 = torch.load("/tmp/w4diag_1.pt").double(), torch.load("/tmp/w4diag_0.pt").double()
+    e1 = ((y1 - ref).abs() / ref.abs().max()).amax(dim=(0, 2)); e0 = ((y0 - ref).abs() / ref.abs().max()).amax(dim=(0, 2))
+    for t_ in (236, 238, 240, 242, 244, 277, 349):
+        print("t", t_, "err w4 %.1e old %.1e" % (float(e1[t_]), float(e0[t_])))
+if os.environ.get("TQDNE_CONV_W4") == "1":
+    # which input element is off?  the output error around t is  sum_{ci, k} w[co, ci, k] * dx[t + k - 2, ci]; assume only input row t
+    # is wrong: rows t-2..t+2 see it through taps k = 4..0 -> least squares for dx[t, :]
+    tmax = ((y.cpu().double() - ref).abs() / ref.abs().max())
+    for bb in range(B):
+        et_b = tmax[bb].amax(dim=1)
+        rows = [t_ for t_ in range(2, T - 2) if et_b[t_] > 1.2e-5 and et_b[t_] == et_b[t_ - 2:t_ + 3].max()]
+        for t_ in rows:
+            E = (y.cpu().double() - ref)[bb, t_ - 2:t_ + 3]
+            A_ = torch.cat([w.double()[:, :, 4 - i] for i in range(5)], dim=0)
+            sol = torch.linalg.lstsq(A_, E.reshape(-1, 1)).solution.flatten()
+            c_ = int(sol.abs().argmax())
+            av = float(a[bb, t_, c_]); hv = float(torch.tensor(av, dtype=torch.float32).half().float())
+            blk = a[bb, t_, (c_ // 16) * 16:(c_ // 16) * 16 + 16]
+            print(f"b {bb} row {t_}: channel {c_} (chunk {c_ // 64}, block {c_ // 16 % 4}, j {c_ % 16}) dx {float(sol[c_]):+.3e}  a {av:+.5f}  a - fp16(a) {av - hv:+.3e}"
+                  f"  block max |a| {float(blk.abs().max()):.3f}  tile row {t_ % 128 + 2}")

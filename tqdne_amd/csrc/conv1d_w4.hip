@@ -170,6 +170,12 @@ __global__ __launch_bounds__(256, 1) void conv1d_w4_kernel(const ConvArgs p) {
         } else {
             u = u * (ACT >= 2 ? (pad1[k] == 1.0f ? 1.0f : 0.0f) : pad1[k]);
         }
+        // ONE fp16 rounding of the fp32 value u, used by the main plane AND by the remainder below.  Without the barrier hipcc
+        // contracts "u = a * b; (half)u" into v_fma_mixlo_f16(a, b, 0) -- the fp16 rounding of the EXACT product -- for one of the two
+        // uses only; when fl32(a * b) is an exact tie between two fp16 numbers the two roundings differ, the remainder is then
+        // taken against the wrong neighbour and that element is off by a whole fp16 ulp (found as 3e-5 output errors on ~1 input
+        // row in 200, tools/w4_diag.py).
+        asm volatile("" : "+v"(u));
         const _Float16 hh = (_Float16)u;   // |x| > 65504 -> inf, NaN stays NaN: out-of-range inputs surface in the output
         if constexpr (j < 8) h0[j] = hh; else h1[j - 8] = hh;
         const float r = fmaf((float)hh, -4096.f, u * 4096.f);   // (x - fp16(x)) * 2^12, exact
