@@ -291,6 +291,36 @@ def test_attention_peaked_softmax():
         assert rel_err(ncw(ops.attention(cl(qkv), H, workspace=ws)), ref) < TOL
 
 
+@pytest.mark.parametrize("trend", ["rising", "falling", "offset"])
+def test_attention_reference_level_moves(trend):
+    """The forward kernel keeps a lazy softmax reference level per query (it only moves when a key tile's maximum exceeds it by
+    2^6): scores that climb by tens of nats from key tile to key tile move it in every tile, falling ones never after the first,
+    and a large common offset (all scores ~ -80 or +80 nats) must not under- or overflow the first tile."""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, D, T = 2, 2, 64, 500
+    qkv = torch.randn(B, 3 * H * D, T, generator=g)
+    q, k, v = [t.clone() for t in qkv.chunk(3, dim=1)]
+    u = torch.randn(H * D, generator=g)
+    u = u / u.reshape(H, D).norm(dim=1).repeat_interleave(D)  # unit vector per head
+    ramp = torch.linspace(-1, 1, T)
+    if trend == "offset":
+        q = q * 0.3 + 8.0 * u[None, :, None]
+        k = k * 0.3 + 80.0 * u[None, :, None] * torch.tensor([1.0, -1.0]).repeat_interleave(D)[None, :, None]  # head 0: +80 nats, head 1: -80
+    else:
+        q = q * 0.3 + 8.0 * u[None, :, None]
+        k = k * 0.3 + 60.0 * u[None, :, None] * (ramp if trend == "rising" else -ramp)[None, None, :]
+    qkv = torch.cat([q, k, v], 1)
+    sc = 1 / math.sqrt(math.sqrt(D))
+    w = torch.einsum("bct,bcs->bts", (q.double() * sc).reshape(B * H, D, T), (k.double() * sc).reshape(B * H, D, T))
+    assert w.abs().max() > 50  # the case is what it claims to be
+    ref = torch.einsum("bts,bcs->bct", torch.softmax(w, dim=-1), v.double().reshape(B * H, D, T)).reshape(B, -1, T).float()
+    out, lse = ops.attention(cl(qkv), H, return_lse=True)
+    assert torch.isfinite(out).all() and torch.isfinite(lse).all()
+    assert rel_err(ncw(out), ref) < TOL
+    assert rel_err(lse.cpu().reshape(B * H, T), torch.logsumexp(w, dim=-1).float(), elem=False) < 1e-5
+
+
 @pytest.mark.parametrize("cin,cout,T", [(3, 64, 4096), (3, 32, 250), (6, 64, 4064), (16, 64, 512)])
 def test_stem(cin, cout, T):
     from tqdne_amd import ops

@@ -224,12 +224,24 @@ int launch_attn(const float* qkv, float* out, float* lse, int B, int T, int H, h
 //     is then a pure 16-byte copy (the first-generation kernel re-did the split in each of the T/64 query tiles);
 //   * 128 queries per workgroup (32 per wave), so each staged key tile feeds twice the MFMA work;
 //   * scores are computed transposed, S^T = K Q^T: the accumulator lane then holds 4 consecutive keys of ONE query,
-//     which is exactly an A-operand fragment of the P V product once the k-slots of a 32-key step are permuted as
+//     which is exactly an operand fragment of the P V product once the k-slots of a 32-key step are permuted as
 //     key(g, j) = 16*(j>>2) + 4*g + (j&3).  V is read with ds_read_b64_tr_b16 from its row-major image with the same
 //     permutation, so P never goes through LDS and V is never transposed;
-//   * softmax reductions: 15 in-lane max/adds + 2 cross-lane steps (lanes l, l^16, l^32) per query.
+//   * round 3: the output is accumulated transposed as well (O^T = V^T P^T, same fragments with the MFMA operands swapped), so a
+//     lane's accumulators all belong to ONE query: the softmax bookkeeping is per lane (no shuffles in the loop), the lane stores
+//     16 contiguous bytes per channel block, and the row sum's cross-lane reduction happens once, after the loop;
+//   * round 3: lazy reference level instead of a running maximum (see the comment at m_ref): the score accumulators start at
+//     -m_ref, p = exp2(accumulator) with no subtraction, and the O rescale exists only on a rarely taken wave-uniform path;
+//   * round 3: the staging loads are asm statements (att_load): hipcc sank plain loads to the end of the iteration.
+//     Same box, B = 64, T = 512, 4 x 64, kernel only (tools/att_ab.sh): 62 -> 57 us.  Ablation builds (-DTQ_ATT_ABL_*) of this
+//     kernel: no MFMAs 45 us, MFMAs only 42.5 us (pipe floor 24.6 us at 2 GHz), no staging 51 us, no LDS reads 55 us: the phases
+//     of a wave serialise (SQ counters: VALU active 36 %, MFMA busy 34 %, 26 % in s_waitcnt), and 12 us are the two rounds'
+//     prologues and epilogues.
 // LDS rows are padded by 32 bytes: conflict-free for the b128 K reads and the transposed V reads (all D).
 // -------------------------------------------------------------------------------------------------
+#ifndef ATT_QB
+#define ATT_QB 2  // 16-query blocks per wave of the forward kernel
+#endif
 namespace {
 typedef short s16x4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 tr_read_f(const unsigned char* p) {
@@ -273,7 +285,10 @@ __global__ void attn_prep_kernel(const float* __restrict__ qkv, unsigned char* _
     *reinterpret_cast<bf16x4*>(base + 3 * plane) = vl;
 }
 
-// staging vector i = tid + it*256 -> (plane, row, 16-byte column) of one 64-key tile of the pre-split K/V planes
+// staging vector i = tid + it*256 -> (plane, row, 16-byte column) of one 64-key tile of the pre-split K/V planes.
+// The loads are asm statements: hipcc sinks ordinary loads from the top of the key-tile iteration to their only use at its end
+// (`tools/pmc_attention.sh`: the waves then spent half of their life in s_waitcnt vmcnt), and neither sched_barrier nor the source
+// order stops that IR-level move.  The price: hipcc does not count them, so `att_wait` must stand before the first use.
 template <int D, int NIT>
 __device__ __forceinline__ void att_load(uint4 (&stg)[NIT], const unsigned char* kvb, size_t gplane, int kt, int tid) {
     constexpr int V16 = D / 8;
@@ -282,9 +297,11 @@ __device__ __forceinline__ void att_load(uint4 (&stg)[NIT], const unsigned char*
         const int i = tid + it * 256;
         const int pl = i / (64 * V16), rem = i % (64 * V16);
         const int row = rem / V16, c16 = rem % V16;
-        stg[it] = *reinterpret_cast<const uint4*>(kvb + pl * gplane + ((size_t)(kt * 64 + row) * D) * 2 + c16 * 16);
+        const unsigned char* src = kvb + pl * gplane + ((size_t)(kt * 64 + row) * D) * 2 + c16 * 16;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[it]) : "v"(src));
     }
 }
+__device__ __forceinline__ void att_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int D, int NIT>
 __device__ __forceinline__ void att_write(const uint4 (&stg)[NIT], unsigned char* buf, int, int tid) {
     constexpr int V16 = D / 8;
@@ -314,7 +331,7 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv,
                                                                 float* __restrict__ out, float* __restrict__ lse, int T, int Tp,
                                                                 int H, float scale) {
-    constexpr int KS = D / 32, CB = D / 16, QB = 2;
+    constexpr int KS = D / 32, CB = D / 16, QB = ATT_QB;
     constexpr int ROWB = 2 * D + 32;
     constexpr int PLANE = 64 * ROWB;
     constexpr int BUFB = 4 * PLANE;          // one LDS buffer: K hi, K lo, V hi, V lo
@@ -326,15 +343,18 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
     if (tid == 0 && blockIdx.x < 4096) tq_att_timeline[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
 #endif
     ATT_T(0)
+#ifdef TQ_ATT_SKEW
+    if ((blockIdx.x >> 8) & 1) { for (int i = 0; i < TQ_ATT_SKEW; ++i) __builtin_amdgcn_s_sleep(16); }
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int nqt = (T + 127) / 128;
+    const int nqt = (T + 64 * ATT_QB - 1) / (64 * ATT_QB);
     int bid = xcd_group_id(blockIdx.x, nqt, gridDim.x / nqt);  // the tiles of one (b, h) share an XCD's L2
     const int qt = bid % nqt; bid /= nqt;
     const int h = bid % H;
     const int b = bid / H;
     const int C3 = 3 * H * D;
-    const int q0w = qt * 128 + wave * 32;
+    const int q0w = qt * (64 * ATT_QB) + wave * (16 * ATT_QB);
 
     const float qscale = scale * 1.44269504088896341f;  // scores in log2 units
     // Q as the B operand of S^T = K Q^T: lane (col = query li, k = 8*g + j)
@@ -357,11 +377,21 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
     if (__builtin_amdgcn_readfirstlane(qh[0][0].u.x ^ ql[1][1].u.y) == 0x12345) return;  // (forces the Q loads to land before the stamp)
 #endif
     ATT_T(1)
+    // O is accumulated transposed (O^T = V^T P^T: rows = channels 4g + r of a block, column = query li), so everything per query
+    // -- reference level, row sum, normalisation -- is per LANE and needs no shuffle.
     f32x4 o[QB][CB];
-    float m_run[QB], l_run[QB];
+    // Lazy reference level: scores leave the MFMAs already relative to m_ref (the accumulators START at -m_ref), p = exp2 of that,
+    // and m_ref only moves when a tile's maximum exceeds it by more than REF_TH (wave-uniform slow path; always on the first
+    // tile).  After tile 0, m_ref is some earlier tile's true row maximum, so the running maximum lies in [m_ref, m_ref + REF_TH]:
+    // p <= 2^REF_TH and the row sum >= 1 -- no overflow, no underflow.  The four lanes (li, li + 16 g) of a query always move
+    // m_ref together, so their partial row sums share one reference and are added once, after the loop.
+    constexpr float REF_TH = 6.0f;
+    float m_ref[QB], l_part[QB];
+    f32x4 mneg[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+        m_ref[qb] = 0.f; l_part[qb] = 0.f;
+        mneg[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) o[qb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -372,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
     {
         uint4 stg[NIT];
         att_load<D, NIT>(stg, kvb, gplane, 0, tid);
+        att_wait();
         att_write<D, NIT>(stg, lds, 0, tid);
     }
     __syncthreads();
@@ -384,92 +415,89 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
         const unsigned char* v_hi = k_hi + 2 * PLANE;
         const unsigned char* v_lo = k_hi + 3 * PLANE;
         uint4 stg[NIT];
+#ifndef TQ_ATT_ABL_NOSTAGE
         att_load<D, NIT>(stg, kvb, gplane, more ? kt + 1 : kt, tid);  // in flight under this tile's MFMAs, written to the other buffer afterwards
-        // ---- S^T tiles: st[kb][qb], lane holds keys kb*16 + 4g + r of query qb*16 + li
+#endif
+        // ---- S^T tiles: st[kb][qb], lane holds (score - m_ref) of keys kb*16 + 4g + r, query qb*16 + li
         f32x4 st[4][QB];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) st[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qb = 0; qb < QB; ++qb) st[kb][qb] = mneg[qb];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 Frag ah, al;
                 const int off = (kb * 16 + li) * ROWB + (ks * 4 + g) * 16;
+#ifdef TQ_ATT_ABL_NOLDS
+                ah.u = make_uint4(off, kt, off ^ 0x3f803f80, 0x3f803f80); al.u = make_uint4(kt, off, 0x3c003c00, off);
+#else
                 ah.u = *reinterpret_cast<const uint4*>(k_hi + off);
                 al.u = *reinterpret_cast<const uint4*>(k_lo + off);
+#endif
 #pragma unroll
+#ifdef TQ_ATT_ABL_NOS
+                for (int qb = 0; qb < QB; ++qb) st[kb][qb] += f32x4{ah.v[0], al.v[1], ah.v[2], al.v[3]} * (float)qh[qb][ks].v[0];
+#else
                 for (int qb = 0; qb < QB; ++qb) st[kb][qb] = mfma_x3(ah.v, al.v, qh[qb][ks].v, ql[qb][ks].v, st[kb][qb]);
+#endif
             }
         }
-        // ---- online softmax per query (lane column), keys spread over kb, r (in-lane) and g (lanes li + 16 g); scores are in
-        //      log2 units (log2 e is folded into Q's scale), so p = exp2(s - m) is one v_sub + one v_exp
-        float alpha[QB];
-        if (s0 + 64 <= T) {  // full key tile (every tile when 64 | T): no masking, every score finite
+        if (s0 + 64 > T) {  // ragged last tile: keys >= T get -inf, i.e. p = 0
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                float mx = st[0][qb][0];
+            for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run[qb], mx);
-                alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);  // exp2(-inf) = 0 on the first tile
-                float rs = 0.f;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - m_new);
-                        st[kb][qb][r] = pv;
-                        rs += pv;
-                    }
-                rs += __shfl_xor(rs, 16);
-                rs += __shfl_xor(rs, 32);
-                l_run[qb] = l_run[qb] * alpha[qb] + rs;
-                m_run[qb] = m_new;
-            }
-        } else {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 4; ++r)
                         if (s0 + kb * 16 + 4 * g + r >= T) st[kb][qb][r] = -INFINITY;
-                        mx = fmaxf(mx, st[kb][qb][r]);
-                    }
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run[qb], mx);
-                alpha[qb] = (m_run[qb] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-                float rs = 0.f;
+        }
+        // ---- lane maxima; does any query of the wave need a new reference?
+        float mx[QB];
+        bool need = kt == 0;
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
+        for (int qb = 0; qb < QB; ++qb) {
+            mx[qb] = st[0][qb][0];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = (st[kb][qb][r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[kb][qb][r] - m_new);
-                        st[kb][qb][r] = pv;
-                        rs += pv;
-                    }
-                rs += __shfl_xor(rs, 16);
-                rs += __shfl_xor(rs, 32);
-                l_run[qb] = l_run[qb] * alpha[qb] + rs;
-                m_run[qb] = m_new;
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx[qb] = fmaxf(mx[qb], st[kb][qb][r]);
+            need = need || (mx[qb] > REF_TH);
+        }
+        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float full = fmaxf(mx[qb], __shfl_xor(mx[qb], 16));
+                full = fmaxf(full, __shfl_xor(full, 32));  // finite: tile 0 has key 0, later tiles only raise
+                const float delta = kt == 0 ? full : fmaxf(full, 0.f);
+                const float alpha = kt == 0 ? 0.f : __builtin_amdgcn_exp2f(-delta);  // (tile 0: O and the row sum are still zero)
+                m_ref[qb] += delta;
+                mneg[qb] = f32x4{-m_ref[qb], -m_ref[qb], -m_ref[qb], -m_ref[qb]};
+                l_part[qb] *= alpha;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) o[qb][cb] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) st[kb][qb] -= delta;
             }
         }
-        // ---- rescale O (rows = queries 4g + r of the block: fetch their alpha from the lane that owns that query)
+        // ---- p = exp2(score - m_ref), lane-partial row sums
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
+        for (int qb = 0; qb < QB; ++qb) {
+            float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ar = __shfl(alpha[qb], 4 * g + r);
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) o[qb][cb][r] *= ar;
-            }
-        // ---- O += P V, k-slot (g, j) of a 32-key step <-> key 16*(j>>2) + 4g + (j&3)
+                for (int r = 0; r < 4; ++r) {
+#ifdef TQ_ATT_ABL_NOEXP
+                    const float pv = st[kb][qb][r] * 0.001f;
+#else
+                    const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r]);
+#endif
+                    st[kb][qb][r] = pv;
+                    rs += pv;
+                }
+            l_part[qb] += rs;
+        }
+        // ---- O^T += V^T P^T, k-slot (g, j) of a 32-key step <-> key 16*(j>>2) + 4g + (j&3)
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
             Frag ph[QB], pl[QB];
@@ -477,42 +505,55 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
+#ifdef TQ_ATT_ABL_NOSPLIT
+                    if ((j & 1) == 0) { ph[qb].u = *reinterpret_cast<const uint4*>(&st[2 * ks2][qb]); pl[qb].u = *reinterpret_cast<const uint4*>(&st[2 * ks2 + 1][qb]); }
+#else
                     __bf16 hh, ll;
                     split_bf16(st[2 * ks2 + (j >> 2)][qb][j & 3], hh, ll);
                     ph[qb].v[j] = hh; pl[qb].v[j] = ll;
+#endif
                 }
             const int vrow = ks2 * 32 + 4 * g + ((lane >> 2) & 3);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 Frag bh, bl;
                 const int off = vrow * ROWB + (cb * 16 + 4 * (lane & 3)) * 2;
+#ifdef TQ_ATT_ABL_NOLDS
+                bh.u = make_uint4(off, kt, off ^ 0x3f803f80, 0x3f803f80); bl.u = make_uint4(kt, off, 0x3c003c00, off);
+#else
                 bh.h[0] = tr_read_f(v_hi + off); bh.h[1] = tr_read_f(v_hi + off + 16 * ROWB);
                 bl.h[0] = tr_read_f(v_lo + off); bl.h[1] = tr_read_f(v_lo + off + 16 * ROWB);
+#endif
+#ifdef TQ_ATT_ABL_NOPV
+                for (int qb = 0; qb < QB; ++qb) o[qb][cb] += f32x4{bh.v[0], bl.v[1], bh.v[2], bl.v[3]} * (float)ph[qb].v[0] + f32x4{pl[qb].v[0], pl[qb].v[1], ph[qb].v[2], ph[qb].v[3]};
+#else
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) o[qb][cb] = mfma_x3(ph[qb].v, pl[qb].v, bh.v, bl.v, o[qb][cb]);
+                for (int qb = 0; qb < QB; ++qb) o[qb][cb] = mfma_x3(bh.v, bl.v, ph[qb].v, pl[qb].v, o[qb][cb]);
+#endif
             }
         }
+#ifndef TQ_ATT_ABL_NOSTAGE
+        att_wait();
         att_write<D, NIT>(stg, lds + BUFB * ((kt + 1) & 1), 0, tid);  // (the last iteration re-stages its own tile: harmless)
+#endif
+#ifndef TQ_ATT_ABL_NOBAR
         __syncthreads();
+#endif
     }
     ATT_T(3)
     ATT_T(4)
-    // ---- normalise, store
+    // ---- normalise, store: the lane holds channels cb*16 + 4g + r of query qb*16 + li
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const float inv_own = 1.0f / l_run[qb];
-        if (lse && g == 0) {
-            const int q = q0w + qb * 16 + li;
-            if (q < T) lse[((size_t)b * H + h) * T + q] = m_run[qb] * 0.693147180559945309f + __logf(l_run[qb]);
-        }
+        float l = l_part[qb] + __shfl_xor(l_part[qb], 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q0w + qb * 16 + li;
+        if (q < T) {
+            if (lse && g == 0) lse[((size_t)b * H + h) * T + q] = m_ref[qb] * 0.693147180559945309f + __logf(l);
+            float* op = out + ((size_t)b * T + q) * (H * D) + h * D + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float inv = __shfl(inv_own, 4 * g + r);
-            const int q = q0w + qb * 16 + 4 * g + r;
-            if (q < T) {
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) out[((size_t)b * T + q) * (H * D) + h * D + cb * 16 + li] = o[qb][cb][r] * inv;
-            }
+            for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<f32x4*>(op + cb * 16) = o[qb][cb] * inv;
         }
     }
     ATT_T(5)
@@ -535,7 +576,7 @@ int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int 
     const size_t sh = 2 * 4 * 64 * ROWB;
     if (sh > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd2_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    const int nqt = (T + 127) / 128;
+    const int nqt = (T + 64 * ATT_QB - 1) / (64 * ATT_QB);
     hipLaunchKernelGGL(attention_fwd2_kernel<D>, dim3(B * H * nqt), dim3(256), sh, stream, qkv,
                        reinterpret_cast<const unsigned char*>(ws), out, lse, T, Tp, H, scale);
     TQ_CHECK_LAUNCH();
