@@ -77,7 +77,38 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * cg);
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    if (tr < nrow) {
+    const int nkc = KT * C_in;
+    if (tr < nrow && nkc <= 16) {
+        // the usual stem (3 input channels, k = 5): the thread's 4 output channels' weights stay in registers and the (tap, channel)
+        // offsets into the input tile in SGPRs -- per output float4 15 LDS reads + 60 FMAs instead of 30 + 60 (round 3; 30.8 -> 30.3 us at
+        // B = 64, T = 4096: the launch is not bound by its instruction count)
+        float4 wr[16];
+        int xoff[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ii = i < nkc ? i : 0;
+            wr[i] = *reinterpret_cast<const float4*>(ws + ii * C_out + 4 * cg);
+            if (i >= nkc) wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int k = ii / C_in, ci = ii % C_in;   // ws is [k][ci][co]
+            xoff[i] = ci * TW + k;
+        }
+        for (int tl = tr; tl < STAT_SLOT; tl += nrow) {
+            const int t = t0 + tl;
+            if (t >= T) break;
+            float4 a = bv;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < nkc) {   // (uniform)
+                    const float xv = xs[xoff[i] + tl];
+                    a.x = fmaf(wr[i].x, xv, a.x); a.y = fmaf(wr[i].y, xv, a.y);
+                    a.z = fmaf(wr[i].z, xv, a.z); a.w = fmaf(wr[i].w, xv, a.w);
+                }
+            }
+            *reinterpret_cast<float4*>(y + ((size_t)b * T + t) * C_out + 4 * cg) = a;
+            s1[0] += a.x; s1[1] += a.y; s1[2] += a.z; s1[3] += a.w;
+            s2[0] += a.x * a.x; s2[1] += a.y * a.y; s2[2] += a.z * a.z; s2[3] += a.w * a.w;
+        }
+    } else if (tr < nrow) {
         for (int tl = tr; tl < STAT_SLOT; tl += nrow) {
             const int t = t0 + tl;
             if (t >= T) break;
@@ -155,7 +186,10 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
                                                         float* __restrict__ y, int T, int C_in, int C_out, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float shm[];
     constexpr int PAD = KT / 2;
-    constexpr int TW = 128 + KT - 1;
+    // 128 INPUT rows per workgroup = two full passes of the 64 quads, 128 - (KT - 1) output positions.  (Round 3: with 128 outputs
+    // the 132 rows took three passes, the third with 4 of 64 quads at work: 42.1 -> 37.5 us at B = 64, T = 4096, same box.)
+    constexpr int TW = 128;
+    constexpr int NOUT = TW - (KT - 1);
     constexpr int NP = KT * MAXCO;     // partial sums per input row
     constexpr int MAXV = 8;            // float4 per thread and row: C_in <= 128
     float* wl = shm;                   // [C_in][KT][MAXCO] weights, co fastest (16-byte broadcast reads)
@@ -167,7 +201,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     }
     const int tile = blockIdx.x % ntiles;
     const int b = blockIdx.x / ntiles;
-    const int t0 = tile * 128;
+    const int t0 = tile * NOUT;
     const int q = threadIdx.x & 3;
     const int nv = C_in >> 4;          // float4 per thread and row (the quad covers C_in channels: 4 threads x nv x 4)
     // folded GroupNorm coefficients of this thread's channels: float4 number q + 4 j
@@ -233,7 +267,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     for (int o = threadIdx.x; o < 128 * C_out; o += 256) {
         const int co = o >> 7, tl = o & 127;
         const int t = t0 + tl;
-        if (t < T) {
+        if (tl < NOUT && t < T) {
             float v = bias ? bias[co] : 0.f;
 #pragma unroll
             for (int k = 0; k < KT; ++k) v += part[(size_t)(tl + k) * NP + k * MAXCO + co];
@@ -252,9 +286,10 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
     if ((gscale == nullptr) != (gshift == nullptr)) return TQ_ERR_ARG;
     if (c_out && (!c_skip || !skip_src)) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || C_in < 16 || C_in % 16 || C_in > 128 || C_out < 1 || C_out > 16) return TQ_ERR_SHAPE;
-    const int ntiles = (T + 127) / 128;
+    const int nout = 128 - (ktaps - 1);   // output positions per workgroup (head_conv_kernel's NOUT)
+    const int ntiles = (T + nout - 1) / nout;
     const int maxco = C_out <= 4 ? 4 : 16;
-    const size_t sh = ((size_t)C_in * ktaps * maxco + (size_t)(128 + ktaps - 1) * ktaps * maxco) * sizeof(float);
+    const size_t sh = ((size_t)C_in * ktaps * maxco + (size_t)128 * ktaps * maxco) * sizeof(float);
     if (sh > 64 * 1024) return TQ_ERR_SHAPE;
 #define TQ_HEAD(K)                                                                                          \
     {                                                                                                       \
