@@ -25,7 +25,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define TQ_ABI_VERSION 3
+#define TQ_ABI_VERSION 4
 
 #define TQ_ERR_ARG (-1)   /* null / inconsistent pointer arguments */
 #define TQ_ERR_SHAPE (-2) /* unsupported shape */
@@ -268,6 +268,11 @@ int tq_attention_fwd(const float* qkv, float* out, float* lse /* (B,H,T) log-sum
 int tq_attention_fwd_presplit(const float* qkv, const void* kv_planes, float* out, int B, int T, int H, int D, hipStream_t stream);
 int tq_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv, int B,
                      int T, int H, int D, hipStream_t stream);
+/* the same with a scratch buffer of 2 * tq_attention_workspace_bytes(): second-generation kernels for D = 32 / 64 (one prep pass
+ * writes bf16 hi / lo planes of Q, K, V, dO and delta; both passes then stream 16-byte copies, P / dS stay in registers); D = 128 or
+ * workspace == NULL fall through to tq_attention_bwd.  Replaces the autograd backward of blocks.py:156-190. */
+int tq_attention_bwd_ws(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+                        void* workspace, int B, int T, int H, int D, hipStream_t stream);
 
 /* ---- EDM / sampler elementwise ------------------------------------------------------------------------------ */
 /* per-sample scalars from sigma: c_in, c_out, c_skip, c_noise, loss weight  (edm.py:24-37); sigma_stride 0 = shared */

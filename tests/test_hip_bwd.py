@@ -234,7 +234,7 @@ def test_dropout_forward_backward_consistency():
     assert rel_err(dw.cpu(), wr.grad) < TOL
 
 
-@pytest.mark.parametrize("H,D,T", [(4, 64, 512), (2, 32, 62), (1, 128, 200), (2, 64, 127)])
+@pytest.mark.parametrize("H,D,T", [(4, 64, 512), (2, 32, 62), (1, 128, 200), (2, 64, 127), (2, 64, 200), (1, 32, 320)])
 def test_attention_backward(H, D, T):
     from tqdne_amd import ops
     g = torch.Generator().manual_seed(H * D + T)
@@ -250,7 +250,7 @@ def test_attention_backward(H, D, T):
     x = cl(qkv.detach())
     out, lse = ops.attention(x, H, return_lse=True)
     assert rel_err(ncw(out), ref) < TOL
-    dqkv = ops.attention_bwd(x, out, cl(dout), lse, H)
-    got = ncw(dqkv)
-    for name, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, 2 * H * D)), ("dv", slice(2 * H * D, 3 * H * D))):
-        assert rel_err(got[:, sl], qkv.grad[:, sl]) < TOL, name
+    for ws in (True, False):   # second-generation kernels (planes in a workspace; D = 128 falls through) | first generation
+        got = ncw(ops.attention_bwd(x, out, cl(dout), lse, H, workspace=ws))
+        for name, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, 2 * H * D)), ("dv", slice(2 * H * D, 3 * H * D))):
+            assert rel_err(got[:, sl], qkv.grad[:, sl]) < TOL, (name, ws)

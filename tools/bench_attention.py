@@ -46,5 +46,8 @@ gerr = ((dq[:nb].double() - q64.grad).abs().max() / q64.grad.abs().max()).item()
 flops = 4.0 * T * T * H * D * B
 t_f = timed(lambda: ops.attention(qkv, H, return_lse=True))
 t_b = timed(lambda: ops.attention_bwd(qkv, out, dout, lse, H))
+t_b1 = timed(lambda: ops.attention_bwd(qkv, out, dout, lse, H, workspace=False))
+dq1 = ops.attention_bwd(qkv, out, dout, lse, H, workspace=False)
+gerr1 = ((dq1[:nb].double() - q64.grad).abs().max() / q64.grad.abs().max()).item()
 print(f"attention B={B} T={T} H={H} D={D}: fwd(+prep) {t_f:.1f} us ({flops / t_f * 1e-6:.0f} TFLOP/s)  bwd {t_b:.1f} us "
-      f"({2.5 * flops / t_b * 1e-6:.0f} TFLOP/s)  max err fwd {err:.2e} bwd {gerr:.2e}")
+      f"({2.5 * flops / t_b * 1e-6:.0f} TFLOP/s; first generation {t_b1:.1f} us)  max err fwd {err:.2e} bwd {gerr:.2e} (first generation {gerr1:.2e})")

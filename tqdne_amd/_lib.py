@@ -23,7 +23,7 @@ PACK_MODE = {TQ_WFMT_BF16X3: 0, TQ_WFMT_F16_MX8: 2, TQ_WFMT_F16_MX6: 3}   # tq_p
 
 
 DEFAULT_SCHEME = "f16mx6"
-ABI_VERSION = 3   # include/tqdne_hip.h TQ_ABI_VERSION
+ABI_VERSION = 4   # include/tqdne_hip.h TQ_ABI_VERSION
 
 
 def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False) -> int:
@@ -107,6 +107,7 @@ _PROTOS = {
     "tq_conv1d_fwd_qkv": (I, [C.POINTER(TqConvDesc)] + [VP] * 7 + [I, I, VP]),
     "tq_attention_workspace_bytes": (SZ, [I, I, I, I]),
     "tq_attention_bwd": (I, [VP] * 6 + [I, I, I, I, VP]),
+    "tq_attention_bwd_ws": (I, [VP] * 7 + [I, I, I, I, VP]),
     "tq_edm_scalars": (I, [VP, I, F, VP, VP, VP, VP, VP, I, VP]),
     "tq_cm_scalars": (I, [VP, I, F, F, VP, VP, I, VP]),
     "tq_edm_noise_inject": (I, [VP, VP, VP, F, F, VP, VP, I, I, VP]),

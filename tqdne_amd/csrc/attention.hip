@@ -953,6 +953,383 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* d_o, const 
 }
 }  // namespace
 
+
+// =================================================================================================
+// Attention backward, second generation (round 3; D = 32 / 64, used when the caller supplies a workspace).  Same mathematics as
+// the two passes above, restructured along the lines of attention_fwd2_kernel:
+//   * one prep pass writes the bf16 hi / lo planes [b][h][plane][Tp][D] of K (x scale), V and of Q (x scale log2 e), dO, and the
+//     row dots delta = dO . O; the main kernels' staging is then a 16-byte copy with the loads of tile i + 1 in flight under
+//     tile i (the first generation staged synchronously and re-split every tile in each of the T / 64 workgroups of a (b, h));
+//   * scores and dP are computed with the streamed operand as the MFMA's A side, so the accumulator lane holds 4 consecutive
+//     streamed rows of ONE stationary row: P and dS feed the second product from registers (no LDS round trip, one barrier per
+//     tile instead of three), with the k-slot permutation of the forward kernel;
+//   * the log-sum-exp and delta of a row enter as the accumulators' START values: p = exp2(acc), dS = p * acc'.
+// Pass A (dQ): 128 queries per workgroup (32 per wave) stationary, 64-key tiles of the K / V planes streamed.
+// Pass B (dK, dV): 64 keys per workgroup (16 per wave) stationary, 64-query tiles of the Q / dO planes streamed.
+// =================================================================================================
+namespace {
+// planes of one (b, h): qg[..][0] Q hi, [1] Q lo, [2] dO hi, [3] dO lo; kv as in the forward.  delta[b][h][t] = sum_d dO O.
+__global__ void attn_bwd_prep_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ d_o,
+                                     unsigned char* __restrict__ kv, unsigned char* __restrict__ qg, float* __restrict__ delta,
+                                     int T, int Tp, int H, int D, float kscale, float qscale, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d4n = D >> 2;               // threads per (b, h, t) row: 8 or 16 consecutive lanes
+    const bool live = i < n;
+    const size_t ii = live ? i : n - 1;
+    const int c4 = (int)(ii % d4n);
+    size_t r = ii / d4n;
+    const int t = (int)(r % Tp); r /= Tp;
+    const int h = (int)(r % H);
+    const size_t b = r / H;
+    float4 qx = make_float4(0, 0, 0, 0), kx = qx, vx = qx, gx = qx, ox = qx;
+    if (live && t < T) {
+        const float* row = qkv + ((size_t)b * T + t) * (3 * H * D);
+        qx = *reinterpret_cast<const float4*>(row + h * D + 4 * c4);
+        kx = *reinterpret_cast<const float4*>(row + (H + h) * D + 4 * c4);
+        vx = *reinterpret_cast<const float4*>(row + (2 * H + h) * D + 4 * c4);
+        const size_t oo = ((size_t)b * T + t) * (H * D) + h * D + 4 * c4;
+        gx = *reinterpret_cast<const float4*>(d_o + oo);
+        ox = *reinterpret_cast<const float4*>(o + oo);
+    }
+    float dl = gx.x * ox.x + gx.y * ox.y + gx.z * ox.z + gx.w * ox.w;
+    for (int sft = 1; sft < d4n; sft <<= 1) dl += __shfl_xor(dl, sft);
+    if (live && c4 == 0 && t < T) delta[((size_t)b * H + h) * T + t] = dl;
+    if (!live) return;
+    const float src[4][4] = {{qx.x * qscale, qx.y * qscale, qx.z * qscale, qx.w * qscale},
+                             {gx.x, gx.y, gx.z, gx.w},
+                             {kx.x * kscale, kx.y * kscale, kx.z * kscale, kx.w * kscale},
+                             {vx.x, vx.y, vx.z, vx.w}};
+    const size_t plane = (size_t)Tp * D * 2;  // bytes
+    const size_t off = (((size_t)b * H + h) * 4) * plane + ((size_t)t * D + 4 * c4) * 2;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { __bf16 a, c; split_bf16(src[w][j], a, c); hi[j] = a; lo[j] = c; }
+        unsigned char* base = (w < 2 ? qg : kv) + off + (size_t)(2 * (w & 1)) * plane;
+        *reinterpret_cast<bf16x4*>(base) = hi;
+        *reinterpret_cast<bf16x4*>(base + plane) = lo;
+    }
+}
+
+// B-operand fragments of the stationary rows straight from a pair of planes (row-major [t][D] bf16): lane (col = row li, k = 8 g + j)
+template <int D>
+__device__ __forceinline__ void load_plane_frags(const unsigned char* hi_plane, size_t plane_bytes, int row, Frag (&fh)[D / 32],
+                                                 Frag (&fl)[D / 32]) {
+    const int g = (threadIdx.x & 63) >> 4;
+    const unsigned char* p = hi_plane + ((size_t)row * D) * 2 + g * 16;
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) {
+        fh[ks].u = *reinterpret_cast<const uint4*>(p + ks * 64);
+        fl[ks].u = *reinterpret_cast<const uint4*>(p + plane_bytes + ks * 64);
+    }
+}
+
+// ---- pass A: dQ^T[d][q] = scale * sum_key Ks^T[d][key] dS^T[key][q] ------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void attention_bwd2_dq_kernel(const unsigned char* __restrict__ qg, const unsigned char* __restrict__ kv,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   float* __restrict__ dqkv, int T, int Tp, int H, float scale) {
+    constexpr int KS = D / 32, CB = D / 16, QB = 2;
+    constexpr int ROWB = 2 * D + 32;
+    constexpr int PLANE = 64 * ROWB;
+    constexpr int BUFB = 4 * PLANE;
+    constexpr int V16 = D / 8;
+    constexpr int NIT = (4 * 64 * V16) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int nqt = (T + 127) / 128;
+    int bid = xcd_group_id(blockIdx.x, nqt, gridDim.x / nqt);
+    const int qt = bid % nqt; bid /= nqt;
+    const int h = bid % H;
+    const int b = bid / H;
+    const int C3 = 3 * H * D;
+    const int q0w = qt * 128 + wave * 32;
+    const size_t gplane = (size_t)Tp * D * 2;
+    const unsigned char* qgb = qg + (((size_t)b * H + h) * 4) * gplane;
+    const unsigned char* kvb = kv + (((size_t)b * H + h) * 4) * gplane;
+
+    // stationary operands: Q (x scale log2 e) and dO of the wave's 32 queries, as B fragments; -lse log2 e and -delta as the
+    // accumulators' start values (rows past T: the planes hold zeros, their results are not stored)
+    Frag qh[QB][KS], ql[QB][KS], gh[QB][KS], gl[QB][KS];
+    f32x4 lneg[QB], dneg[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0w + qb * 16 + li;
+        load_plane_frags<D>(qgb, gplane, q < Tp ? q : Tp - 1, qh[qb], ql[qb]);
+        load_plane_frags<D>(qgb + 2 * gplane, gplane, q < Tp ? q : Tp - 1, gh[qb], gl[qb]);
+        const bool ok = q < T;
+        const float lv = ok ? -1.44269504088896341f * lse[((size_t)b * H + h) * T + q] : 0.f;
+        const float dv = ok ? -delta[((size_t)b * H + h) * T + q] : 0.f;
+        lneg[qb] = f32x4{lv, lv, lv, lv};
+        dneg[qb] = f32x4{dv, dv, dv, dv};
+    }
+    f32x4 dq[QB][CB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) dq[qb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (T + 63) / 64;
+    {
+        uint4 stg[NIT];
+        att_load<D, NIT>(stg, kvb, gplane, 0, tid);
+        att_wait();
+        att_write<D, NIT>(stg, lds, 0, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int s0 = kt * 64;
+        const unsigned char* k_hi = lds + BUFB * (kt & 1);
+        const unsigned char* k_lo = k_hi + PLANE;
+        const unsigned char* v_hi = k_hi + 2 * PLANE;
+        const unsigned char* v_lo = k_hi + 3 * PLANE;
+        uint4 stg[NIT];
+        att_load<D, NIT>(stg, kvb, gplane, (kt + 1) < nkt ? kt + 1 : kt, tid);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            // S^T and dP^T of the 32 keys of this step: lane holds keys kb*16 + 4g + r of query qb*16 + li
+            f32x4 st[2][QB], dp[2][QB];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int kb = 2 * ks2 + kk;
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) { st[kk][qb] = lneg[qb]; dp[kk][qb] = dneg[qb]; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    Frag ah, al;
+                    const int off = (kb * 16 + li) * ROWB + (ks * 4 + g) * 16;
+                    ah.u = *reinterpret_cast<const uint4*>(k_hi + off);
+                    al.u = *reinterpret_cast<const uint4*>(k_lo + off);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) st[kk][qb] = mfma_x3(ah.v, al.v, qh[qb][ks].v, ql[qb][ks].v, st[kk][qb]);
+                    ah.u = *reinterpret_cast<const uint4*>(v_hi + off);
+                    al.u = *reinterpret_cast<const uint4*>(v_lo + off);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) dp[kk][qb] = mfma_x3(ah.v, al.v, gh[qb][ks].v, gl[qb][ks].v, dp[kk][qb]);
+                }
+            }
+            // dS = p (dP - delta), p = exp2(score - lse); keys past T (zero rows of the planes) get p = 0
+            Frag sh[QB], sl[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = j >> 2, r = j & 3;
+                    float pv = __builtin_amdgcn_exp2f(st[kk][qb][r]);
+                    if (s0 + 64 > T && s0 + (2 * ks2 + kk) * 16 + 4 * g + r >= T) pv = 0.f;
+                    __bf16 hh, ll;
+                    split_bf16(pv * dp[kk][qb][r], hh, ll);
+                    sh[qb].v[j] = hh; sl[qb].v[j] = ll;
+                }
+            // dQ^T += Ks^T dS^T, k-slot (g, j) of the 32-key step <-> key 16*(j>>2) + 4g + (j&3)
+            const int krow = ks2 * 32 + 4 * g + ((lane >> 2) & 3);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                Frag bh, bl;
+                const int off = krow * ROWB + (cb * 16 + 4 * (lane & 3)) * 2;
+                bh.h[0] = tr_read_f(k_hi + off); bh.h[1] = tr_read_f(k_hi + off + 16 * ROWB);
+                bl.h[0] = tr_read_f(k_lo + off); bl.h[1] = tr_read_f(k_lo + off + 16 * ROWB);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) dq[qb][cb] = mfma_x3(bh.v, bl.v, sh[qb].v, sl[qb].v, dq[qb][cb]);
+            }
+        }
+        att_wait();
+        att_write<D, NIT>(stg, lds + BUFB * ((kt + 1) & 1), 0, tid);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0w + qb * 16 + li;
+        if (q < T) {
+            float* op = dqkv + ((size_t)b * T + q) * C3 + h * D + 4 * g;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) *reinterpret_cast<f32x4*>(op + cb * 16) = dq[qb][cb] * scale;
+        }
+    }
+}
+
+// ---- pass B: dV^T[d][key] = sum_q dO^T[d][q] P[q][key],  dK^T[d][key] = scale * sum_q Qs^T[d][q] dS[q][key] -------------------
+// KB 16-key blocks per wave (64 KB keys per workgroup): each staged query tile is used KB times
+template <int D, int KB>
+__global__ __launch_bounds__(256, 2) void attention_bwd2_dkv_kernel(const unsigned char* __restrict__ qg, const unsigned char* __restrict__ kv,
+                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                    float* __restrict__ dqkv, int T, int Tp, int H, float kfac) {
+    constexpr int KS = D / 32, CB = D / 16;
+    constexpr int ROWB = 2 * D + 32;
+    constexpr int PLANE = 64 * ROWB;
+    constexpr int BUFB = 4 * PLANE;
+    constexpr int V16 = D / 8;
+    constexpr int NIT = (4 * 64 * V16) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // per buffer, -lse log2 e | -delta of the query tile: 128 floats in the 32-byte row padding of the buffer's first 16 rows (a
+    // kilobyte of its own would push the workgroup past half of the CU's LDS, i.e. to one workgroup per CU)
+    auto lrow_at = [&](int buf, int i) -> float* { return reinterpret_cast<float*>(lds + BUFB * buf + (i >> 3) * ROWB + 2 * D) + (i & 7); };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int nkt = (T + 64 * KB - 1) / (64 * KB);
+    int bid = xcd_group_id(blockIdx.x, nkt, gridDim.x / nkt);
+    const int kt = bid % nkt; bid /= nkt;
+    const int h = bid % H;
+    const int b = bid / H;
+    const int C3 = 3 * H * D;
+    const int key0 = kt * (64 * KB) + wave * (16 * KB) + li;   // + 16 kb
+    const size_t gplane = (size_t)Tp * D * 2;
+    const unsigned char* qgb = qg + (((size_t)b * H + h) * 4) * gplane;
+    const unsigned char* kvb = kv + (((size_t)b * H + h) * 4) * gplane;
+    const float* lse_b = lse + ((size_t)b * H + h) * T;
+    const float* del_b = delta + ((size_t)b * H + h) * T;
+
+    Frag kh[KB][KS], kl[KB][KS], vh[KB][KS], vl[KB][KS];   // B fragments of the wave's keys (col = key li of block kb)
+    f32x4 dk[KB][CB], dv[KB][CB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int key = key0 + 16 * kb;
+        load_plane_frags<D>(kvb, gplane, key < Tp ? key : Tp - 1, kh[kb], kl[kb]);   // (rows past T are zero; past Tp: not stored)
+        load_plane_frags<D>(kvb + 2 * gplane, gplane, key < Tp ? key : Tp - 1, vh[kb], vl[kb]);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) { dk[kb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kb][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+
+    // -lse log2 e (threads 0..63) | -delta (64..127) of query tile qt: requested at the top of an iteration (an asm load like the
+    // staging loads -- behind a compiler-managed load hipcc waits for vmcnt(0) at the first use, i.e. for the staging loads too),
+    // scaled and parked in LDS at its end.  (Queries past T: p = exp2(0 + 0) = 1 times dO = 0 rows: contributes nothing.)
+    const float* row_src = tid < 64 ? lse_b : del_b;
+    const float row_fac = tid < 64 ? -1.44269504088896341f : -1.0f;
+    auto load_row_of = [&](int qt, float& v) {
+        const int q = qt * 64 + (tid & 63);
+        const float* src = row_src + (q < T ? q : 0);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(src));
+    };
+    auto park_row_of = [&](int qt, int buf, float v) {
+        const int q = qt * 64 + (tid & 63);
+        if (tid < 128) *lrow_at(buf, tid) = q < T ? v * row_fac : 0.f;
+    };
+    const int nqt = (T + 63) / 64;
+    {
+        uint4 stg[NIT];
+        att_load<D, NIT>(stg, qgb, gplane, 0, tid);
+        float rv;
+        load_row_of(0, rv);
+        att_wait();
+        att_write<D, NIT>(stg, lds, 0, tid);
+        park_row_of(0, 0, rv);
+    }
+    __syncthreads();
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int buf = qt & 1;
+        const unsigned char* q_hi = lds + BUFB * buf;
+        const unsigned char* q_lo = q_hi + PLANE;
+        const unsigned char* g_hi = q_hi + 2 * PLANE;
+        const unsigned char* g_lo = q_hi + 3 * PLANE;
+        uint4 stg[NIT];
+        att_load<D, NIT>(stg, qgb, gplane, (qt + 1) < nqt ? qt + 1 : qt, tid);
+        float rv;
+        load_row_of((qt + 1) < nqt ? qt + 1 : qt, rv);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            // S and dP of the 32 queries of this step against 16 keys: lane holds queries qb*16 + 4g + r of key li
+            f32x4 s[2], dp[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int qb = 2 * ks2 + kk;
+                s[kk] = *reinterpret_cast<const f32x4*>(lrow_at(buf, qb * 16 + 4 * g));
+                dp[kk] = *reinterpret_cast<const f32x4*>(lrow_at(buf, 64 + qb * 16 + 4 * g));
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    Frag ah, al;
+                    const int off = (qb * 16 + li) * ROWB + (ks * 4 + g) * 16;
+                    ah.u = *reinterpret_cast<const uint4*>(q_hi + off);
+                    al.u = *reinterpret_cast<const uint4*>(q_lo + off);
+                    s[kk] = mfma_x3(ah.v, al.v, kh[kb][ks].v, kl[kb][ks].v, s[kk]);
+                    ah.u = *reinterpret_cast<const uint4*>(g_hi + off);
+                    al.u = *reinterpret_cast<const uint4*>(g_lo + off);
+                    dp[kk] = mfma_x3(ah.v, al.v, vh[kb][ks].v, vl[kb][ks].v, dp[kk]);
+                }
+            }
+            Frag ph, pl, sh, sl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = j >> 2, r = j & 3;
+                const float pv = __builtin_amdgcn_exp2f(s[kk][r]);
+                __bf16 hh, ll;
+                split_bf16(pv, hh, ll);
+                ph.v[j] = hh; pl.v[j] = ll;
+                split_bf16(pv * dp[kk][r], hh, ll);
+                sh.v[j] = hh; sl.v[j] = ll;
+            }
+            // k-slot (g, j) of the 32-query step <-> query 16*(j>>2) + 4g + (j&3); A = dO^T / Qs^T by transposed reads
+            const int qrow = ks2 * 32 + 4 * g + ((lane >> 2) & 3);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                Frag bh, bl;
+                const int off = qrow * ROWB + (cb * 16 + 4 * (lane & 3)) * 2;
+                bh.h[0] = tr_read_f(g_hi + off); bh.h[1] = tr_read_f(g_hi + off + 16 * ROWB);
+                bl.h[0] = tr_read_f(g_lo + off); bl.h[1] = tr_read_f(g_lo + off + 16 * ROWB);
+                dv[kb][cb] = mfma_x3(bh.v, bl.v, ph.v, pl.v, dv[kb][cb]);
+                bh.h[0] = tr_read_f(q_hi + off); bh.h[1] = tr_read_f(q_hi + off + 16 * ROWB);
+                bl.h[0] = tr_read_f(q_lo + off); bl.h[1] = tr_read_f(q_lo + off + 16 * ROWB);
+                dk[kb][cb] = mfma_x3(bh.v, bl.v, sh.v, sl.v, dk[kb][cb]);
+            }
+        }
+        att_wait();
+        att_write<D, NIT>(stg, lds + BUFB * (buf ^ 1), 0, tid);
+        park_row_of((qt + 1) < nqt ? qt + 1 : qt, buf ^ 1, rv);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int key = key0 + 16 * kb;
+        if (key < T) {
+            float* op = dqkv + ((size_t)b * T + key) * C3 + 4 * g;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                *reinterpret_cast<f32x4*>(op + (H + h) * D + cb * 16) = dk[kb][cb] * kfac;
+                *reinterpret_cast<f32x4*>(op + (2 * H + h) * D + cb * 16) = dv[kb][cb];
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_attn_bwd2(const float* qkv, const float* out, const float* d_o, const float* lse, float* delta, float* dqkv, void* ws,
+                     int B, int T, int H, hipStream_t stream) {
+    const int Tp = (T + 63) / 64 * 64;
+    const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
+    const float log2e = 1.44269504088896341f;
+    unsigned char* kvp = reinterpret_cast<unsigned char*>(ws);
+    unsigned char* qgp = kvp + (size_t)B * H * 4 * Tp * D * 2;
+    const size_t n = (size_t)B * H * Tp * (D / 4);
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, qkv, out, d_o, kvp, qgp, delta, T,
+                       Tp, H, D, scale, scale * log2e, n);
+    TQ_CHECK_LAUNCH();
+    constexpr int ROWB = 2 * D + 32;
+    const size_t shA = 2 * 4 * 64 * ROWB;
+    const size_t shB = shA;
+    if (shA > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd2_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
+    // (two key blocks per wave at D = 64 need 256 registers + 244 bytes of spills -- of the staging registers whose loads are in
+    // flight, tools/asm_inflight_check.py -- so the paper's head size runs one)
+    constexpr int KB = D <= 32 ? 2 : 1;
+    if (shB > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd2_dkv_kernel<D, KB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
+    const int nqt = (T + 127) / 128, nkt = (T + 64 * KB - 1) / (64 * KB);
+    hipLaunchKernelGGL(attention_bwd2_dq_kernel<D>, dim3(B * H * nqt), dim3(256), shA, stream, qgp, kvp, lse, delta, dqkv, T, Tp, H, scale);
+    TQ_CHECK_LAUNCH();
+    // dK = scale * dS^T Qs with Qs = scale Q; the Q planes carry scale * log2 e
+    hipLaunchKernelGGL((attention_bwd2_dkv_kernel<D, KB>), dim3(B * H * nkt), dim3(256), shB, stream, qgp, kvp, lse, delta, dqkv, T, Tp, H,
+                       scale / log2e);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" int tq_attention_bwd_ws(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
+                                   float* dqkv, void* workspace, int B, int T, int H, int D, hipStream_t stream);
+
 extern "C" int tq_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
                                 float* dqkv, int B, int T, int H, int D, hipStream_t stream) {
     if (!qkv || !out || !dout || !lse || !delta || !dqkv) return TQ_ERR_ARG;
@@ -961,4 +1338,13 @@ extern "C" int tq_attention_bwd(const float* qkv, const float* out, const float*
     if (D == 32) return launch_attn_bwd<32>(qkv, out, dout, lse, delta, dqkv, B, T, H, stream);
     if (D == 128) return launch_attn_bwd<128>(qkv, out, dout, lse, delta, dqkv, B, T, H, stream);
     return TQ_ERR_SHAPE;
+}
+
+extern "C" int tq_attention_bwd_ws(const float* qkv, const float* out, const float* dout, const float* lse, float* delta,
+                                   float* dqkv, void* workspace, int B, int T, int H, int D, hipStream_t stream) {
+    if (!qkv || !out || !dout || !lse || !delta || !dqkv) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || H <= 0) return TQ_ERR_SHAPE;
+    if (workspace && D == 64) return launch_attn_bwd2<64>(qkv, out, dout, lse, delta, dqkv, workspace, B, T, H, stream);
+    if (workspace && D == 32) return launch_attn_bwd2<32>(qkv, out, dout, lse, delta, dqkv, workspace, B, T, H, stream);
+    return tq_attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, D, stream);   // D = 128, or no workspace: first generation
 }

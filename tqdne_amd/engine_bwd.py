@@ -376,8 +376,12 @@ class BackwardPlan:
         dqkv = self.grad(qkv)
         delta = self._empty(B, ab.num_heads, T)
         self.op_flops[len(self.ops)] = 2 * 4 * ab.channels * T * T * B
-        self.ops.append([self.lib.tq_attention_bwd, [_p(qkv.buf), _p(att.buf), _p(datt), _p(t["lse"]), _p(delta), _p(dqkv), B, T,
-                                                     ab.num_heads, t["D"]], "attention bwd"])
+        # second-generation kernels (D = 32 / 64) take a scratch buffer for the bf16 planes of Q, K, V, dO: one per shape, shared by
+        # the blocks of the sweep (2 * tq_attention_workspace_bytes = 16 H Tp D bytes per sample)
+        Tp = (T + 63) // 64 * 64
+        ws = self.scratch("attn_bwd_ws", 4 * ab.num_heads * Tp * t["D"])
+        self.ops.append([self.lib.tq_attention_bwd_ws, [_p(qkv.buf), _p(att.buf), _p(datt), _p(t["lse"]), _p(delta), _p(dqkv), _p(ws),
+                                                        B, T, ab.num_heads, t["D"]], "attention bwd"])
         self._wgrad(t["rec_qkv"], dqkv)
         G = self.scratch("G", T, Cc)
         gst = self._dgrad(t["rec_qkv"], dqkv, T, [G], accumulate=False)

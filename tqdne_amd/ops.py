@@ -126,14 +126,15 @@ def attention(qkv, heads, return_lse=False, workspace=True):
     return (out, lse) if return_lse else out
 
 
-def attention_bwd(qkv, out, dout, lse, heads):
+def attention_bwd(qkv, out, dout, lse, heads, workspace=True):
     lib = _lib.load()
     B, T, C3 = qkv.shape
     D = C3 // (3 * heads)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, heads, T, device=qkv.device)
-    check(lib.tq_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, T, heads, D, _stream(qkv.device)),
-          "attention bwd")
+    ws = torch.empty(2 * lib.tq_attention_workspace_bytes(B, T, heads, D), dtype=torch.uint8, device=qkv.device) if workspace else None
+    check(lib.tq_attention_bwd_ws(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(ws), B, T, heads, D,
+                                  _stream(qkv.device)), "attention bwd")
     return dqkv
 
 
