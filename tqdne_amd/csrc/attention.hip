@@ -438,7 +438,14 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
 #ifdef TQ_ATT_ABL_NOS
                 for (int qb = 0; qb < QB; ++qb) st[kb][qb] += f32x4{ah.v[0], al.v[1], ah.v[2], al.v[3]} * (float)qh[qb][ks].v[0];
 #else
+#ifdef TQ_ATT_ABL_S2
+                for (int qb = 0; qb < QB; ++qb) {   // ablation (wrong numerics): the S phase at half of its matrix work
+                    if (ks == 0) st[kb][qb] = mfma_bf16(ah.v, qh[qb][ks].v, st[kb][qb]);
+                    else st[kb][qb] = mfma_bf16(al.v, ql[qb][ks].v, mfma_bf16(ah.v, qh[qb][ks].v, st[kb][qb]));
+                }
+#else
                 for (int qb = 0; qb < QB; ++qb) st[kb][qb] = mfma_x3(ah.v, al.v, qh[qb][ks].v, ql[qb][ks].v, st[kb][qb]);
+#endif
 #endif
             }
         }
