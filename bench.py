@@ -90,6 +90,9 @@ def conv_flops_per_sample(unet, T):
     return total
 
 
+PARITY_TRAJECTORY = (1, 6, 12)   # sampler steps whose state is compared on the way to the final sample (error growth over the NFEs)
+
+
 def parity_inputs(cfg, B, T):
     """Inputs of the same-run parity gate: drawn from a seeded CPU generator, so the GPU
     process and the CPU-oracle child build bit-identical tensors without exchanging them."""
@@ -141,8 +144,10 @@ def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads, reps, pa
         with torch.no_grad():
             den = OE.denoise(p, net, pin["noisy"], pin["sigma"], cond=pin["cond"])
             lss = OE.loss_step(p, net, pin["signal"], pin["eps"], pin["noise"], cond=pin["cond"])
-            smp = OE.sample_deterministic(p, net, pin["start"], nsample_steps, cond=pin["cond"])
-        np.savez(parity_path, denoise=den.numpy(), loss=lss.numpy(), sample=smp.numpy())
+            trace = {}
+            smp = OE.sample_deterministic(p, net, pin["start"], nsample_steps, cond=pin["cond"], trace=trace)
+        traj = {f"sample_step{k}": trace[k].numpy() for k in PARITY_TRAJECTORY if k < nsample_steps}
+        np.savez(parity_path, denoise=den.numpy(), loss=lss.numpy(), sample=smp.numpy(), **traj)
         train()
     else:
         train()
@@ -231,7 +236,10 @@ def parity_block(gpu, cpu_path, args):
     ok = True
     names = {"denoise": "LightningEDM.forward, sigma in {0.02, 0.5, 5, 60}", "loss": "EDM loss (dropout off)",
              "sample": f"{args.sample_steps}-step Heun sample ({2 * args.sample_steps - 1} NFE)"}
-    for k in ("denoise", "loss", "sample"):
+    traj = [f"sample_step{k}" for k in PARITY_TRAJECTORY if k < args.sample_steps and f"sample_step{k}" in gpu]
+    for k in traj:   # (error growth across the NFEs: the sampler's fp64 state after k of the steps, 2k network evaluations)
+        names[k] = f"sampler state after {k[len('sample_step'):]} of the {args.sample_steps} steps ({2 * int(k[len('sample_step'):])} NFE)"
+    for k in ["denoise", "loss"] + traj + ["sample"]:
         a, b = gpu[k].double().reshape(-1), torch.from_numpy(z[k]).double().reshape(-1)
         d = (a - b).abs()
         norm = float(d.max() / b.abs().max().clamp_min(1e-30))
@@ -509,7 +517,11 @@ def main():
             lss = edm.step_with_noise(pd["signal"], pd["eps"], pd["noise"], cond=pd["cond"]).cpu()
             psig = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
             smp = edm.sample_deterministically(pd["start"] * psig[0], psig, None, pd["cond"]).cpu()
-        gpu_parity = dict(denoise=den, loss=lss, sample=smp)
+            # the state after k steps = the same integration over the first k + 1 sigmas (the Heun correction is skipped only on
+            # step num_sampling_steps - 1, so every step of the truncated schedule is a full one, as in the oracle's trace)
+            traj = {f"sample_step{k}": edm.sample_deterministically(pd["start"] * psig[0], psig[:k + 1], None, pd["cond"]).cpu()
+                    for k in PARITY_TRAJECTORY if k < args.sample_steps}
+        gpu_parity = dict(denoise=den, loss=lss, sample=smp, **traj)
         del pd
 
     trainer = DataParallelTrainer(edm, world_size=world, overlap=not args.no_overlap) if do_train else None
