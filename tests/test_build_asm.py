@@ -30,3 +30,28 @@ def test_asm_issued_loads_are_never_touched_in_flight(tmp_path):
         assert n > 0 and not bad, (k, n, bad[:5])
         meta = txt[txt.index(".amdhsa_kernel " + k):]
         assert int(re.search(r"private_segment_fixed_size (\d+)", meta).group(1)) == 0, k   # no spills at all
+
+
+def test_the_checker_flags_a_touched_register(tmp_path):
+    """the checker itself: a register written between an asm-issued load and the kernel's vmcnt(0) must be reported, one written
+    after the wait must not; compiler-issued loads (outside ASMSTART / ASMEND) are the compiler's business"""
+    from asm_inflight_check import check
+    src = """
+_ZN4testEv:
+	global_load_dwordx4 v[20:23], v[0:1], off offset:16
+	v_mov_b32_e32 v20, 0
+	;;#ASMSTART
+	global_load_dwordx4 v[10:13], v[2:3], off
+	;;#ASMEND
+	v_add_f32_e32 v5, v6, v7
+	v_mov_b32_e32 v11, 0
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	v_mov_b32_e32 v12, 0
+	s_endpgm
+"""
+    f = tmp_path / "t.s"
+    f.write_text(src)
+    n, bad = check(str(f), "_ZN4testEv")
+    assert n == 1 and bad == ["v_mov_b32_e32 v11, 0"], (n, bad)
