@@ -234,7 +234,7 @@ def test_dropout_forward_backward_consistency():
     assert rel_err(dw.cpu(), wr.grad) < TOL
 
 
-@pytest.mark.parametrize("H,D,T", [(4, 64, 512), (2, 32, 62), (1, 128, 200), (2, 64, 127), (2, 64, 200), (1, 32, 320), (2, 64, 1), (2, 32, 65)])
+@pytest.mark.parametrize("H,D,T", [(4, 64, 512), (2, 32, 62), (1, 128, 200), (2, 64, 127), (2, 64, 200), (1, 32, 320), (2, 64, 3), (2, 32, 65)])
 def test_attention_backward(H, D, T):
     from tqdne_amd import ops
     g = torch.Generator().manual_seed(H * D + T)
