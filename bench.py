@@ -381,6 +381,80 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+class Watchdog:
+    """A hung rendezvous or first collective must be VISIBLE in the driver's record (SCALE_rNN.json) instead of a silent timeout of
+    the whole run: a timer thread that, unless cancelled in time, prints ONE diagnostic JSON line on stdout (same top-level keys as
+    the result line, ``value`` null, ``error`` set) and ends the process with exit code 3 -- a fresh exit, nothing is re-exec'ed."""
+
+    def __init__(self, seconds: float, stage: str, rank: int, world: int, extra=None):
+        import threading
+        self.stage, self.rank, self.world, self.seconds, self.extra = stage, rank, world, seconds, dict(extra or {})
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._t.start()
+
+    def _fire(self):
+        line = dict(metric="waveforms/sec (train step + 18-step EDM sample), 3ch x 4096", value=None, unit="waveforms/s",
+                    n_gpus=self.world, error=f"rank {self.rank}: stage '{self.stage}' did not complete within {self.seconds:.0f} s",
+                    stage=self.stage, rank=self.rank,
+                    env={k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE",
+                                                         "HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES", "NCCL_DEBUG")},
+                    **self.extra)
+        try:
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+            log("WATCHDOG:", line["error"])
+        finally:
+            os._exit(3)
+
+    def cancel(self):
+        self._t.cancel()
+
+
+def init_distributed(backend: str, rank: int, world: int, dev=None, init_timeout_s: float = None, first_timeout_s: float = None) -> int:
+    """init_process_group + the FIRST collective (a ones tensor summed over the ranks) under a watchdog each; returns the number of
+    ranks that took part, which must equal ``world``.  Timeouts: TQDNE_BENCH_INIT_TIMEOUT (default 420 s: a fresh box pages torch in
+    for 1-2 minutes per rank) and TQDNE_BENCH_FIRST_COLLECTIVE_TIMEOUT (default 180 s)."""
+    import datetime
+    import torch.distributed as dist
+    init_timeout_s = float(os.environ.get("TQDNE_BENCH_INIT_TIMEOUT", 420)) if init_timeout_s is None else init_timeout_s
+    first_timeout_s = float(os.environ.get("TQDNE_BENCH_FIRST_COLLECTIVE_TIMEOUT", 180)) if first_timeout_s is None else first_timeout_s
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    wd = Watchdog(init_timeout_s, "init_process_group", rank, world, dict(backend=backend))
+    kw = dict(device_id=dev) if (backend == "nccl" and dev is not None) else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=init_timeout_s + first_timeout_s + 60), **kw)
+    wd.cancel()
+    wd = Watchdog(first_timeout_s, "first_collective", rank, world, dict(backend=backend))
+    ones = torch.ones(1, device=dev if dev is not None else "cpu")
+    dist.all_reduce(ones)
+    n = int(ones.item())   # (synchronises: the collective has run)
+    wd.cancel()
+    if n != world:
+        raise SystemExit(f"first collective summed {n} ranks, expected {world}")
+    return n
+
+
+def replica_checksum(params) -> "torch.Tensor":
+    """(2,) int64 on the parameters' device: wrapping sum of the fp32 bit patterns and their count -- equal on two ranks iff (up to a
+    2^-64 accident) the replicas hold bit-identical weights.  No host sync."""
+    ps = [p.detach().reshape(-1) for p in params]
+    flat = torch.cat(ps) if len(ps) > 1 else ps[0]
+    bits = flat.contiguous().view(torch.int32).to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64) % 1000003   # (position-weighted: a permutation changes it)
+    return torch.stack([(bits * w).sum(), torch.tensor(bits.numel(), device=bits.device, dtype=torch.int64)])
+
+
+def gather_checksums(cs: "torch.Tensor", world: int):
+    """every rank's checksum on every rank -> list of ints (hex strings in the JSON line)"""
+    import torch.distributed as dist
+    if world <= 1:
+        return [int(cs[0].item())]
+    out = [torch.zeros_like(cs) for _ in range(world)]
+    dist.all_gather(out, cs)
+    return [int(t[0].item()) for t in out]
+
+
 def op_class(name):
     """kernel class of a plan launch, by its name (DESIGN.md section 5's table)"""
     if name.startswith("conv:"):
@@ -462,12 +536,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import datetime
     import torch.distributed as dist
+    first_collective_ranks = 1
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(minutes=10))
+        first_collective_ranks = init_distributed("nccl", rank, world, dev)
 
     import __graft_entry__
     if rank == 0:
@@ -525,6 +597,8 @@ def main():
         del pd
 
     trainer = DataParallelTrainer(edm, world_size=world, overlap=not args.no_overlap) if do_train else None
+    # replicas: every rank's weights right after the trainer's rank-0 broadcast (compared across ranks in the JSON line)
+    cs_start = replica_checksum(edm.unet.parameters())
     sigmas = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
     eps0 = start_noise * sigmas[0]
     eps32 = start_noise.float()
@@ -587,6 +661,13 @@ def main():
         allr = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(allr, torch.tensor([1e3 * dt_rank / args.steps], device=dev, dtype=torch.float64))
         rank_ms = [float(t.item()) for t in allr]
+    # replicas after the timed steps: data parallelism is only correct if every rank applied the same update to the same weights
+    sums_start = gather_checksums(cs_start, world)
+    sums_end = gather_checksums(replica_checksum(edm.unet.parameters()), world)
+    replicas = dict(after_broadcast=len(set(sums_start)) == 1, after_timed_steps=len(set(sums_end)) == 1,
+                    weights_moved=(sums_start[0] != sums_end[0]) if do_train else None,
+                    checksum_after_broadcast=[f"{v & 0xFFFFFFFFFFFFFFFF:016x}" for v in sums_start],
+                    checksum_after_timed_steps=[f"{v & 0xFFFFFFFFFFFFFFFF:016x}" for v in sums_end])
     ms_per_step = 1e3 * dt / args.steps
     log(f"timed region done: {ms_per_step:.1f} ms/step")
     value = world * B / (dt / args.steps)
@@ -736,7 +817,9 @@ def main():
                        "hip_graph": bool(use_graph) or (use_graph is None and B <= 16),
                        "sampler_lanes": 1 if (use_graph or (use_graph is None and B <= 16)) else sampler_lanes(B), "mode": args.mode},
             "parts": parts,
-            "rccl_ranks": rccl_ranks, "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
+            "rccl_ranks": rccl_ranks, "rccl_ranks_ok": rccl_ranks == world and first_collective_ranks == world,
+            "replicas_equal": replicas["after_broadcast"] and replicas["after_timed_steps"], "replicas": replicas,
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "gradient_exchange": exchange,
             "whole_step_algorithmic_tflops": work_flop / (dt / args.steps) / 1e12,
             "whole_step_mfma_frac": work_flop / (dt / args.steps) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
@@ -766,6 +849,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rccl_ranks != world or not (replicas["after_broadcast"] and replicas["after_timed_steps"]):
+        # (the line above already carries rccl_ranks_ok / replicas_equal = false; a scaling number from such a run must not pass silently)
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define TQ_ABI_VERSION 4
+#define TQ_ABI_VERSION 5
 
 #define TQ_ERR_ARG (-1)   /* null / inconsistent pointer arguments */
 #define TQ_ERR_SHAPE (-2) /* unsupported shape */
@@ -57,7 +57,8 @@ typedef struct ihipStream_t* hipStream_t;
  * mode 3). */
 #define TQ_WFMT_F16_MX6 2
 
-/* GroupNorm finalisation fused into the launch that completes a tensor's statistics (ABI 3; TqConvDesc.gn_fuse, NULL = off).
+/* EXPERIMENT (only in builds with TQ_BUILD_EXPERIMENTS_BIT; otherwise TqConvDesc.gn_fuse is reserved and must be NULL: a non-NULL
+ * value returns TQ_ERR_ARG).  GroupNorm finalisation fused into the launch that completes a tensor's statistics (ABI 3).
  * With TQ_CONV_STATS the launch's workgroups publish their partial sums, take an arrival ticket per sample, and the workgroup whose
  * ticket completes sample b folds the statistics of that sample into the scale / shift of the GroupNorm that CONSUMES the produced
  * tensor (what tq_gn_finalize would do in a launch of its own: bit-identical coefficients).  The consumer may normalise the
@@ -95,7 +96,7 @@ typedef struct TqConvDesc {
      * read such a tensor un-normalised (fused 1x1 skip convs, up-sampling convs) to TQ_WFMT_BF16X3.  Device pointer, never reset
      * by the library. */
     int32_t* range_flag;
-    const TqGnFuse* gn_fuse; /* host pointer, read at launch; NULL: statistics are finalised by a tq_gn_finalize launch */
+    const TqGnFuse* gn_fuse; /* reserved, NULL (experiment builds: host pointer, read at launch; see TqGnFuse) */
 } TqConvDesc;
 
 /* flags of TqConvBwdDesc.flags: which stages the FORWARD conv applied to its input */
@@ -117,6 +118,11 @@ typedef struct TqConvBwdDesc {
 } TqConvBwdDesc;
 
 int tq_abi_version(void);
+/* Bit mask of optional parts compiled into this library.  TQ_BUILD_EXPERIMENTS_BIT: the opt-in kernels that lost their A/B
+ * (one-wave-per-SIMD conv, slim 64-channel tile, in-launch GroupNorm fold = TqConvDesc.gn_fuse) are present; the default build
+ * (`python -m tqdne_amd._build`) leaves them out, `TQDNE_BUILD_EXPERIMENTS=1` builds them into libtqdne_hip_exp.so. */
+#define TQ_BUILD_EXPERIMENTS_BIT 1
+int tq_build_flags(void);
 
 /* ---- weights -------------------------------------------------------------------------------------------- */
 /* Pack a torch Conv1d weight (C_out, C_in, K) fp32 into per-lane MFMA fragments.

@@ -6,7 +6,7 @@ streams, f16+mx8 forward convs, dropout 0.1 in the train step) -- GPU vs the CPU
   (iii) the fp16-range conv scheme on trained-like statistics (heavy-tailed weights, residual-stream magnitudes up to 1e4, per-channel
         scale spread of 1e3), and the range guard that moves a plan to bf16x3 before the fp16 range is left
   (iv)  a dropout-ON training step: the kernels' counter-based masks are rebuilt on the CPU from the same hash (csrc/common.hpp
-        hash_u32) and fed to the oracle; loss and every gradient must agree (edm.py:126-134, unet.py:101)
+        drop_hash) and fed to the oracle; loss and every gradient must agree (edm.py:126-134, unet.py:101)
   (v)   LightningEDM.forward under autograd (edm.py:105-113 is an ordinary differentiable call in the reference)
 """
 
@@ -176,22 +176,34 @@ def test_range_guard_moves_the_plan_to_bf16x3():
 
 
 # ---------------------------------------------------------------------------------------------------------------- (iv)
-def _hash_u32(seed, site, idx):
-    """csrc/common.hpp hash_u32 on numpy uint64 arrays (wrapping arithmetic)"""
-    M = np.uint64
+def _mix32(x):
+    """csrc/common.hpp mix32 on numpy uint32 arrays (wrapping arithmetic)"""
+    M = np.uint32
+    x = np.asarray(x, dtype=np.uint32).copy()
     with np.errstate(over="ignore"):
-        z = M(seed) + M(0x9E3779B97F4A7C15) * M(site + 1) + idx * M(0xBF58476D1CE4E5B9)
-        z ^= z >> M(30)
-        z *= M(0xBF58476D1CE4E5B9)
-        z ^= z >> M(27)
-        z *= M(0x94D049BB133111EB)
-        z ^= z >> M(31)
-    return (z >> M(32)).astype(np.uint32)
+        x ^= x >> M(16)
+        x *= M(0x7FEB352D)
+        x ^= x >> M(15)
+        x *= M(0x846CA68B)
+        x ^= x >> M(16)
+    return x
+
+
+def _drop_key(seed, site, b):
+    """csrc/common.hpp drop_key: the per-sample key of dropout site ``site`` under the 64-bit ``seed``"""
+    M = np.uint32
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    with np.errstate(over="ignore"):
+        k = _mix32(M(seed & 0xFFFFFFFF) ^ M(0x9E3779B9))
+        k = _mix32(k ^ M(seed >> 32))
+        k = _mix32(k + M(0x85EBCA6B) * M(site + 1))
+        return _mix32(k + M(0xC2B2AE35) * M(b + 1))
 
 
 def _dropout_masks(cfg, B, T_of_block, seed, p):
-    """{block name: (B, C, T) mask scaled by 1/(1-p)} exactly as conv1d_mfma.hip's ACT == 3 prologue draws it: element index
-    ((b*T + t)*C + c) of site k (k-th ResBlock in execution order, from 1), keep iff hash >= uint32(p * 2^32)."""
+    """{block name: (B, C, T) mask scaled by 1/(1-p)} exactly as conv1d_mfma.hip's ACT == 3 prologue draws it: element t*C + c
+    of sample b at site k (k-th ResBlock in execution order, from 1) is kept iff drop_hash(drop_key(seed, k, b), t*C + c) >=
+    uint32(p * 2^32)."""
     from oracle import unet as OU
     p32 = np.float32(p)
     thresh = np.uint32(int(float(p32) * 4294967296.0))
@@ -199,8 +211,8 @@ def _dropout_masks(cfg, B, T_of_block, seed, p):
     masks = {}
     for k, (name, C) in enumerate(OU.res_block_names(cfg), start=1):
         T = T_of_block(name)
-        idx = np.arange(B * T * C, dtype=np.uint64)
-        keep = _hash_u32(seed, k, idx) >= thresh
+        idx = np.arange(T * C, dtype=np.uint32)
+        keep = np.stack([_mix32(idx ^ _drop_key(seed, k, b)) >= thresh for b in range(B)])
         masks[name] = torch.from_numpy(np.where(keep, scale, np.float32(0)).astype(np.float32).reshape(B, T, C)).permute(0, 2, 1).contiguous()
     return masks
 
@@ -315,3 +327,55 @@ def test_paper_config_consistency_sampling_b64_vs_oracle():
     # batch independence at the bench batch: the same four waveforms sampled alone must be bit-identical
     y1p = cm.sample_from(start[pick].to(dev()), [], [], cond=cond[pick].to(dev()))
     assert torch.equal(y1p, y1[pick]), "a sample must not depend on what else is in the batch"
+
+
+# ---------------------------------------------------------------------------------------------------------------- (vii)
+def test_paper_config_training_step_b64_all_gradients_vs_oracle():
+    """The benchmarked training step at the benchmarked batch: paper UNet, B = 64, 3 x 4096, dropout off, driven the way
+    DataParallelTrainer drives it (edm_loss_and_grads: one flat gradient buffer, buckets handed out from inside the sweep, the
+    weight-gradient split plan of B = 64 with up to 32 units per split) -- loss and ALL parameter gradients vs torch autograd
+    through the CPU oracle (edm.py:115-134).  The oracle runs the batch in chunks of 8 samples (the loss is a mean over the
+    batch, so the gradient is the sum of the chunks' gradients scaled by chunk / B): bounded host memory, same result."""
+    from oracle import edm as OE
+    from tqdne_amd.autograd import edm_loss_and_grads
+    edm, sd, cfg = _paper_edm(dropout=0.0, seed=23)
+    edm.train()
+    B, T, CH = 64, 4096, 8
+    g = torch.Generator().manual_seed(177)
+    sig = 0.5 * torch.randn(B, 3, T, generator=g)
+    cond = torch.randn(B, 5, generator=g)
+    eps, noise = torch.randn(B, generator=g), torch.randn(B, 3, T, generator=g)
+    bucket_elems = (16 << 20) // 4    # DataParallelTrainer's default: 16 MB buckets = 4 over the 62 MB of gradients
+    slices = []
+    loss, flat = edm_loss_and_grads(edm, sig.to(dev()), eps.to(dev()), noise.to(dev()), cond.to(dev()), None,
+                                    on_bucket=lambda sl: slices.append((sl.data_ptr(), sl.numel())), bucket_elems=bucket_elems)
+    torch.cuda.synchronize()
+    eng = edm.unet._engine(B, T, dev())
+    # the buckets tile [0, n_grad) of the flat buffer in order
+    assert len(slices) == 4, [n for _, n in slices]
+    at = flat.data_ptr()
+    for ptr, n in slices:
+        assert ptr == at
+        at += 4 * n
+    assert at == flat.data_ptr() + 4 * eng._bwd.n_grad
+    params = {("unet." + k): v.clone().requires_grad_(k != "time_embed.W") for k, v in sd.items()}
+    net = OE.make_net(params, cfg)
+    lo = 0.0
+    for i in range(0, B, CH):
+        sl = slice(i, i + CH)
+        l = OE.loss_step(OE.EDMParams(), net, sig[sl], eps[sl], noise[sl], cond=cond[sl]) * (CH / B)
+        l.backward()
+        lo += float(l.detach())
+    e_loss = abs(float(loss) - lo) / abs(lo)
+    gmax = max(float(v.grad.abs().max()) for v in params.values() if v.grad is not None)
+    worst, wname, n = 0.0, "", 0
+    for name, q in edm.unet.named_parameters():
+        if not q.requires_grad:
+            continue
+        e = grad_err(q.grad, params["unet." + name].grad, gmax, name)
+        n += 1
+        if e > worst:
+            worst, wname = e, name
+    print(f"paper UNet, B=64 training step (flat buffer, {len(slices)} buckets): loss rel err {e_loss:.2e}; worst of {n} gradients "
+          f"{worst:.2e} at {wname}")
+    assert n == 310 and e_loss < TOL and worst < TOL

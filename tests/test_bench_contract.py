@@ -51,6 +51,11 @@ def test_bench_json_contract_tiny_config():
     # self-evidence of the collective path (a ones tensor summed over RCCL when N > 1), per-rank times, exchange exposure
     assert d["rccl_ranks"] == 1 and d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] and len(d["rank_ms_per_step"]["all"]) == 1
     assert d["gradient_exchange"]["rccl_ranks"] == 1 and d["gradient_exchange"]["hidden_by_overlap_ms"] == 0.0
+    # scaling-run self-checks (trivially true at N = 1, but the keys and their shape are what SCALE_rNN.json will carry)
+    assert d["rccl_ranks_ok"] is True and d["replicas_equal"] is True
+    rep = d["replicas"]
+    assert rep["after_broadcast"] and rep["after_timed_steps"] and rep["weights_moved"] is True
+    assert len(rep["checksum_after_broadcast"]) == 1 and len(rep["checksum_after_timed_steps"]) == 1
 
 
 @pytest.mark.timeout(600)

@@ -185,6 +185,8 @@ def test_training_step_next_to_other_streams():
         assert worst < 1e-4, worst
 
 
+@pytest.mark.skipif(__import__("os").environ.get("TQDNE_BUILD_EXPERIMENTS") != "1",
+                    reason="the in-launch GroupNorm fold is an experiment: run with TQDNE_BUILD_EXPERIMENTS=1 (builds libtqdne_hip_exp.so)")
 def test_fused_groupnorm_fold_poisoned_buffers_and_equals_separate_launches():
     """GroupNorm finalisation rides in the launch that completes the statistics (TqGnFuse: the last-arriving workgroup of a sample
     folds them).  (i) With every coefficient buffer poisoned with NaN before each forward, outputs are finite and bit-identical

@@ -162,3 +162,55 @@ def test_rank_seeding_gives_distinct_reproducible_streams():
         seeds[rank] = (s1, s2, tuple(draws.tolist()))
     assert len({v[0] for v in seeds.values()}) == 3 and len({v[2] for v in seeds.values()}) == 3
     rng.seed_rank(0, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------- bench.py, N > 1 plumbing
+def _bench_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import bench
+    n = bench.init_distributed("gloo", rank, world, None, init_timeout_s=60, first_timeout_s=60)
+    g = torch.Generator().manual_seed(3)
+    params = [torch.randn(1000, generator=g), torch.randn(7, 5, generator=g)]
+    same = bench.gather_checksums(bench.replica_checksum(params), world)
+    params[1][3, 2] += 1e-7 * (rank + 1)             # one element, one ulp-scale change, on each rank differently
+    diff = bench.gather_checksums(bench.replica_checksum(params), world)
+    perm = [params[0].flip(0), params[1]]            # same multiset of values in another order
+    ret[rank] = dict(n=n, same=len(set(same)) == 1, diff=len(set(diff)) == world,
+                     perm=int(bench.replica_checksum(perm)[0]) != int(bench.replica_checksum([params[0], params[1]])[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bench_rendezvous_first_collective_and_replica_checksums_world2():
+    """bench.py's N > 1 plumbing on gloo: init + first collective count the ranks; the replica checksum is equal for identical
+    weights, differs for a one-element change and for a permutation"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bench_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r] == dict(n=world, same=True, diff=True, perm=True), ret[r]
+
+
+@pytest.mark.timeout(120)
+def test_bench_watchdog_reports_a_hung_rendezvous():
+    """rank 0 of a 2-rank job whose peer never shows up: instead of hanging until the driver's clock runs out, the watchdog prints
+    ONE diagnostic JSON line (value null, error, stage) and the process exits non-zero"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench; bench.init_distributed('gloo', 0, 2, None)" % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), TQDNE_BENCH_INIT_TIMEOUT="4", RANK="0", WORLD_SIZE="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=100)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["stage"] == "init_process_group" and "did not complete" in d["error"] and d["n_gpus"] == 2

@@ -409,6 +409,8 @@ def test_pack_jobs_equals_one_pack_per_tensor():
     assert torch.equal(dst[3:], src) and float(dst[:3].abs().sum()) == 0.0
 
 
+@pytest.mark.skipif(__import__("os").environ.get("TQDNE_BUILD_EXPERIMENTS") != "1",
+                    reason="conv1d_w4 and the slim tile are experiments: run with TQDNE_BUILD_EXPERIMENTS=1 (builds libtqdne_hip_exp.so)")
 @pytest.mark.parametrize("switch", ["TQDNE_CONV_W4", "TQDNE_CONV_SLIM"])
 def test_opt_in_conv_kernels_in_a_child_process(switch):
     """The two conv kernels of round 3 that stay behind switches (read once per process): the one-wave-per-SIMD kernel

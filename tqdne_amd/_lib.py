@@ -23,7 +23,7 @@ PACK_MODE = {TQ_WFMT_BF16X3: 0, TQ_WFMT_F16_MX8: 2, TQ_WFMT_F16_MX6: 3}   # tq_p
 
 
 DEFAULT_SCHEME = "f16mx6"
-ABI_VERSION = 4   # include/tqdne_hip.h TQ_ABI_VERSION
+ABI_VERSION = 5   # include/tqdne_hip.h TQ_ABI_VERSION
 
 
 def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False) -> int:
@@ -92,6 +92,7 @@ class TqConvBwdDesc(C.Structure):
 
 _PROTOS = {
     "tq_abi_version": (I, []),
+    "tq_build_flags": (I, []),
     "tq_conv_weight_pack_bytes": (SZ, [I, I, I, I]),
     "tq_pack_conv_weight": (I, [VP, I, I, I, I, VP, VP]),
     "tq_conv_tile_co": (I, [I]),
@@ -152,7 +153,13 @@ _OPTIONAL = {}
 
 def lib_path() -> str:
     # TQDNE_HIP_LIB: developer override used by tools/ to A/B kernel variants; the default is the in-tree build
-    return os.environ.get("TQDNE_HIP_LIB", _build.LIBPATH)
+    # (TQDNE_BUILD_EXPERIMENTS=1: the build that also holds the opt-in kernels, libtqdne_hip_exp.so)
+    return os.environ.get("TQDNE_HIP_LIB", _build.EXP_LIBPATH if _build.EXPERIMENTS else _build.LIBPATH)
+
+
+def has_experiments() -> bool:
+    """True when the loaded library was built with the opt-in kernels (conv1d_w4, slim tile, in-launch GroupNorm fold)."""
+    return bool(load().tq_build_flags() & 1)
 
 
 def load():

@@ -226,10 +226,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
                     for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
                 }
                 if (p.flags & TQ_CONV_DROPOUT) {
-                    const uint64_t e0 = ((uint64_t)b * T_src + pos) * Cin + cb + 4 * m;
+                    const uint32_t e0 = (uint32_t)pos * (uint32_t)Cin + (uint32_t)(cb + 4 * m);
+                    const uint32_t dkey = drop_key(p.drop_seed, p.drop_site, (uint32_t)b);   // (b is uniform: scalar unit)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        v[j] = (hash_u32(p.drop_seed, p.drop_site, e0 + j) >= p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+                        v[j] = (drop_hash(dkey, e0 + j) >= p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
                 }
             }
             bf16x4 h, l;
@@ -321,25 +322,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
                 }
 }
 
-// dw[i*KT + k] = sum_s slab[s][k][i];  block (64, 4): x -> i (coalesced), y -> split partition, grid.y -> tap
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
-                                                           int KT, int C_out, int C_in) {
-    __shared__ float red[4][64];
-    const size_t n = (size_t)C_out * C_in;
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const int k = blockIdx.y;
-    float a0 = 0.f, a1 = 0.f;
+// dw[i*KT + k] = sum_s slab[s][k][i].  One workgroup (64 x 4 threads) owns 256 consecutive i for ALL taps: thread (x, y) sums the
+// splits s = y, y + 4, ... of the four elements 4x .. 4x + 3 of every tap with 16-byte loads, 2 KT of them in flight; the four
+// partitions meet in LDS and the 256 KT results leave as one contiguous run of dw.  (Rounds 1-3: one 4-byte element per thread and
+// tap, two loads in flight, 4-byte stores KT floats apart -- 27 us per launch on average, 76 launches per training step.)
+template <int KT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, size_t n) {
+    __shared__ __attribute__((aligned(16))) float red[4][KT][260];   // (260: 16-byte rows whose taps sit 4 banks apart)
+    const int x = threadIdx.x, y = threadIdx.y;
+    const size_t i0 = (size_t)blockIdx.x * 256;
+    const size_t i = i0 + 4 * x;
+    float4 acc[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
-        int s = threadIdx.y;
-        for (; s + 4 < nsplit; s += 8) {
-            a0 += slab[((size_t)s * KT + k) * n + i];
-            a1 += slab[((size_t)(s + 4) * KT + k) * n + i];
+        const float* base = slab + i;
+        int sidx = y;
+        for (; sidx + 4 < nsplit; sidx += 8) {
+            float4 v0[KT], v1[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                v0[k] = *reinterpret_cast<const float4*>(base + ((size_t)sidx * KT + k) * n);
+                v1[k] = *reinterpret_cast<const float4*>(base + ((size_t)(sidx + 4) * KT + k) * n);
+            }
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                acc[k].x += v0[k].x + v1[k].x; acc[k].y += v0[k].y + v1[k].y;
+                acc[k].z += v0[k].z + v1[k].z; acc[k].w += v0[k].w + v1[k].w;
+            }
         }
-        if (s < nsplit) a0 += slab[((size_t)s * KT + k) * n + i];
+        if (sidx < nsplit) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)sidx * KT + k) * n);
+                acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w;
+            }
+        }
     }
-    red[threadIdx.y][threadIdx.x] = a0 + a1;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) *reinterpret_cast<float4*>(&red[y][k][4 * x]) = acc[k];
     __syncthreads();
-    if (threadIdx.y == 0 && i < n) dw[i * KT + k] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const int tid = y * 64 + x;
+    const size_t nleft = n - i0 < 256 ? n - i0 : 256;   // (n is a multiple of 4, not necessarily of 256)
+    for (int o = tid; o < (int)nleft * KT; o += 256) {
+        const int il = o / KT, k = o - il * KT;
+        dw[i0 * KT + o] = (red[0][k][il] + red[1][k][il]) + (red[2][k][il] + red[3][k][il]);
+    }
 }
 
 int wgrad_nci(const TqConvDesc* d) {
@@ -469,8 +497,10 @@ extern "C" int tq_conv1d_bwd_weight_colsum(const TqConvDesc* d, const float* dy,
     }
     if (rc) return rc;
     const size_t n = (size_t)d->C_out * (d->C_in0 + d->C_in1);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64), d->ktaps), dim3(64, 4), 0, stream, a.slab, dw, a.nsplit,
-                       d->ktaps, d->C_out, d->C_in0 + d->C_in1);
+    const dim3 rgrid((unsigned)((n + 255) / 256)), rblock(64, 4);
+    if (d->ktaps == 5) hipLaunchKernelGGL(wgrad_reduce_kernel<5>, rgrid, rblock, 0, stream, a.slab, dw, a.nsplit, n);
+    else if (d->ktaps == 3) hipLaunchKernelGGL(wgrad_reduce_kernel<3>, rgrid, rblock, 0, stream, a.slab, dw, a.nsplit, n);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, rgrid, rblock, 0, stream, a.slab, dw, a.nsplit, n);
     TQ_CHECK_LAUNCH();
     return 0;
 }
@@ -488,17 +518,22 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
                                                               float* __restrict__ cA, float* __restrict__ cB,
                                                               float* __restrict__ cC, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
-    extern __shared__ double sh[];  // [nsub][C][2] partial sums (then [C][2] totals in place), then [32][2]
+    extern __shared__ double sh[];  // [nsub][Cb][2] partial sums (then [Cb][2] totals in place), then [groups of this block][2]
+    // grid (B, NP): block (b, part) owns the channels [part * Cb, (part + 1) * Cb) = 32 / NP whole groups of sample b (groups are
+    // independent).  Round 4: one block per sample was a latency chain (slot loads -> barrier -> G serial fp64 steps per group ->
+    // barrier -> C atomics): 18 us per launch, 51 launches per training step.
     const int b = blockIdx.x;
-    // Slot sums: nsub threads per channel (all 256 threads busy for C <= 128), each walking its slots four at a time with the four
-    // loads in flight together.  (Round 3: one thread per channel with one dependent 8-byte load after the other was a chain of
-    // T / 128 = 32 memory latencies -- 21.6 us per launch, 51 launches per training step.)  Fixed summation order: deterministic.
-    const int nsub = C <= 128 ? (int)blockDim.x / C : 1;
+    const int Cb = C / (int)gridDim.y;
+    const int c0 = (int)blockIdx.y * Cb;
+    // Slot sums: nsub threads per channel, each walking its slots four at a time with the four loads in flight together.  Fixed
+    // summation order: deterministic.
+    int nsub = Cb <= 128 ? (int)blockDim.x / Cb : 1;
+    if (nsub > nslots) nsub = nslots;
     double* cs = sh;
-    double* gp = sh + 2 * C * nsub;
-    for (int idx = threadIdx.x; idx < C * nsub; idx += blockDim.x) {
-        const int c = idx % C, sub = idx / C;
-        const float* pp = gst + ((size_t)b * nslots * C + c) * 2;
+    double* gp = sh + 2 * Cb * nsub;
+    for (int idx = threadIdx.x; idx < Cb * nsub; idx += blockDim.x) {
+        const int c = idx % Cb, sub = idx / Cb;
+        const float* pp = gst + ((size_t)b * nslots * C + c0 + c) * 2;
         double s1 = 0.0, s2 = 0.0;
         int s = sub;
         for (; s + 3 * nsub < nslots; s += 4 * nsub) {
@@ -519,37 +554,39 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     if (nsub > 1) {
         double t1 = 0.0, t2 = 0.0;
         const int c = threadIdx.x;
-        if (c < C)
-            for (int sub = 0; sub < nsub; ++sub) { t1 += cs[2 * (sub * C + c)]; t2 += cs[2 * (sub * C + c) + 1]; }
+        if (c < Cb)
+            for (int sub = 0; sub < nsub; ++sub) { t1 += cs[2 * (sub * Cb + c)]; t2 += cs[2 * (sub * Cb + c) + 1]; }
         __syncthreads();
-        if (c < C) { cs[2 * c] = t1; cs[2 * c + 1] = t2; }
+        if (c < Cb) { cs[2 * c] = t1; cs[2 * c + 1] = t2; }
         __syncthreads();
     }
     const int G = C / GN_GROUPS;
-    if (threadIdx.x < GN_GROUPS) {
-        const int g = threadIdx.x;
+    const int ngrp = Cb / G, g0 = c0 / G;
+    if ((int)threadIdx.x < ngrp) {
+        const int gl = threadIdx.x, g = g0 + gl;
         const double mean = (double)mr[((size_t)b * GN_GROUPS + g) * 2], rstd = (double)mr[((size_t)b * GN_GROUPS + g) * 2 + 1];
         double p1 = 0.0, p2 = 0.0;
         for (int j = 0; j < G; ++j) {
-            const int c = g * G + j;
-            const double gm = (double)gamma[c];
-            p1 += gm * cs[2 * c];
-            p2 += gm * (cs[2 * c + 1] - mean * cs[2 * c]);
+            const int cl = gl * G + j;
+            const double gm = (double)gamma[c0 + cl];
+            p1 += gm * cs[2 * cl];
+            p2 += gm * (cs[2 * cl + 1] - mean * cs[2 * cl]);
         }
         p2 *= rstd;
         const double n = (double)G * (double)T;
-        gp[2 * g] = -rstd * rstd * p2 / n;                             // coefficient of x
-        gp[2 * g + 1] = rstd * rstd * p2 * mean / n - rstd * p1 / n;   // constant
+        gp[2 * gl] = -rstd * rstd * p2 / n;                             // coefficient of x
+        gp[2 * gl + 1] = rstd * rstd * p2 * mean / n - rstd * p1 / n;   // constant
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / G;
+    for (int cl = threadIdx.x; cl < Cb; cl += blockDim.x) {
+        const int c = c0 + cl;
+        const int g = c / G, gl = g - g0;
         const float mean = mr[((size_t)b * GN_GROUPS + g) * 2], rstd = mr[((size_t)b * GN_GROUPS + g) * 2 + 1];
         cA[(size_t)b * C + c] = rstd * gamma[c];
-        cB[(size_t)b * C + c] = (float)gp[2 * g];
-        cC[(size_t)b * C + c] = (float)gp[2 * g + 1];
-        atomicAdd(dgamma + c, (float)((double)rstd * (cs[2 * c + 1] - (double)mean * cs[2 * c])));
-        atomicAdd(dbeta + c, (float)cs[2 * c]);
+        cB[(size_t)b * C + c] = (float)gp[2 * gl];
+        cC[(size_t)b * C + c] = (float)gp[2 * gl + 1];
+        atomicAdd(dgamma + c, (float)((double)rstd * (cs[2 * cl + 1] - (double)mean * cs[2 * cl])));
+        atomicAdd(dbeta + c, (float)cs[2 * cl]);
     }
 }
 
@@ -658,9 +695,13 @@ extern "C" int tq_gn_bwd_finalize(const float* gstats, const float* mean_rstd, c
     if (!gstats || !mean_rstd || !gamma || !coef_a || !coef_b || !coef_c || !dgamma || !dbeta) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || C <= 0 || C % GN_GROUPS) return TQ_ERR_SHAPE;
     const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
-    const int nsub = C <= 128 ? 256 / C : 1;   // (as in the kernel)
-    const size_t sh = (size_t)(2 * C * nsub + 2 * GN_GROUPS) * sizeof(double);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), sh, stream, gstats, mean_rstd, gamma, C, T, nslots, coef_a,
+    static const int forced = [] { const char* e = getenv("TQDNE_GNBWD_PARTS"); return e ? atoi(e) : 0; }();   // (A/B switch: 1 = round 3's grid)
+    const int NP = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? forced : 4;   // 32 / NP whole groups per block
+    const int Cb = C / NP;
+    int nsub = Cb <= 128 ? 256 / Cb : 1;   // (as in the kernel)
+    if (nsub > nslots) nsub = nslots;
+    const size_t sh = (size_t)(2 * Cb * nsub + 2 * GN_GROUPS) * sizeof(double);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B, NP), dim3(256), sh, stream, gstats, mean_rstd, gamma, C, T, nslots, coef_a,
                        coef_b, coef_c, dgamma, dbeta);
     TQ_CHECK_LAUNCH();
     return 0;

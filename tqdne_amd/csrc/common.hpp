@@ -81,15 +81,25 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// counter-based dropout RNG: keep-decision for element index `idx` of site `site`.
-// (murmur3-style finaliser over a 64-bit counter; same function is re-evaluated in backward)
-__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint32_t site, uint64_t idx) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1) + idx * 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 32);
+// Counter-based dropout RNG: the keep decision of element `e` (= row * C + channel inside one sample) of sample `b` at dropout
+// site `site` is  drop_hash(drop_key(seed, site, b), e) >= threshold, re-evaluated wherever the mask is needed (forward staging,
+// weight-gradient staging, data-gradient epilogue).  Round 4: a 32-bit finaliser (two 32-bit multiplies per element) on a per-sample
+// key that the scalar unit forms once per workgroup / unit; rounds 1-3 ran a 64-bit splitmix per element (three 64-bit multiplies =
+// twelve quarter-rate 32-bit ones), which cost the dropout convs +14 % forward, +14...17 % in their weight gradient and +6...8 % in
+// their data gradient (profiles/r03_f_layers_train_b64.txt).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32" integer finaliser (bijective, full avalanche)
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
 }
+__device__ __forceinline__ uint32_t drop_key(uint64_t seed, uint32_t site, uint32_t b) {
+    uint32_t k = mix32((uint32_t)seed ^ 0x9E3779B9u);
+    k = mix32(k ^ (uint32_t)(seed >> 32));
+    k = mix32(k + 0x85EBCA6Bu * (site + 1u));
+    return mix32(k + 0xC2B2AE35u * (b + 1u));
+}
+__device__ __forceinline__ uint32_t drop_hash(uint32_t key, uint32_t e) { return mix32(e ^ key); }
 
 }  // namespace tq
 

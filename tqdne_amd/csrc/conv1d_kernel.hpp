@@ -1,0 +1,1216 @@
+// Fused 1-D convolution for the tqdne UNet on gfx950 (MI355X).
+//
+//   y[b,t,co] = bias[co] + emb[b,co] + res[b,t,co]
+//             + sum_{k,ci} W[co,ci,k] * f(x[b, t*stride + k - pad, ci])
+//   f(v) = dropout(SiLU(gscale[b,ci]*v + gshift[b,ci]))      (each stage optional)
+//
+// replaces, per call, the reference's GroupNorm32 -> SiLU -> Dropout -> Conv1d -> (+emb) -> (+skip)
+// chain (tqdne/unet.py:86-102,131-143; tqdne/blocks.py:56-66,92-101,127-145), the channel concat
+// of unet.py:396 (two source tensors, never materialised) and F.interpolate(nearest, x2) of
+// blocks.py:63 (folded into the gather index).  It also emits per-channel partial sums
+// (sum, sum of squares) of y per 128-position slot so the *next* GroupNorm needs no pass over y.
+//
+// Mapping to CDNA4:
+//   * implicit GEMM D[co][t] += W[co][ci,k] * X[ci,k][t] on v_mfma_f32_16x16x32_bf16, fp32 operands split
+//     into bf16 hi/lo and multiplied as hi*hi + hi*lo + lo*hi (fp32 accumulate): gfx950 has no TF32/xf32,
+//     and exact-f32 MFMA is 16x slower than bf16 MFMA.
+//   * A operand (weights) is pre-packed per lane (tq_pack_conv_weight) and streamed straight from L2 into
+//     registers: waves of a workgroup are split along co, so no wave re-reads another wave's weights.
+//   * B operand (activations) is staged through LDS once per 32-channel chunk: 16-byte coalesced fp32
+//     loads of channels-last rows, GN/SiLU/dropout/split in registers, 8-byte LDS stores into an
+//     XOR-swizzled [row][4 x 16B] image that the ds_write_b64 stores and the ds_read_b128 fragment reads hit
+//     conflict-free for any tap shift.  The K taps are row shifts of the same LDS image (no im2col).
+//   * double-buffered LDS, global loads for chunk c+1 issued before the MFMAs of chunk c.
+//   * epilogue: accumulator lane = 4 consecutive co at one t -> one 16-byte store per 16x16 tile.
+//
+// This header holds the kernel template and its tile dispatch; it is compiled into several translation units (one per family of
+// instantiations: conv1d_fwd_k5a.hip, conv1d_fwd_k5b.hip, conv1d_fwd_k13.hip, conv1d_resample.hip, conv1d_dgrad.hip) so that the
+// library builds in parallel; conv1d_mfma.hip holds the C ABI and the weight packers.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.hpp"
+#include "conv_args.hpp"
+#include "gn_fold.hpp"
+#include <atomic>
+#include "../../include/tqdne_hip.h"
+
+using namespace tq;
+
+#ifdef TQ_STAMP
+// diagnostic build only: per-phase wave-cycle sums (never compiled into the shipped library)
+static __device__ unsigned long long tq_stamps[12];
+#ifdef TQ_STAMP_OWNER
+extern "C" int tq_debug_read_stamps(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tq_stamps), sizeof(unsigned long long) * 12);
+    if (e != hipSuccess) return (int)e;
+    if (reset) {
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(tq_stamps), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
+// per-workgroup timeline (thread 0; plain stores, no atomics): [entry, loop begin, loop end, exit] as s_memrealtime (100 MHz)
+// in [0..3] and s_memtime (shader clock) in [4..7] -- in-kernel clock = d s_memtime / d s_memrealtime
+static __device__ unsigned long long tq_timeline[4096 * 8];
+#ifdef TQ_STAMP_OWNER
+extern "C" int tq_debug_read_timeline(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tq_timeline), sizeof(unsigned long long) * 8 * n);
+}
+#endif
+#define TQ_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define TQ_T(x)
+#endif
+
+namespace {
+
+#ifndef TQ_STAGE_PRE
+#define TQ_STAGE_PRE 5
+#endif
+
+// SCH (contraction scheme of the fp32 product x * w; both operands arrive as fp32):
+//   0  "bf16x3": x = xh + xl, w = wh + wl in bf16; xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_bf16, 32-channel chunks.
+//   1  "f16+mx8": per 64-channel chunk two v_mfma_f32_16x16x32_f16 on xh = fp16(x), wh = fp16(w), plus ONE block-scaled fp8 MFMA
+//      (v_mfma_scale_f32_16x16x128_f8f6f4) for both first-order corrections: a lane's bytes 0..15 carry fp8(xl * 2^12) against
+//      fp8(w), bytes 16..31 fp8(x) against fp8(wl * 2^12), uniform E8M0 scales 2^0 (A) and 2^-12 (B).  The corrections are 2^-12
+//      of the product, so fp8's 2^-4 leaves ~2^-15 like bf16x3, at 2/3 of its MFMA cycles.  fp16 RANGE applies to x (|x| > 65504
+//      becomes inf in the output, relative precision is lost below 6e-5): forward activations only.
+//   2  "f16+mx6": as 1, but the correction operands are e2m3 (fp6) with a per-lane E8M0 block scale (one per 16 channels x
+//      {x_l * 2^12, x}), produced by v_cvt_scalef32_2xpk16_fp6_f32: the block-scaled MFMA then takes 4 passes instead of 8 (12
+//      instead of 16 per 64 channels) and the corrections no longer clamp (fp8 with uniform scales saturates beyond |x| = 448 and
+//      |x_l| = 0.109): measured 5e-5 against 7e-4 of the output scale on heavy-tailed data (tools/micro/fp6_scheme_probe.hip).
+//      Staging layout: a thread owns 16 consecutive channels of a row (= exactly one lane fragment of the correction operand).
+// TBW: 16-position blocks per wave along t (8, or 4 for the "slim" 64-channel tile: half the accumulators, so that three or four
+// workgroups share a CU and their load / MFMA / store phases interleave -- see dispatch_tile)
+template <int KT, int STRIDE, int UPS, int WM, int WN, int SCH = 0, int TBW = 8>
+struct Cfg {
+    static constexpr int CH = SCH ? 64 : 32;     // channels per chunk
+    static constexpr int ROWB = 2 * CH;          // bytes per row of one LDS plane
+    static constexpr int TPR = (SCH == 2) ? 4 : CH / 4;  // staging threads per row (4 channels each; scheme 2: 16 channels each)
+    static constexpr int NW = SCH ? 8 : 4;       // 16-byte weight fragments per lane and (chunk, tap): 2 co blocks x NW/2
+    static constexpr int NBF = SCH ? 4 : 2;      // 16-byte activation fragments per lane and (tap, t-block)
+    static constexpr int NTHR = 64 * WM * WN;
+    static constexpr int WT = 16 * TBW;  // output positions per wave
+    static constexpr int NT = WT * WN;   // output positions per workgroup
+    static constexpr int MT = 32 * WM;   // output channels per workgroup
+    static constexpr int ROWS = (STRIDE == 1) ? (NT + KT - 1) : (2 * NT + 1);
+    static constexpr int NIT = (ROWS * TPR + NTHR - 1) / NTHR;
+    // staging iterations prefetched into registers across the MFMA phase.  The 4-wave tile of scheme 1 stages twice as many rows
+    // per thread as the 8-wave one and has no registers left for them: with 5 in flight it spilled 36 registers into the chunk
+    // loop, with 1 (the rest loaded + written in batches after the MFMAs, covered by the co-resident workgroup) none: -4 ... -10 %
+    static constexpr int PRE_MAX = (SCH == 1 && WM == 4) ? 1 : TQ_STAGE_PRE;
+    static constexpr int PRE = NIT < PRE_MAX ? NIT : PRE_MAX;
+    static constexpr int SYNC_BATCH = 4;           // the rest is loaded+written synchronously in batches
+    static constexpr int ITERS = (NIT <= PRE) ? NIT : PRE + ((NIT - PRE + SYNC_BATCH - 1) / SYNC_BATCH) * SYNC_BATCH;
+    // scheme 2 stages rows [0, NT) in NFULL full iterations of NTHR 16-channel tasks and the KT - 1 halo rows in one predicated step
+    static constexpr int NFULL = (SCH == 2) ? (NT * 4) / NTHR : 0;
+    static constexpr int HALO_TASKS = (SCH == 2) ? (ROWS - NT) * 4 : 0;
+    static constexpr int ROWS_PAD = (SCH == 2) ? ROWS : (ITERS * NTHR + TPR - 1) / TPR;  // every staging task lands in-bounds: no predicate
+    static constexpr int PLANE = (ROWS_PAD > ROWS ? ROWS_PAD : ROWS) * ROWB;  // bytes per plane
+    static constexpr int BUF = 2 * PLANE;         // hi + lo
+    static constexpr int LDS_BYTES = 2 * BUF;     // double buffered
+    static constexpr int PAD = (STRIDE == 1) ? (KT / 2) : 1;
+};
+
+// ACT (compile time): prologue applied while staging -- 0 none, 1 folded GN, 2 GN + SiLU, 3 GN + SiLU + dropout
+// FUSE: the ResBlock's 1x1 skip convolution (unet.py:112,143) is accumulated into the same MFMA accumulators as extra
+// 32-channel stages read from the block input (plain, centre tap), instead of a separate launch + residual round trip
+// PW ("pointwise, input-stationary"; 1x1 convs of the attention block, blocks.py:127-145): the whole input tile (all <= 4 chunks)
+// is staged ONCE into its own LDS buffers with every load in flight together, then the workgroup runs over all output-channel
+// tiles: no per-chunk barrier / load round trip (a 1x1 chunk has 1/5 of the MFMA work to hide one under) and no re-staging of
+// the same rows by 3 channel-tile workgroups (qkv).
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false, int TBW = 8>
+__global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_kernel(const ConvArgs p) {
+    static_assert(SCH == 0 || (EPI != 1 && STRIDE == 1), "the fp16-range scheme serves stride-1 forward launches");
+    static_assert(TBW == 8 || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW), "slim tile: bf16x3 forward, 2 x 2 waves");
+    static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH >= 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, fp16-range schemes");
+    static_assert(SCH != 2 || WN == 1, "scheme 2 tiles are 128 positions wide");
+    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef TQ_STAMP
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+
+    const int n_ttiles = (p.T_out + C::NT - 1) / C::NT;
+    const int n_ctiles = (p.C_out + C::MT - 1) / C::MT;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so ids i and i + 8 share an L2.  The channel tiles
+    // of one (b, t-tile) re-read the same input rows: give them ids 8 apart (same XCD) instead of adjacent (different XCDs).
+    int bid = blockIdx.x;
+    int ct, tile;
+    const int ntile = p.B * n_ttiles;
+    if constexpr (PW) {
+        ct = 0;  // the workgroup visits every channel tile itself
+        tile = bid;
+    } else if (n_ctiles > 1 && (ntile & 7) == 0) {
+        const int grp = bid / (8 * n_ctiles), within = bid % (8 * n_ctiles);
+        ct = within >> 3;
+        tile = grp * 8 + (within & 7);
+    } else {
+        ct = bid % n_ctiles;
+        tile = bid / n_ctiles;
+    }
+    const int tt = tile % n_ttiles;
+    const int b = tile / n_ttiles;
+    const int t0 = tt * C::NT;
+    // per-sample key of the dropout hash (scalar unit; only the dropout prologue / the data gradient's dropout chain read it)
+    const uint32_t dkey = (ACT == 3 || EPI == 1) ? drop_key(p.drop_seed, p.drop_site, (uint32_t)b) : 0u;
+    int co_wave = ct * C::MT + wm * 32;
+    const bool wave_active = co_wave < p.C_out;
+
+    const int Cin = p.C0 + p.C1;
+    const int nchunks = Cin / C::CH;
+    const int nskip = FUSE ? ((p.sC0 + p.sC1) / C::CH) : 0;
+    const int nstages = nchunks + nskip;  // stage s < nchunks: main chunk (KT taps); else skip chunk (centre tap)
+    const int T_src = UPS ? 2 * p.T_in : p.T_in;  // extent of the (virtually upsampled) input
+
+    // ---- staging bookkeeping: thread owns 4 consecutive channels (m) of rows i = (tid + it*NTHR) / TPR
+    const int m = tid % C::TPR;
+    const int wslot = m >> 1, whalf = m & 1;  // 16-byte slot (k quarter) and 8-byte half owned by this thread
+    // (the fused-skip launch of the 8-wave scheme-1 tile prefetches 4 of its 5 staging iterations and loads the last one after the
+    // MFMAs: one float4 less in flight across the chunk loop is what it takes to keep that loop free of spills)
+    // (the dropout prologue of the training forward needs more still: 1 + 4)
+    constexpr bool TIGHT = SCH == 1 && WM == 8 && C::PRE == 5 && C::NIT == 5;
+    constexpr int PRE = (TIGHT && ACT == 3) ? 1 : (TIGHT && FUSE) ? 4 : C::PRE;
+    constexpr int SYNC_BATCH = (TIGHT && ACT == 3) ? 4 : (TIGHT && FUSE) ? 1 : C::SYNC_BATCH;
+    float4 raw[PRE];
+    float4 g_a, g_s;
+
+    auto src_pos = [&](int i) -> int __attribute__((always_inline)) {
+        if (STRIDE == 1) return t0 - C::PAD + i;
+        // de-interleaved image: rows [0, NT] hold even offsets v=2*idx, rows [NT+1, 2NT] odd offsets
+        const int par = (i > C::NT) ? 1 : 0;
+        const int idx = i - par * (C::NT + 1);
+        return 2 * t0 - C::PAD + 2 * idx + par;
+    };
+
+    auto chunk_base = [&](int stage, int& cs) -> const float* __attribute__((always_inline)) {
+        const bool sk = FUSE && stage >= nchunks;
+        const int cb = (sk ? stage - nchunks : stage) * C::CH;
+        const float* a0 = sk ? p.sx0 : p.x0;
+        const float* a1 = sk ? p.sx1 : p.x1;
+        const int c0 = sk ? p.sC0 : p.C0, c1 = sk ? p.sC1 : p.C1;
+        const bool first = cb < c0;
+        const float* src = first ? a0 : a1;
+        cs = first ? c0 : c1;
+        const int coff = first ? cb : cb - c0;
+        return src + (size_t)b * p.T_in * cs + coff + 4 * m;
+    };
+
+    // branch-free: out-of-range rows load a clamped (valid) row and are zeroed in write_one -- an exec-masked load would put
+    // control flow in front of the MFMA phase and make hipcc drain every outstanding load there (s_waitcnt vmcnt(0))
+    auto load_one = [&](const float* base, int cs, int it) -> float4 __attribute__((always_inline)) {
+        const int i = (tid + it * C::NTHR) / C::TPR;
+        int pos = src_pos(i);
+        pos = pos < 0 ? 0 : (pos >= T_src ? T_src - 1 : pos);
+        const int srow = UPS ? (pos >> 1) : pos;
+        return *reinterpret_cast<const float4*>(base + (size_t)srow * cs);
+    };
+
+    // transform + split + LDS store of one staged float4: ~12 VALU per element, no branches (rows past the tile go to padding
+    // rows of the LDS image; rows outside the signal are multiplied by 0 = the conv's zero padding of the ACTIVATED input)
+    auto write_one = [&](int chunk, int buf, int it, const float4& rv) __attribute__((always_inline)) {
+        unsigned char* hi_plane = lds + buf * C::BUF;
+        unsigned char* lo_plane = hi_plane + C::PLANE;
+        const int i = (tid + it * C::NTHR) / C::TPR;
+        const int pos = src_pos(i);
+        const float msk = (pos >= 0 && pos < T_src) ? 1.f : 0.f;
+        float u[4] = {rv.x, rv.y, rv.z, rv.w};
+        const bool act = !(FUSE && chunk >= nchunks);  // skip stages stage the raw block input
+        if (ACT >= 1 && act) {
+            u[0] = fmaf(g_a.x, u[0], g_s.x); u[1] = fmaf(g_a.y, u[1], g_s.y);
+            u[2] = fmaf(g_a.z, u[2], g_s.z); u[3] = fmaf(g_a.w, u[3], g_s.w);
+        }
+        if (ACT >= 2 && act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)  // u * sigmoid(u) = u / (1 + 2^(-u*log2 e)): v_mul, v_exp, v_add, v_rcp, v_mul
+                u[j] = u[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[j] * -1.4426950408889634f));
+        }
+        if (ACT == 3 && act) {
+            const int cb = chunk * C::CH;
+            const int pc = pos < 0 ? 0 : pos;
+            const uint32_t e0 = (uint32_t)pc * (uint32_t)Cin + (uint32_t)(cb + 4 * m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                u[j] = (drop_hash(dkey, e0 + j) >= p.drop_thresh) ? u[j] * p.drop_scale : 0.f;
+        }
+        if constexpr (SCH == 0) {
+            uint32_t hb[4];
+            float lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u[j] *= msk;
+                hb[j] = __float_as_uint(u[j]) & 0xFFFF0000u;  // hi = x truncated to bf16; lo (rounded) carries the remainder
+                lo[j] = u[j] - __uint_as_float(hb[j]);
+            }
+            uint2 hv;
+            hv.x = (hb[0] >> 16) | hb[1];
+            hv.y = (hb[2] >> 16) | hb[3];
+            bf16x4 l;
+            l[0] = (__bf16)lo[0]; l[1] = (__bf16)lo[1]; l[2] = (__bf16)lo[2]; l[3] = (__bf16)lo[3];
+            const int off = i * 64 + ((wslot ^ (((i >> 2) & 1) << 1)) << 4) + (whalf << 3);
+            *reinterpret_cast<uint2*>(hi_plane + off) = hv;
+            *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
+        } else {
+            // 128-byte rows of 8 x 16-byte units, unit' = unit ^ (row & 7): conflict-free for ds_read_b128 at every row offset.
+            // Main plane: fp16(x) (round to nearest), unit = channel / 8.  Correction plane: unit g (= channel / 16) holds
+            // fp8(xl * 2^12) of channels 16g..16g+15 and unit 4 + g holds fp8(x) of the same channels, so a lane group's two
+            // reads sit at byte offsets b and b ^ 64 of the row in both planes.
+            f16x4 hv;
+            float xl[4], xc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u[j] *= msk;
+                hv[j] = (_Float16)u[j];  // |x| > 65504 -> inf, NaN stays NaN: out-of-range inputs surface in the output
+                xl[j] = __builtin_amdgcn_fmed3f(u[j] - (float)hv[j], -0.109375f, 0.109375f);  // * 2^12 stays inside e4m3 (448)
+                xc[j] = __builtin_amdgcn_fmed3f(u[j], -448.f, 448.f);                           // (the conversions do not saturate)
+            }
+            i16x2 c8 = {0, 0};
+            c8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(c8, xl[0], xl[1], 0.000244140625f, false);  // divides by the scale
+            c8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(c8, xl[2], xl[3], 0.000244140625f, true);
+            int x8 = __builtin_amdgcn_cvt_pk_fp8_f32(xc[0], xc[1], 0, false);
+            x8 = __builtin_amdgcn_cvt_pk_fp8_f32(xc[2], xc[3], x8, true);
+            const int sw = i & 7;
+            const int row = i * 128;
+            *reinterpret_cast<f16x4*>(hi_plane + row + ((wslot ^ sw) << 4) + (whalf << 3)) = hv;
+            const int g = m >> 2, byte = (m & 3) << 2;
+            *reinterpret_cast<i16x2*>(lo_plane + row + ((g ^ sw) << 4) + byte) = c8;
+            *reinterpret_cast<int*>(lo_plane + row + (((4 + g) ^ sw) << 4) + byte) = x8;
+        }
+    };
+
+    // ---- scheme 2 staging: a thread owns the 16 consecutive channels 16 m2 .. 16 m2 + 15 of a row (one lane fragment of the
+    // block-scaled operand); folded GroupNorm coefficients come from an LDS table filled once per workgroup (32 of them per
+    // thread would not fit in registers across the MFMA phase)
+    const int m2 = tid & 3;
+    float4 raw2[4];
+    float nlog2e = -1.4426950408889634f, n4096 = -4096.f;
+    asm volatile("" : "+s"(nlog2e), "+s"(n4096));  // kept in an SGPR: a literal would split the packed multiply into two scalar-literal ones
+
+    float* gtab = reinterpret_cast<float*>(lds + (PW ? 4 * C::BUF : C::LDS_BYTES));   // [Cin] scale, [Cin] shift of sample b
+    auto chunk_base2 = [&](int stage, int& cs) -> const float* __attribute__((always_inline)) {
+        const bool sk = FUSE && stage >= nchunks;
+        const int cb = (sk ? stage - nchunks : stage) * C::CH;
+        const float* a0 = sk ? p.sx0 : p.x0;
+        const float* a1 = sk ? p.sx1 : p.x1;
+        const int c0 = sk ? p.sC0 : p.C0, c1 = sk ? p.sC1 : p.C1;
+        const bool first = cb < c0;
+        cs = first ? c0 : c1;
+        return (first ? a0 : a1) + (size_t)b * p.T_in * cs + (first ? cb : cb - c0) + 16 * m2;
+    };
+    auto load16 = [&](const float* base, int cs, int row, float4 (&v)[4]) __attribute__((always_inline)) {
+        int pos = src_pos(row);
+        pos = pos < 0 ? 0 : (pos >= T_src ? T_src - 1 : pos);
+        const float4* q = reinterpret_cast<const float4*>(base + (size_t)(UPS ? (pos >> 1) : pos) * cs);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    };
+    auto write16 = [&](int chunk, int buf, int row, const float4 (&v)[4]) __attribute__((always_inline)) {
+        unsigned char* hi_plane = lds + buf * C::BUF;
+        unsigned char* lo_plane = hi_plane + C::PLANE;
+        const int pos = src_pos(row);
+        const float msk = (pos >= 0 && pos < T_src) ? 1.f : 0.f;
+        float u[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                       v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+        const bool act = !(FUSE && chunk >= nchunks);  // skip stages stage the raw block input
+        if (ACT >= 1 && act) {
+            const int cb = chunk * C::CH + 16 * m2;
+            const float4* ga = reinterpret_cast<const float4*>(gtab + cb);
+            const float4* gs = reinterpret_cast<const float4*>(gtab + Cin + cb);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 a = ga[q4], sh = gs[q4];
+                u[4 * q4 + 0] = fmaf(a.x, u[4 * q4 + 0], sh.x); u[4 * q4 + 1] = fmaf(a.y, u[4 * q4 + 1], sh.y);
+                u[4 * q4 + 2] = fmaf(a.z, u[4 * q4 + 2], sh.z); u[4 * q4 + 3] = fmaf(a.w, u[4 * q4 + 3], sh.w);
+            }
+        }
+        // Per element (this conversion runs in lock-step on both waves of a SIMD with the matrix pipe idle -- tools/stamps.py:
+        // 18 % of the chunk loop of the 512 -> 256 layer -- so every VALU instruction counts): packed fp32 ops wherever two
+        // elements share an operation; rows outside the signal are zeroed through the sigmoid (1 / (inf + e) = 0) instead of a
+        // multiplication by the mask; the fp16 remainder comes from ONE mixed-precision fma on the packed half.
+        if (ACT >= 2 && act) {
+            const float one = (pos >= 0 && pos < T_src) ? 1.0f : __builtin_inff();
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                f32x2 uu = {u[j], u[j + 1]};
+                f32x2 e = uu * nlog2e;   // u * sigmoid(u) = u / (1 + 2^(-u log2 e))
+                e = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + one;
+                uu = uu * f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+                u[j] = uu.x; u[j + 1] = uu.y;
+            }
+        }
+        const float mm = (ACT >= 2 && act) ? 1.f : msk;  // (skip stages and un-activated inputs: the plain mask)
+        if (ACT == 3 && act) {
+            const int pc = pos < 0 ? 0 : pos;
+            const uint32_t e0 = (uint32_t)pc * (uint32_t)Cin + (uint32_t)(chunk * C::CH + 16 * m2);
+            // the 16 keep decisions into a bit mask first (four hash chains at a time: 16 interleaved ones are what made the 64-bit
+            // hash of rounds 1-3 spill in this variant), then applied with static indices
+            unsigned keep = 0;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j)
+                keep |= (drop_hash(dkey, e0 + j) >= p.drop_thresh ? 1u : 0u) << j;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) u[j] = ((keep >> j) & 1u) ? u[j] * p.drop_scale : 0.f;
+        }
+        f16x8 h0, h1;
+        f32x16 xl, xf;
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            f32x2 x = {u[j], u[j + 1]};
+            if constexpr (ACT < 2 || FUSE) x = x * mm;
+            // |x| > 65504 -> inf, NaN stays NaN: out-of-range inputs surface in the output
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 hp = {(_Float16)x.x, (_Float16)x.y};
+            if (j < 8) { h0[j] = hp.x; h0[j + 1] = hp.y; } else { h1[j - 8] = hp.x; h1[j - 7] = hp.y; }
+            const f32x2 x4k = x * 4096.f;
+            // (x - fp16(x)) * 2^12 = x * 2^12 - fp16(x) * 2^12, exact (both products and their difference are representable):
+            // one v_fma_mix_f32 per element straight from the packed half (hipcc's own choice is two conversions + a packed fma)
+            float r0, r1;
+            const unsigned hpu = __builtin_bit_cast(unsigned, hp);
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hpu), "s"(n4096), "v"(x4k.x));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hpu), "s"(n4096), "v"(x4k.y));
+            xl[j] = r0; xl[j + 1] = r1; xf[j] = x.x; xf[j + 1] = x.y;
+            mx = fmaxf(fmaxf(mx, fabsf(r0)), fabsf(x.x));
+            mx = fmaxf(fmaxf(mx, fabsf(r1)), fabsf(x.y));
+        }
+        const unsigned bb = e8m0_block_scale(mx);
+        const u32x6 pk = cvt_2xpk16_fp6(xl, xf, __uint_as_float(bb << 23));
+        const int sw = row & 7;
+        const int ro = row * 128;
+        *reinterpret_cast<uint4*>(hi_plane + ro + (((2 * m2) ^ sw) << 4)) = __builtin_bit_cast(uint4, h0);
+        *reinterpret_cast<uint4*>(hi_plane + ro + (((2 * m2 + 1) ^ sw) << 4)) = __builtin_bit_cast(uint4, h1);
+        *reinterpret_cast<uint4*>(lo_plane + ro + ((m2 ^ sw) << 4)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        // the lane's E8M0 byte for the MFMA, with the 2^-12 of both correction products folded in
+        *reinterpret_cast<uint4*>(lo_plane + ro + (((4 + m2) ^ sw) << 4)) = make_uint4(pk[4], pk[5], bb - 12u, 0u);
+    };
+
+    // phase 1 (before the MFMAs of the previous chunk): issue the first PRE iterations' loads
+    auto stage_load = [&](int chunk) __attribute__((always_inline)) {
+        if constexpr (SCH == 2) {
+            int cs2;
+            const float* base2 = chunk_base2(chunk, cs2);
+            load16(base2, cs2, tid >> 2, raw2);
+            return;
+        }
+        int cs;
+        const float* base = chunk_base(chunk, cs);
+#pragma unroll
+        for (int it = 0; it < PRE; ++it) raw[it] = load_one(base, cs, it);
+        if (ACT >= 1) {  // folded GroupNorm coefficients of this thread's 4 channels (skip stages: clamped, unused)
+            const int cb = (chunk < nchunks ? chunk : nchunks - 1) * C::CH;
+            g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
+            g_s = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cb + 4 * m);
+        }
+    };
+
+    // phase 2 (after them): transform + LDS write; iterations beyond PRE are loaded here in small batches
+    auto stage_write = [&](int chunk, int buf) __attribute__((always_inline)) {
+        if constexpr (SCH == 2) {
+            int cs2;
+            const float* base2 = chunk_base2(chunk, cs2);
+            // the KT - 1 halo rows: loads issued first by every thread (tasks past the halo re-read its last row: an L1 hit),
+            // converted last, by the HALO_TASKS threads that own them -- their latency hides behind the main conversion
+            float4 hv4[4];
+            if constexpr (C::HALO_TASKS > 0) {
+                const int hr = tid >> 2;
+                load16(base2, cs2, C::NT + (hr < C::ROWS - C::NT ? hr : C::ROWS - C::NT - 1), hv4);
+            }
+            write16(chunk, buf, tid >> 2, raw2);
+#pragma unroll 1
+            for (int it = 1; it < C::NFULL; ++it) {   // (4-wave tile: second half of the rows, loaded here; prefetching it too: neutral)
+                float4 t4[4];
+                load16(base2, cs2, (tid >> 2) + it * (C::NTHR / 4), t4);
+                write16(chunk, buf, (tid >> 2) + it * (C::NTHR / 4), t4);
+            }
+            if constexpr (C::HALO_TASKS > 0) {
+                if (tid < C::HALO_TASKS) write16(chunk, buf, C::NT + (tid >> 2), hv4);
+            }
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < PRE; ++it)
+            write_one(chunk, buf, it, raw[it]);
+        if (C::NIT > PRE) {
+            int cs;
+            const float* base = chunk_base(chunk, cs);
+#pragma unroll 1
+            for (int it0 = PRE; it0 < C::NIT; it0 += SYNC_BATCH) {
+                float4 tmp[SYNC_BATCH];
+#pragma unroll
+                for (int j = 0; j < SYNC_BATCH; ++j) tmp[j] = load_one(base, cs, it0 + j);
+#pragma unroll
+                for (int j = 0; j < SYNC_BATCH; ++j) write_one(chunk, buf, it0 + j, tmp[j]);
+            }
+        }
+    };
+
+    f32x4 acc[2][TBW];
+    if constexpr (!PW) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int pw_c0 = 0;  // PW: first chunk of the pair the MFMA stream works on ("taps" of that stream = chunks = LDS buffers)
+
+    const int kq = lane >> 4;
+    const int tl_lane = wn * C::WT + (lane & 15);
+    const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * (C::NW / 2)) * 64 + lane;  // (PW: advanced per channel tile)
+    const size_t wstep = (size_t)p.ncob_pad * (C::NW / 2) * 64;  // uint4 per (chunk, tap)
+
+    // ---- MFMA phase of one chunk.  Written as straight-line code (no branches inside: hipcc's waitcnt insertion falls back to
+    // s_waitcnt vmcnt(0) / lgkmcnt(0) at every control-flow join, which serialises each prefetch with its consumer) and pinned
+    // with sched_barrier so that (1) the weight fragments of tap k+2 are requested before the MFMAs of tap k+1 and (2) the
+    // LDS reads of t-block tb+1 are in flight under the MFMAs of t-block tb.
+    const int last_step = nchunks * KT + nskip - 1;
+    // w[cbk * NW/2 + q]: scheme 0: q = 0 hi, 1 lo; scheme 1: q = 0, 1 fp16 fragments of channels [0,32), [32,64) of the chunk,
+    // q = 2 | 3 the 32 correction bytes (fp8(w) | fp8(wl * 2^12)) of channels 16 * (lane >> 4) ...
+    auto load_w = [&](int step, Frag (&w)[C::NW]) __attribute__((always_inline)) {
+        const int st = step < last_step ? step : last_step;  // clamped: the final refills re-read the last fragments
+#ifdef TQ_ABL_NOW
+        const uint4* wp = wbase + (size_t)(st & 1) * wstep;  // ablation: weights stay L1-resident
+#else
+        const uint4* wp = wbase + (size_t)st * wstep;
+#endif
+#pragma unroll
+        for (int q = 0; q < C::NW; ++q) w[q].u = wp[q * 64];
+    };
+
+    // scheme 0 LDS image: row = 64 B = 4 slots of 16 B (one k-quarter each), slot' = kq ^ (2 * ((row >> 2) & 1)): conflict-free for
+    // ds_read_b128 at every row offset (tap shift) and for the 8-byte staging stores.  Row of t-block tb is rowk + 16*tb, which
+    // leaves the swizzle term unchanged (both schemes): one address per tap, t-blocks are immediate offsets.
+    auto tap_base = [&](int k) -> int __attribute__((always_inline)) {
+        int tl = tl_lane;
+        if constexpr (SCH >= 1) {
+            // recomputed per tap (4 VALU): hoisted out of the chunk loop the per-tap addresses are live across it, get spilled,
+            // and each reload waits for vmcnt(0), i.e. for the staging loads in flight
+            asm volatile("" : "+v"(tl));
+        }
+        if constexpr (PW) return tl * 128 + ((kq ^ (tl & 7)) << 4) + (pw_c0 + k) * C::BUF;
+        const int rowk = (STRIDE == 1) ? (tl + k) : ((k & 1) * (C::NT + 1) + tl + (k >> 1));
+        if constexpr (SCH == 0) return rowk * 64 + ((kq ^ (((rowk >> 2) & 1) << 1)) << 4);
+        else return rowk * 128 + ((kq ^ (rowk & 7)) << 4);
+    };
+    auto read_b = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int b0, int tb, Frag (&f)[C::NBF])
+        __attribute__((always_inline)) {
+#ifdef TQ_ABL_NOLDS
+        const int toff = 0;
+        (void)tb;
+#else
+        const int toff = tb * 16 * C::ROWB;
+#endif
+        if constexpr (SCH == 0) {
+            f[0].u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);
+            f[1].u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);
+        } else {
+            f[0].u = *reinterpret_cast<const uint4*>(hi_plane + b0 + toff);          // fp16, channels 8 kq ...
+            f[1].u = *reinterpret_cast<const uint4*>(hi_plane + (b0 ^ 64) + toff);   // fp16, channels 32 + 8 kq ...
+            f[2].u = *reinterpret_cast<const uint4*>(lo_plane + b0 + toff);          // fp8(xl * 2^12), channels 16 kq ...
+            f[3].u = *reinterpret_cast<const uint4*>(lo_plane + (b0 ^ 64) + toff);   // fp8(x), same channels
+        }
+    };
+    // the MFMAs of one (tap, t-block) step for both 16-channel blocks of the wave
+    auto mma_step = [&](const Frag (&w)[C::NW], const Frag (&f)[C::NBF], int tb) __attribute__((always_inline)) {
+        if constexpr (SCH == 0) {
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = mfma_x3(w[cbk * 2].v, w[cbk * 2 + 1].v, f[0].v, f[1].v, acc[cbk][tb]);
+        } else if constexpr (SCH == 2) {
+            // fp6 fragments: dwords 0..5 of the i32x8 (the last two are ignored for 6-bit operands); the lane's E8M0 byte travels
+            // in dword 6 of its own fragment (weights: from the packer; activations: from write16, with the 2^-12 folded in).  (Reading
+            // dwords 4, 5 and the scale with an 8- and a 4-byte LDS read makes the six operand registers contiguous without the
+            // two v_mov per step hipcc inserts here, but those reads are 2-way bank-conflicted in this image: measured equal.)
+            const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
+                              (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
+            const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 0].u), b0v, acc[cbk][tb], 0, 0, 0);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 1].u), b1v, acc[cbk][tb], 0, 0, 0);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const Frag& c0 = w[cbk * 4 + 2];
+                const Frag& c1 = w[cbk * 4 + 3];
+                const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
+                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, (int)c1.u.z, 0, (int)f[3].u.z);
+            }
+        } else {
+            const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
+                              (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
+            const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
+            // Issue order: the four short fp16 MFMAs first (dependent ones two apart), the two long block-scaled ones last.  With
+            // the scaled MFMA first, the second accumulator's fp16 MFMA had to wait for it (16 passes against 4 of cover).
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 0].u), b0v, acc[cbk][tb], 0, 0, 0);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 1].u), b1v, acc[cbk][tb], 0, 0, 0);
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const Frag& c0 = w[cbk * 4 + 2];
+                const Frag& c1 = w[cbk * 4 + 3];
+                const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
+                // E8M0 scales: A 127 (2^0), B 115 (2^-12) on every lane: both correction products carry 2^-12
+#ifdef TQ_ABL_FP6TIME
+                // ablation (wrong numerics): the same stream with the block-scaled MFMA at its fp6 issue rate (4 passes instead of 8)
+                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, 127, 0, 115);
+#else
+                acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 0, 0, 0, 127, 0, 115);
+#endif
+            }
+        }
+    };
+
+#ifndef TQ_LDS_DEPTH
+#define TQ_LDS_DEPTH 2
+#endif
+#ifndef TQ_LDS_DEPTH1
+#define TQ_LDS_DEPTH1 1
+#endif
+    // Weight fragments live in two register buffers (taps alternate a, b, a, ...); after tap k its buffer is refilled with
+    // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
+    // b = tap 1 already in flight.
+    Frag wa[C::NW], wb[C::NW];
+#ifndef TQ_LDS_DEPTH2
+#define TQ_LDS_DEPTH2 1
+#endif
+    // scheme 1: 128 MFMA cycles per step, and registers are tight; scheme 2: 96 cycles per step, ~225 registers
+    constexpr int LDS_DEP = SCH == 2 ? TQ_LDS_DEPTH2 : (SCH ? TQ_LDS_DEPTH1 : TQ_LDS_DEPTH);
+
+    // MFMA phase of one chunk = ONE stream of NTAPS x 8 (tap, t-block) steps.  B fragments are read LDS_DEP steps ahead of the
+    // MFMAs that consume them, across tap boundaries too (a per-tap restart exposed the LDS latency KT times per chunk).
+    auto mma_stream = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int s0, auto ntaps_c, auto first_tap_c)
+        __attribute__((always_inline)) {
+        constexpr int NTAPS = decltype(ntaps_c)::value, K0 = decltype(first_tap_c)::value;
+        constexpr int DEP = LDS_DEP, NB = LDS_DEP + 1, NS = NTAPS * TBW;
+        Frag bf[NB][C::NBF];
+        int b0 = tap_base(K0), b0n = b0;
+#pragma unroll
+        for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bf[t]);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int kk = st / TBW, tb = st % TBW;
+            if (tb == 0 && kk + 1 < NTAPS) b0n = tap_base(K0 + kk + 1);
+            const int sn = st + DEP;  // step whose fragments are requested now
+            if (sn < NS) read_b(hi_plane, lo_plane, (sn / TBW) == kk ? b0 : b0n, sn % TBW, bf[sn % NB]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk & 1) mma_step(wb, bf[st % NB], tb); else mma_step(wa, bf[st % NB], tb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tb == TBW - 1) {  // tap done: refill its weight buffer two steps of the (chunk, tap) sequence ahead
+                const int nxt = (NTAPS == 1) ? (s0 + 1) : ((kk + 2 < NTAPS) ? (s0 + kk + 2) : ((kk & 1) ? (s0 + NTAPS + 1) : (s0 + NTAPS)));
+                if (kk & 1) load_w(nxt, wb); else load_w(nxt, wa);
+                b0 = b0n;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    auto compute = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const unsigned char* hi_plane = lds + buf * C::BUF;
+        mma_stream(hi_plane, hi_plane + C::PLANE, chunk * KT, std::integral_constant<int, KT>{}, std::integral_constant<int, 0>{});
+    };
+
+    // skip stage j: one (centre) tap.  Buffer a holds this step's weights and b the next one's (the last main chunk's
+    // wrap-around refills fetched skip steps 0 / 1 as "next chunk, taps 0 / 1"); b is shifted into a afterwards and refilled:
+    // every buffer access stays statically indexed (a pointer select between a and b would demote both to scratch)
+    auto compute_skip = [&](int j, int buf) __attribute__((always_inline)) {
+        const unsigned char* hi_plane = lds + buf * C::BUF;
+        const unsigned char* lo_plane = hi_plane + C::PLANE;
+        constexpr int DEP = LDS_DEP, NB = LDS_DEP + 1;
+        Frag bf[NB][C::NBF];
+        const int b0 = tap_base(C::PAD);
+#pragma unroll
+        for (int t = 0; t < DEP; ++t) read_b(hi_plane, lo_plane, b0, t, bf[t]);
+#pragma unroll
+        for (int tb = 0; tb < TBW; ++tb) {
+            if (tb + DEP < TBW) read_b(hi_plane, lo_plane, b0, tb + DEP, bf[(tb + DEP) % NB]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(wa, bf[tb % NB], tb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < C::NW; ++q) wa[q] = wb[q];
+        load_w(nchunks * KT + j + 2, wb);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if constexpr (SCH == 2 && ACT >= 1) {  // folded GroupNorm coefficients of sample b -> LDS (read by write16)
+        const float4* gsrc = reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin);
+        const float4* hsrc = reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin);
+        float4* g4 = reinterpret_cast<float4*>(gtab);
+        for (int i = tid; i < (Cin >> 2); i += C::NTHR) { g4[i] = gsrc[i]; g4[(Cin >> 2) + i] = hsrc[i]; }
+        __syncthreads();
+    }
+    const int npass = PW ? n_ctiles : 1;
+    if constexpr (PW) {
+        // every chunk's loads in flight together (64 + 32 registers, nothing else is live yet), then one transform + store pass
+        static_assert(!PW || SCH == 2 || C::NIT == C::PRE, "PW stages a chunk in PRE iterations");
+        static_assert(!PW || SCH != 2 || (C::NFULL == 1 && C::HALO_TASKS == 0), "PW, scheme 2: one 16-channel task per thread and chunk");
+        if constexpr (SCH == 2) {
+            float4 rr2[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int cs2;
+                const float* base2 = chunk_base2(c < nchunks ? c : nchunks - 1, cs2);
+                load16(base2, cs2, tid >> 2, rr2[c]);
+            }
+            load_w(0, wa);
+            load_w(1, wb);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) write16(c < nchunks ? c : nchunks - 1, c, tid >> 2, rr2[c]);
+            __syncthreads();
+        } else {
+        float4 rr[4][C::PRE], ga4[4], gs4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cc = c < nchunks ? c : nchunks - 1;  // (fewer than 4 chunks: the spare buffers get a copy of the last one)
+            int cs;
+            const float* base = chunk_base(cc, cs);
+#pragma unroll
+            for (int it = 0; it < C::PRE; ++it) rr[c][it] = load_one(base, cs, it);
+            if (ACT >= 1) {
+                ga4[c] = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cc * C::CH + 4 * m);
+                gs4[c] = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cc * C::CH + 4 * m);
+            }
+        }
+        load_w(0, wa);
+        load_w(1, wb);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (ACT >= 1) { g_a = ga4[c]; g_s = gs4[c]; }
+#pragma unroll
+            for (int it = 0; it < C::PRE; ++it) write_one(c < nchunks ? c : nchunks - 1, c, it, rr[c][it]);
+        }
+        __syncthreads();
+        }
+    }
+    int pass = 0;
+next_pass:  // (PW only: a loop statement here costs the other instantiations registers)
+    if constexpr (PW) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; 2 * j < nchunks; ++j) {
+            pw_c0 = 2 * j;
+            mma_stream(lds, lds + C::PLANE, 2 * j, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        }
+        // the next channel tile's first weights are requested BEFORE this tile's stores: vmcnt retires in order, behind the
+        // stores they would only arrive once the whole output tile has drained
+        if (pass + 1 < npass) wbase += (size_t)(C::MT >> 4) * (C::NW / 2) * 64;
+        load_w(0, wa);
+        load_w(1, wb);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        // ---- main loop over the stages (32-channel chunks of the conv input, then of the fused skip input)
+        stage_load(0);
+        if (wave_active) {
+            load_w(0, wa);
+            if (KT > 1 || nskip > 0) load_w(1, wb);
+        }
+        stage_write(0, 0);
+        __syncthreads();
+#ifdef TQ_STAMP
+        unsigned long long s_load = 0, s_mma = 0, s_write = 0, s_bar = 0;
+        const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && blockIdx.x < 4096) {
+            unsigned long long* tl = tq_timeline + blockIdx.x * 8;
+            tl[0] = r_entry; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[4] = t_entry; tl[5] = t_begin;
+        }
+#endif
+#ifdef TQ_SKEW
+        // Half-phase skew of the two waves of a SIMD (8-wave tile: waves w and w + 4 share one): waves 4-7 convert + store their
+        // share of chunk c + 1 BEFORE their MFMA phase of chunk c (from loads issued one chunk earlier), waves 0-3 after theirs, so
+        // that one of the two is in its matrix stream while the other one stages.  Same barriers, same LDS hand-over: at the start
+        // of an iteration every wave has left the MFMA phase that read the buffer about to be overwritten.
+        // Diagnostic build only (-DTQ_SKEW): parity-green and spill-free in the fp6 layout (232-242 registers), but measured no
+        // faster (18-step sample 164.7 vs 165.7 ms, single layers 0-7 % slower): moving staging between the two waves of a SIMD
+        // is zero-sum here, as MI355X_MICROARCH.md's two-waves-per-SIMD section predicts.
+        if constexpr (!FUSE && SCH == 2 && WM == 8) {
+            // (ONE copy of the MFMA stream: two copies behind a wave-uniform branch made hipcc spill ~60 registers)
+            const bool skew = wave >= 4;
+            if (skew && nstages > 1) stage_load(1);
+            for (int c = 0; c + 1 < nstages; ++c) {
+                if (skew) stage_write(c + 1, (c + 1) & 1);
+                const int nxt = c + (skew ? 2 : 1);
+                stage_load(nxt < nstages ? nxt : nstages - 1);
+                if (wave_active) compute(c, c & 1);
+                if (!skew) stage_write(c + 1, (c + 1) & 1);
+                __syncthreads();
+            }
+            if (wave_active) compute(nstages - 1, (nstages - 1) & 1);
+        } else
+#endif
+        if constexpr (!FUSE) {
+            for (int c = 0; c + 1 < nstages; ++c) {
+                TQ_T(tA)
+#ifndef TQ_ABL_NOSTAGE
+                stage_load(c + 1);  // issued before the MFMA phase; the phase's first weight waits concern older loads only
+#endif
+                TQ_T(tB)
+                if (wave_active) {
+                    if (!FUSE || c < nchunks) compute(c, c & 1);
+                    else compute_skip(c - nchunks, c & 1);
+                }
+                TQ_T(tC)
+#ifndef TQ_ABL_NOSTAGE
+                stage_write(c + 1, (c + 1) & 1);
+#endif
+                TQ_T(tD)
+                __syncthreads();
+                TQ_T(tE)
+#ifdef TQ_STAMP
+                s_load += tB - tA; s_mma += tC - tB; s_write += tD - tC; s_bar += tE - tD;
+#endif
+            }
+            if (wave_active) {
+                if (!FUSE || nskip == 0) compute(nstages - 1, (nstages - 1) & 1);
+                else compute_skip(nskip - 1, (nstages - 1) & 1);
+            }
+        } else {
+            // Fused skip conv: main chunks and skip chunks run in SEPARATE loops (one loop with a per-stage branch between the
+            // two MFMA streams cost ~50 registers: both streams' live ranges end up merged across the loop)
+            for (int c = 0; c + 1 < nchunks; ++c) {
+                stage_load(c + 1);
+                if (wave_active) compute(c, c & 1);
+                stage_write(c + 1, (c + 1) & 1);
+                __syncthreads();
+            }
+            stage_load(nchunks);  // first skip chunk, under the last main chunk
+            if (wave_active) compute(nchunks - 1, (nchunks - 1) & 1);
+            stage_write(nchunks, nchunks & 1);
+            __syncthreads();
+            for (int j = 0; j + 1 < nskip; ++j) {
+                const int st = nchunks + j;
+                stage_load(st + 1);
+                if (wave_active) compute_skip(j, st & 1);
+                stage_write(st + 1, (st + 1) & 1);
+                __syncthreads();
+            }
+            if (wave_active) compute_skip(nskip - 1, (nstages - 1) & 1);
+        }
+#ifdef TQ_STAMP
+        if (lane == 0) {
+            const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 7) {  // one workgroup's phase sums are enough (atomics from every wave perturb the kernel)
+                atomicAdd(&tq_stamps[0], s_load); atomicAdd(&tq_stamps[1], s_mma); atomicAdd(&tq_stamps[2], s_write);
+                atomicAdd(&tq_stamps[3], s_bar); atomicAdd(&tq_stamps[4], t_loop - t_begin); atomicAdd(&tq_stamps[5], 1ull);
+            }
+            if (tid == 0 && blockIdx.x < 4096) {
+                unsigned long long* tl = tq_timeline + blockIdx.x * 8;
+                tl[2] = __builtin_amdgcn_s_memrealtime(); tl[6] = t_loop;
+            }
+        }
+#endif
+
+    }
+    // ---- epilogue
+    if (!PW && !wave_active) return;
+    if constexpr (EPI == 2) {
+        // qkv projection feeding attention_fwd2 (blocks.py:139-145): q stays fp32 in the (B, T, 3 H D) tensor, k (scaled by
+        // D^-1/4 like q inside the kernel) and v are written as the bf16 hi / lo planes kv[b][h][K hi, K lo, V hi, V lo][t][d]
+        // the attention kernel streams -- instead of fp32 here plus a separate split pass over them (tq_attention_fwd)
+        const int HD = p.kvH * p.kvD;
+        const size_t plane = (size_t)p.kvTp * p.kvD * 2;  // bytes
+        float4 add[2];
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+            const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+            add[cbk] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int tb = 0; tb < TBW; ++tb) {
+            const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+            if (t < p.T_out) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk) {
+                    const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+                    const float v[4] = {acc[cbk][tb][0] + add[cbk].x, acc[cbk][tb][1] + add[cbk].y,
+                                        acc[cbk][tb][2] + add[cbk].z, acc[cbk][tb][3] + add[cbk].w};
+                    const int sec = co / HD;
+                    if (sec == 0) {
+                        *reinterpret_cast<float4*>(p.y + ((size_t)b * p.T_out + t) * p.C_out + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        const int r = co - sec * HD, h = r / p.kvD, d = r - h * p.kvD;
+                        const float sc = sec == 1 ? p.kvscale : 1.0f;
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            __bf16 a, c;
+                            split_bf16(v[j] * sc, a, c);
+                            hi[j] = a; lo[j] = c;
+                        }
+                        unsigned char* base = p.kv + (((size_t)b * p.kvH + h) * 4 + (sec == 1 ? 0 : 2)) * plane + ((size_t)t * p.kvD + d) * 2;
+                        *reinterpret_cast<bf16x4*>(base) = hi;
+                        *reinterpret_cast<bf16x4*>(base + plane) = lo;
+                    }
+                }
+            }
+        }
+    } else if constexpr (EPI == 0) {
+    // TQ_CONV_POLY2: the upper half of the (virtual) output channels is phase 1 of an upsampling conv: real channel co - C,
+    // real row 2t + 1 of a tensor with twice the rows and half the channels (a wave's 32 channels never straddle the phases)
+    const bool poly = p.flags & TQ_CONV_POLY2;
+    const int Cr = poly ? (p.C_out >> 1) : p.C_out;
+    const int ph = (poly && co_wave >= Cr) ? 1 : 0;
+    const int co_real = co_wave - ph * Cr;
+    const int slot = poly ? 2 * ((t0 >> 7) + wn) + ph : (t0 >> 7) + (TBW == 8 ? wn : 0);
+    const float* emb_b = (p.flags & TQ_CONV_EMB) ? p.emb + (size_t)b * p.emb_stride : nullptr;
+    // The two 16-channel blocks of a wave are the two 64-byte halves of one 128-byte output line: they are stored back to back
+    // (t-block outer, channel block inner).  With the channel block as the outer loop the halves reached L2 microseconds apart
+    // and PMC showed 1.46x the output bytes written to HBM.
+    float4 add[2];
+    float s1[2][4], s2[2][4];
+#pragma unroll
+    for (int cbk = 0; cbk < 2; ++cbk) {
+        const int co = co_real + cbk * 16 + 4 * (lane >> 4);
+        add[cbk] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) add[cbk] = *reinterpret_cast<const float4*>(p.bias + co);
+        if (emb_b) {
+            const float4 e = *reinterpret_cast<const float4*>(emb_b + co);
+            add[cbk].x += e.x; add[cbk].y += e.y; add[cbk].z += e.z; add[cbk].w += e.w;
+        }
+        if (FUSE && p.sbias) {
+            const float4 e = *reinterpret_cast<const float4*>(p.sbias + co);
+            add[cbk].x += e.x; add[cbk].y += e.y; add[cbk].z += e.z; add[cbk].w += e.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[cbk][j] = 0.f; s2[cbk][j] = 0.f; }
+    }
+#pragma unroll
+    for (int tb = 0; tb < TBW; ++tb) {
+        const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+        if (t < p.T_out) {
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const int co = co_real + cbk * 16 + 4 * (lane >> 4);
+                const size_t o = poly ? ((size_t)b * 2 * p.T_out + 2 * t + ph) * Cr + co : ((size_t)b * p.T_out + t) * p.C_out + co;
+                float4 v = make_float4(acc[cbk][tb][0] + add[cbk].x, acc[cbk][tb][1] + add[cbk].y,
+                                       acc[cbk][tb][2] + add[cbk].z, acc[cbk][tb][3] + add[cbk].w);
+                if (p.flags & TQ_CONV_RES) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+#ifdef TQ_ABL_NOEPI
+                if (v.x == 1.2345e30f)  // ablation: keep the arithmetic, drop the stores
+#endif
+                *reinterpret_cast<float4*>(p.y + o) = v;
+                s1[cbk][0] += v.x; s1[cbk][1] += v.y; s1[cbk][2] += v.z; s1[cbk][3] += v.w;
+                s2[cbk][0] += v.x * v.x; s2[cbk][1] += v.y * v.y; s2[cbk][2] += v.z * v.z; s2[cbk][3] += v.w * v.w;
+            }
+        }
+    }
+    if (p.flags & TQ_CONV_STATS) {
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[cbk][j] += __shfl_xor(s1[cbk][j], o);
+                    s2[cbk][j] += __shfl_xor(s2[cbk][j], o);
+                }
+            }
+        }
+        if constexpr (TBW == 4) {
+            // slim tile: the two waves of a channel half cover the two 64-position halves of ONE 128-position statistics slot; the
+            // second one hands its sums over through LDS (the staging buffers are idle) and the first one stores the slot's total
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(lds) + (wm * 4 + (lane >> 4)) * 16;   // [wm][kq][cbk][j][2]
+            if (wn == 1 && (lane & 15) == 0) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { red[(cbk * 4 + j) * 2] = s1[cbk][j]; red[(cbk * 4 + j) * 2 + 1] = s2[cbk][j]; }
+            }
+            __syncthreads();
+            if (wn == 0 && (lane & 15) == 0) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s1[cbk][j] += red[(cbk * 4 + j) * 2]; s2[cbk][j] += red[(cbk * 4 + j) * 2 + 1]; }
+            }
+        }
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+            const int co = co_real + cbk * 16 + 4 * (lane >> 4);
+            if ((lane & 15) == 0 && slot < p.nslots && (TBW == 8 || wn == 0)) {
+                float* st = p.stats + (((size_t)b * p.nslots + slot) * Cr + co) * 2;
+#ifdef TQ_BUILD_EXPERIMENTS
+                if (p.gf_counters) {
+                    // fused finalisation: the last-arriving workgroup of sample b reads these pairs in THIS launch -- 8-byte
+                    // agent-scope atomic stores (write-through, global_store_dwordx2 sc1), read back with the matching loads
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned long long u = (unsigned long long)__float_as_uint(s1[cbk][j]) |
+                                                     ((unsigned long long)__float_as_uint(s2[cbk][j]) << 32);
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(st + 2 * j), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else
+#endif
+                {
+                    *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
+                    *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
+                }
+                // range guard: max|y| <= sqrt(sum of squares); (65504 / 2)^2 = 1.0727e9.  NaN / inf fail the comparison too
+                const float q = fmaxf(fmaxf(s2[cbk][0], s2[cbk][1]), fmaxf(s2[cbk][2], s2[cbk][3]));
+                if (p.range_flag && !(q < 1.0727e9f)) *p.range_flag = 1;
+            }
+        }
+    }
+#ifdef TQ_BUILD_EXPERIMENTS
+    if constexpr (!PW) {
+        if (p.gf_counters) {   // (uniform over the launch; every wave of the workgroup is here: the host refuses ragged channel tiles)
+            // GroupNorm finalisation by the last arriver (TqGnFuse): every storing wave drains its stores, the workgroup meets, ONE
+            // lane takes the sample's ticket (agent-scope atomic add, returning); the workgroup whose ticket completes the sample
+            // -- tickets count up for ever: (ticket + 1) % workgroups-per-sample == 0 -- folds the statistics of that sample.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(lds);
+            if (tid == 0) {
+                const unsigned long long t = __hip_atomic_fetch_add(p.gf_counters + b, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = ((t + 1ull) % (unsigned long long)p.gf_narrive) == 0ull ? 1 : 0;
+            }
+            __syncthreads();
+            const bool last = *flag != 0;
+            __syncthreads();   // (the flag word is part of the fold's scratch)
+            if (last) {
+                const int Cown = poly ? Cr : p.C_out;
+                const int ns = p.nslots;
+                double* sh = reinterpret_cast<double*>(lds);
+                if (p.gf_partner_first)
+                    gn_fold_sample<false, true>(sh, b, p.gf_partner, p.gf_Cp, p.stats, Cown, poly ? 2 * p.T_out : p.T_out, ns, p.gf_gamma,
+                                                p.gf_beta, p.gf_gscale, p.gf_gshift, p.gf_mean_rstd);
+                else
+                    gn_fold_sample<true, false>(sh, b, p.stats, Cown, p.gf_partner, p.gf_Cp, poly ? 2 * p.T_out : p.T_out, ns, p.gf_gamma,
+                                                p.gf_beta, p.gf_gscale, p.gf_gshift, p.gf_mean_rstd);
+            }
+        }
+    }
+#endif
+    } else {
+        // data gradient: acc = d loss / d xhat.  Chain through dropout, SiLU and the folded GroupNorm scale of the
+        // FORWARD conv's prologue:  g = acc * mask/(1-p) * silu'(u), u = a*x + s  (the GN statistics' own dependence
+        // on x is handled by tq_gn_bwd_finalize / tq_gn_bwd_apply from the partial sums (sum g, sum g*x) emitted here)
+        const int slot = (t0 >> 7) + wn;
+        const int Ctot = p.C_out;
+        // as in the forward epilogue: t-block outer, channel block inner, so the two halves of a 128-byte line are stored together
+        float* dst[2]; const float* fx[2]; int cs[2], cc[2];
+        float4 ga[2], gs[2];
+        float s1[2][4], s2[2][4];
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+            const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+            if (co < p.OC0) { dst[cbk] = p.y; fx[cbk] = p.fx0; cs[cbk] = p.OC0; cc[cbk] = co; }
+            else            { dst[cbk] = p.y1; fx[cbk] = p.fx1; cs[cbk] = Ctot - p.OC0; cc[cbk] = co - p.OC0; }
+            ga[cbk] = make_float4(1.f, 1.f, 1.f, 1.f); gs[cbk] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bflags & TQ_BWD_GN) {
+                ga[cbk] = *reinterpret_cast<const float4*>(p.fgs + (size_t)b * Ctot + co);
+                gs[cbk] = *reinterpret_cast<const float4*>(p.fgh + (size_t)b * Ctot + co);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[cbk][j] = 0.f; s2[cbk][j] = 0.f; }
+        }
+#pragma unroll
+        for (int tb = 0; tb < TBW; ++tb) {
+            const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+            if (t < p.T_out) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk) {
+                    const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+                    const size_t o = ((size_t)b * p.T_out + t) * cs[cbk] + cc[cbk];
+                    float v[4] = {acc[cbk][tb][0], acc[cbk][tb][1], acc[cbk][tb][2], acc[cbk][tb][3]};
+                    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bflags & (TQ_BWD_GN | TQ_BWD_SILU | TQ_BWD_STATS)) {
+                        const float4 x4 = *reinterpret_cast<const float4*>(fx[cbk] + o);
+                        xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                    }
+                    if (p.bflags & TQ_BWD_SILU) {
+                        const float a4[4] = {ga[cbk].x, ga[cbk].y, ga[cbk].z, ga[cbk].w};
+                        const float h4[4] = {gs[cbk].x, gs[cbk].y, gs[cbk].z, gs[cbk].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= dsilu_f(a4[j] * xv[j] + h4[j]);
+                    }
+                    if (p.bflags & TQ_BWD_DROPOUT) {
+                        const uint32_t e0 = (uint32_t)t * (uint32_t)Ctot + (uint32_t)co;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[j] = (drop_hash(dkey, e0 + j) >= p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+                    }
+                    if (p.bflags & TQ_BWD_ACCUM) {
+                        const float4 r = *reinterpret_cast<const float4*>(dst[cbk] + o);
+                        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                    }
+                    *reinterpret_cast<float4*>(dst[cbk] + o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s1[cbk][j] += v[j]; s2[cbk][j] += v[j] * xv[j]; }
+                }
+            }
+        }
+        if (p.bflags & TQ_BWD_STATS) {
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        s1[cbk][j] += __shfl_xor(s1[cbk][j], o);
+                        s2[cbk][j] += __shfl_xor(s2[cbk][j], o);
+                    }
+                }
+                if ((lane & 15) == 0 && slot < p.nslots) {
+                    float* st = p.stats + (((size_t)b * p.nslots + slot) * Ctot + co) * 2;
+                    *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
+                    *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
+                }
+            }
+        }
+    }
+    if constexpr (PW) {
+        co_wave += C::MT;
+        if (++pass < npass) goto next_pass;
+    }
+#ifdef TQ_STAMP
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned long long* tl = tq_timeline + blockIdx.x * 8;
+        tl[3] = __builtin_amdgcn_s_memrealtime(); tl[7] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+}
+
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH = 0, bool PW = false, int TBW = 8>
+int launch(const ConvArgs& a, hipStream_t stream) {
+    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW, TBW>;
+    // scheme 2 keeps the folded GroupNorm coefficients of the workgroup's sample behind the staging buffers (2 x C_in floats)
+    constexpr int GTAB_MAX = (SCH == 2 && ACT >= 1) ? 2 * 4 * 1024 : 0;   // room for C_in <= 1024
+    constexpr int LDS_BYTES = (PW ? 4 * C::BUF : C::LDS_BYTES) + GTAB_MAX;
+    if (SCH == 2 && a.C0 + a.C1 > 1024) return TQ_ERR_SHAPE;
+    // The dynamic-LDS limit is a per-device property of the kernel: remember, per device ordinal, that it has been raised
+    // (idempotent call: two threads racing here both set the same value; the mask only saves the repeated runtime call).
+    static std::atomic<uint64_t> attr_done{0};
+    int dev_ord = 0;
+    (void)hipGetDevice(&dev_ord);
+    const uint64_t dev_bit = 1ull << (dev_ord & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & dev_bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done.fetch_or(dev_bit, std::memory_order_release);
+    }
+    const int n_ttiles = (a.T_out + C::NT - 1) / C::NT;
+    const int n_ctiles = (a.C_out + C::MT - 1) / C::MT;
+    const unsigned grid = (unsigned)(a.B * n_ttiles * (PW ? 1 : n_ctiles));
+#ifdef TQ_BUILD_EXPERIMENTS
+    if (a.gf_counters) {
+        // fused GroupNorm finalisation: every workgroup of a sample takes a ticket -- all its waves must reach the epilogue (no ragged
+        // channel tile) and the fold's scratch (2 C + 64 doubles) must fit the staging buffers it reuses
+        const int Ctot = ((a.flags & TQ_CONV_POLY2) ? a.C_out / 2 : a.C_out) + a.gf_Cp;
+        if (PW || EPI != 0 || (a.C_out % C::MT) || (size_t)(2 * Ctot + 64) * sizeof(double) > (size_t)LDS_BYTES) return TQ_ERR_SHAPE;
+        ConvArgs a2 = a;
+        a2.gf_narrive = n_ttiles * n_ctiles;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), LDS_BYTES, stream, a2);
+        TQ_CHECK_LAUNCH();
+        return 0;
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), LDS_BYTES, stream, a);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
+int dispatch_tile(const ConvArgs& a, hipStream_t s) {
+    if (a.wfmt == TQ_WFMT_F16_MX6) {  // same shapes as TQ_WFMT_F16_MX8 (below), fp6 block-scaled corrections
+        if constexpr (STRIDE == 1 && EPI != 1) {
+            if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
+            if constexpr (KT == 1 && UPS == 0 && ACT <= 1) {
+                const int cin = a.C0 + a.C1;
+                if (a.C_out % 256 == 0 && a.C_out >= 512 && (cin == 128 || cin == 256))
+                    return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2, true>(a, s);
+            }
+            // (256-channel outputs as two co-resident 4-wave workgroups instead of one 8-wave one: measured 2-8 % slower per layer)
+            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
+            if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 2>(a, s);
+        }
+        return TQ_ERR_SHAPE;
+    }
+    if (a.wfmt == TQ_WFMT_F16_MX8) {  // built for stride-1 forward launches with 128 | C_out and 64-channel sources; with the fused
+        // skip conv only for the 256-channel tile (the 128-channel one has 4 of its 8 waves' worth of registers to hide latency
+        // with and spills > 100 of them)
+        if constexpr (STRIDE == 1 && EPI != 1) {
+
+            if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
+            if constexpr (KT == 1 && UPS == 0 && ACT <= 1) {  // the attention block's 1x1 convs: input-stationary variant
+                const int cin = a.C0 + a.C1;
+                // (one channel tile, i.e. proj_out: nothing to share, measured equal -> the generic path)
+                if (a.C_out % 256 == 0 && a.C_out >= 512 && (cin == 128 || cin == 256))
+                    return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1, true>(a, s);
+            }
+            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 1>(a, s);
+            if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 1>(a, s);
+        }
+        return TQ_ERR_SHAPE;
+    }
+    if (a.wfmt != TQ_WFMT_BF16X3) return TQ_ERR_ARG;
+    // 256 output channels: one 8-wave workgroup stages each input tile once instead of two 4-wave workgroups staging it
+    // twice (measured -32 % for pointwise convs, which are staging-bound, and -2...-5 % for k = 5)
+    if constexpr (STRIDE == 1 && UPS == 0) {
+        if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE>(a, s);
+    }
+    if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE>(a, s);
+    if constexpr (STRIDE == 1) {
+#ifdef TQ_BUILD_EXPERIMENTS
+        if constexpr (UPS == 0 && EPI == 0 && KT == 5 && ACT != 3) {   // (the dropout prologue spills in this tile: training keeps 64 x 256)
+            // 64-channel outputs at T = 4096 are bound by their load / store bursts, not by MFMA cycles (section 5 of DESIGN.md).
+            // The slim tile (64 channels x 128 positions, 32 accumulator registers per wave, 152-168 registers) lets three
+            // workgroups share a CU instead of two.  Measured (tools/slim_ab.py, B = 64, same box, bit-identical outputs): SLOWER --
+            // 64 -> 64: 52-55 vs 50 us, 64+64 -> 64: 90 vs 82, 128+64 -> 64: 118-123 vs 115: 2048 tiles on 768 slots are 2.7 rounds
+            // where 1024 tiles on 512 slots are exactly 2, and every tile re-streams the weights and 4 halo rows for half the
+            // positions.  Off by default; TQDNE_CONV_SLIM=1 selects it.
+            static const int slim = [] { const char* e = getenv("TQDNE_CONV_SLIM"); return (e && e[0] == '1') ? 1 : 0; }();
+            if (slim && a.C_out % 64 == 0 && !(a.flags & TQ_CONV_POLY2))
+                return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT, FUSE, 0, false, 4>(a, s);
+        }
+#endif
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT, FUSE>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 2, EPI, ACT, FUSE>(a, s);
+    } else {
+        if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1, EPI, ACT, FUSE>(a, s);
+        return launch<KT, STRIDE, UPS, 1, 1, EPI, ACT, FUSE>(a, s);
+    }
+}
+
+// forward prologue variants; strided / upsampled convs and data gradients only exist un-activated in the networks served
+template <int KT>
+int dispatch_act(const ConvArgs& a, hipStream_t s) {
+    const bool gn = a.flags & TQ_CONV_GN, silu = a.flags & TQ_CONV_SILU, drop = a.flags & TQ_CONV_DROPOUT;
+    if ((!gn && silu) || (drop && !silu)) return TQ_ERR_ARG;  // supported prologues: none | GN | GN+SiLU | GN+SiLU+dropout
+    if (a.sx0) {  // fused 1x1 skip conv: built for the ResBlock's second conv (k = 5, GN + SiLU [+ dropout])
+        if constexpr (KT == 5) {
+            if (gn && silu && drop) return dispatch_tile<KT, 1, 0, 0, 3, true>(a, s);
+            if (gn && silu) return dispatch_tile<KT, 1, 0, 0, 2, true>(a, s);
+        }
+        return TQ_ERR_SHAPE;
+    }
+    if (gn && silu && drop) return dispatch_tile<KT, 1, 0, 0, 3>(a, s);
+    if (gn && silu) return dispatch_tile<KT, 1, 0, 0, 2>(a, s);
+    if (gn) return dispatch_tile<KT, 1, 0, 0, 1>(a, s);
+    return dispatch_tile<KT, 1, 0, 0, 0>(a, s);
+}
+
+}  // namespace

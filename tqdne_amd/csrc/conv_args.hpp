@@ -72,8 +72,19 @@ __device__ __forceinline__ unsigned e8m0_block_scale(float mx) {
 }
 
 
-// conv1d_w4.hip: the one-wave-per-SIMD variant of the stride-1 forward launches in the fp16 + MX-fp6 scheme.  Returns TQ_ERR_SHAPE
-// (nothing launched) for a launch it is not built for; the caller then takes the two-waves-per-SIMD kernel.
+// Entry points of the translation units that instantiate conv1d_kernel.hpp (split so that the library builds in parallel); each
+// returns 0, a TQ_ERR_* code or a hipError_t like the C ABI.
+int conv_launch_fwd_k1(const ConvArgs& a, hipStream_t stream);
+int conv_launch_fwd_k3(const ConvArgs& a, hipStream_t stream);
+int conv_launch_fwd_k5(const ConvArgs& a, hipStream_t stream);    // conv1d_fwd_k5a.hip (hands dropout / fused-skip launches to k5b)
+int conv_launch_fwd_k5b(const ConvArgs& a, hipStream_t stream);
+int conv_launch_qkv(const ConvArgs& a, hipStream_t stream);
+int conv_launch_resample(const ConvArgs& a, int ktaps, int stride, hipStream_t stream);
+int conv_launch_dgrad(const ConvArgs& a, int ktaps, hipStream_t stream);
+
+// conv1d_w4.hip (TQDNE_BUILD_EXPERIMENTS builds only): the one-wave-per-SIMD variant of the stride-1 forward launches in the fp16 +
+// MX-fp6 scheme.  Returns TQ_ERR_SHAPE (nothing launched) for a launch it is not built for; the caller then takes the
+// two-waves-per-SIMD kernel.
 int conv1d_w4_launch(const ConvArgs& a, int ktaps, hipStream_t stream);
 
 }  // namespace tq

@@ -9,6 +9,13 @@
 using namespace tq;
 
 extern "C" int tq_abi_version(void) { return TQ_ABI_VERSION; }
+extern "C" int tq_build_flags(void) {
+#ifdef TQ_BUILD_EXPERIMENTS
+    return TQ_BUILD_EXPERIMENTS_BIT;
+#else
+    return 0;
+#endif
+}
 
 // =================================================================================================
 // GroupNorm32 finalisation: per-channel partial (sum, sumsq) of up to two concatenated sources ->

@@ -62,6 +62,7 @@ FUSE_SKIP = os.environ.get("TQDNE_FUSE_SKIP", "1") != "0"  # A/B switch for the 
 # tq_gn_finalize launch per GroupNorm: TQDNE_GN_FUSE=1.  Built, parity- and concurrency-tested (tests/test_concurrency.py), and
 # measured NEUTRAL (18-step sample at B = 64, 4 lanes: 165.7 vs 166.0 ms; 1 lane 174.5 vs 172.8; tiny UNet B = 4: 41.9 vs 41.6 ms):
 # what the 49 launches cost comes back as the fold's dependent-load chain on the tail of the producing launch -> off by default
+# (an experiment since round 4: only libraries built with TQDNE_BUILD_EXPERIMENTS=1 carry it)
 GN_FUSE = os.environ.get("TQDNE_GN_FUSE", "0") == "1"
 FUSE_SKIP_CO = 32  # smallest output-channel multiple fused (measured: 128 -> +3.9 %, 64 -> +1.3 % more on the bench step)
 
@@ -355,6 +356,8 @@ class UNetEngine:
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) > 1 else None
         prod = s0.prod if GN_FUSE else None
+        if GN_FUSE and not _lib.has_experiments():
+            raise RuntimeError("TQDNE_GN_FUSE=1 needs the experiments build of the library (TQDNE_BUILD_EXPERIMENTS=1)")
         if prod and all(not d.gn_fuse for d in prod):
             for d in prod:   # (one TqGnFuse and one ticket counter per launch form: the forms tile the tensor differently)
                 f = _lib.TqGnFuse()

@@ -5,7 +5,7 @@ DistributedSampler's rank offset), so the noise levels, the noise and the dropou
 (experiments/train_1d_edm.py:34-41; tqdne/edm.py:126-134; tqdne/unet.py:101).  Here
 
 * ``seed_rank(seed, rank)`` seeds torch's generators with ``seed + rank`` (eps / noise draws) and records the rank,
-* ``next_dropout_seed()`` hands the HIP kernels' counter-based dropout hash (csrc/common.hpp ``hash_u32``) a 64-bit seed
+* ``next_dropout_seed()`` hands the HIP kernels' counter-based dropout hash (csrc/common.hpp ``drop_key`` / ``drop_hash``) a 64-bit seed
   built from (torch's initial seed, the rank, a per-process call counter): masks differ between ranks and between
   steps, and are reproducible for a fixed (seed, rank, call number).
 """
