@@ -297,7 +297,7 @@ def other_configs(dev, args):
 
         ms, ms_train = med(step), med(train_only)
         r = dict(config="cfg0: tiny 1-D EDM UNet (32 base channels, 2 res blocks, no attention), B=4, 3x4096: 1 train step + "
-                        f"{args.sample_steps}-step Heun sample (whole integration replayed from one HIP graph)",
+                        f"{args.sample_steps}-step Heun sample",
                  value=B / (ms * 1e-3), unit="waveforms/s", ms_per_step=ms, parts=dict(train_ms=ms_train, sample_ms=ms - ms_train))
         if not args.no_cpu_baseline:
             try:
@@ -520,7 +520,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true", help="replay the whole sampler integration from one HIP graph (neutral at B=64: GPU-bound)")
     ap.add_argument("--no-auto-graph", dest="auto_graph", action="store_false",
-                    help="never graph-replay the sampler (default: the sampler's own choice, a whole-loop graph for B <= 16)")
+                    help="never graph-replay the sampler (default: the sampler's own choice: eager unless TQDNE_SAMPLER_GRAPH=1)")
     args = ap.parse_args()
     if args.no_train:
         args.mode = "sample"
@@ -602,7 +602,7 @@ def main():
     sigmas = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
     eps0 = start_noise * sigmas[0]
     eps32 = start_noise.float()
-    use_graph = True if args.graph else (None if args.auto_graph else False)   # None: the sampler's own choice (graph for B <= 16)
+    use_graph = True if args.graph else (None if args.auto_graph else False)   # None: the sampler's own choice (eager unless TQDNE_SAMPLER_GRAPH=1)
 
     # HIP-event probe around the dominant kernel (the heaviest k=5 conv launch of the forward)
     eng = edm.unet._engine(B, T, dev)
@@ -814,8 +814,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (contractions on MFMA with fp32 accumulate: bf16x3, and fp16 + block-scaled-fp6 corrections on the 128/256-channel forward convs; sampler state f64)", "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}",
-                       "hip_graph": bool(use_graph) or (use_graph is None and B <= 16),
-                       "sampler_lanes": 1 if (use_graph or (use_graph is None and B <= 16)) else sampler_lanes(B), "mode": args.mode},
+                       "hip_graph": bool(use_graph) or (use_graph is None and os.environ.get("TQDNE_SAMPLER_GRAPH") == "1"),
+                       "sampler_lanes": 1 if (use_graph or (use_graph is None and os.environ.get("TQDNE_SAMPLER_GRAPH") == "1")) else sampler_lanes(B),
+                       "mode": args.mode},
             "parts": parts,
             "rccl_ranks": rccl_ranks, "rccl_ranks_ok": rccl_ranks == world and first_collective_ranks == world,
             "replicas_equal": replicas["after_broadcast"] and replicas["after_timed_steps"], "replicas": replicas,

@@ -195,6 +195,8 @@ int tq_stem_conv_fwd(const float* x_nct, const float* in_scale, const float* w, 
 /* Last conv: GroupNorm32+SiLU (folded scale/shift) -> conv k "same" to C_out<=16 -> (B, C_out, T) output,
  * then out = c_out[b] * conv + c_skip[b] * skip_src[b, co, t]  (EDM / consistency preconditioning, edm.py:111-113,
  * consistency_model.py:78); c_out/c_skip/skip_src NULL = plain conv output.  unet.py:355-357,398. */
+/* LDS bytes tq_head_conv_fwd needs for a shape; 0 = unsupported shape (16 | C_in <= 128, C_out <= 16, k in {1, 3, 5}, <= 64 KB). */
+size_t tq_head_conv_lds_bytes(int C_in, int C_out, int ktaps);
 int tq_head_conv_fwd(const float* x, const float* gscale, const float* gshift, const float* w, const float* bias,
                      const float* c_out, const float* c_skip, const float* skip_src, float* y_nct, int B, int T, int C_in,
                      int C_out, int ktaps, hipStream_t stream);

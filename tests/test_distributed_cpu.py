@@ -214,3 +214,50 @@ def test_bench_watchdog_reports_a_hung_rendezvous():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["value"] is None and d["stage"] == "init_process_group" and "did not complete" in d["error"] and d["n_gpus"] == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------- range-guard flag, N > 1
+def _skip_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tqdne_amd.trainer import DataParallelTrainer
+
+    class T(DataParallelTrainer):
+        AGREE_EVERY = 4
+
+        def __init__(self):   # (only what _range_skip_flag touches)
+            self.world, self.group, self.fused = world, None, True
+            self.flag = torch.zeros(1, dtype=torch.int32)
+            self.auto = True
+
+        def _local_range_flag(self):
+            return self.flag, self.auto
+
+    t = T()
+    log = []
+    for step in range(1, 11):
+        if step == 2 and rank == 1:
+            t.flag.fill_(1)            # only rank 1's forward came near the fp16 range
+        if step == 3 and rank == 1:
+            t.flag.zero_(); t.auto = False    # ... its host has moved its plans to bf16x3
+        if step == 5 and rank == 0:
+            t.auto = False             # rank 0 follows later
+        f = t._range_skip_flag()
+        log.append(None if f is None else (float(f[0]) != 0.0, float(f[1])))
+    ret[rank] = log
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_range_flag_raised_by_one_rank_skips_on_all_and_the_exchange_ends_by_agreement():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_skip_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0] == ret[1], (ret[0], ret[1])          # every rank sees the same predicate at every step: replicas stay equal
+    log = ret[0]
+    assert log[0] == (False, 0.0) and log[1] == (True, 0.0)            # step 2: rank 1's flag drops the step on BOTH ranks
+    assert log[2] == (False, 1.0) and log[4] == (False, 2.0)           # off-scheme ranks are counted
+    assert log[7] == (False, 2.0) and log[8] is None and log[9] is None   # agreed at step 8 (AGREE_EVERY = 4): no more collectives

@@ -100,6 +100,7 @@ _PROTOS = {
     "tq_conv1d_fwd_skip": (I, [C.POINTER(TqConvDesc)] + [VP] * 13),
     "tq_stem_conv_fwd": (I, [VP] * 6 + [I] * 5 + [VP]),
     "tq_head_conv_fwd": (I, [VP] * 9 + [I] * 5 + [VP]),
+    "tq_head_conv_lds_bytes": (SZ, [I, I, I]),
     "tq_gn_finalize": (I, [VP, I, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
     "tq_embed_fwd": (I, [VP] * 14 + [I, I, I, VP]),
     "tq_linear_fwd": (I, [VP] * 4 + [I, I, I, VP]),

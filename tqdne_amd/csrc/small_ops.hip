@@ -286,18 +286,28 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
 }
 }  // namespace
 
+// dynamic LDS of head_conv_kernel for a shape, or 0 when the kernel is not built for it (the one place that knows the limits: the
+// launcher below and the plan builder, through tq_head_conv_lds_bytes, both ask here)
+static size_t head_conv_lds(int C_in, int C_out, int ktaps) {
+    if (C_in < 16 || C_in % 16 || C_in > 128 || C_out < 1 || C_out > 16 || (ktaps != 1 && ktaps != 3 && ktaps != 5)) return 0;
+    const int maxco = C_out <= 4 ? 4 : 16;
+    const size_t sh = ((size_t)C_in * ktaps * maxco + (size_t)128 * ktaps * maxco) * sizeof(float);
+    return sh > 64 * 1024 ? 0 : sh;
+}
+
+extern "C" size_t tq_head_conv_lds_bytes(int C_in, int C_out, int ktaps) { return head_conv_lds(C_in, C_out, ktaps); }
+
 extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float* gshift, const float* w, const float* bias,
                                 const float* c_out, const float* c_skip, const float* skip_src, float* y, int B, int T,
                                 int C_in, int C_out, int ktaps, hipStream_t stream) {
     if (!x || !w || !y) return TQ_ERR_ARG;
     if ((gscale == nullptr) != (gshift == nullptr)) return TQ_ERR_ARG;
     if (c_out && (!c_skip || !skip_src)) return TQ_ERR_ARG;
-    if (B <= 0 || T <= 0 || C_in < 16 || C_in % 16 || C_in > 128 || C_out < 1 || C_out > 16) return TQ_ERR_SHAPE;
+    const size_t sh = head_conv_lds(C_in, C_out, ktaps);
+    if (B <= 0 || T <= 0 || sh == 0) return TQ_ERR_SHAPE;
     const int nout = 128 - (ktaps - 1);   // output positions per workgroup (head_conv_kernel's NOUT)
     const int ntiles = (T + nout - 1) / nout;
     const int maxco = C_out <= 4 ? 4 : 16;
-    const size_t sh = ((size_t)C_in * ktaps * maxco + (size_t)128 * ktaps * maxco) * sizeof(float);
-    if (sh > 64 * 1024) return TQ_ERR_SHAPE;
 #define TQ_HEAD(K)                                                                                          \
     {                                                                                                       \
         auto kern = (maxco == 4) ? head_conv_kernel<K, 4> : head_conv_kernel<K, 16>;                        \

@@ -35,7 +35,16 @@ class DDPMScheduler:
 
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 1e-4, beta_end: float = 0.02,
                  beta_schedule: str = "linear", prediction_type: str = "epsilon", clip_sample: bool = True,
-                 clip_sample_range: float = 1.0, variance_type: str = "fixed_small"):
+                 clip_sample_range: float = 1.0, variance_type: str = "fixed_small", trained_betas=None,
+                 thresholding: bool = False, dynamic_thresholding_ratio: float = 0.995, sample_max_value: float = 1.0,
+                 timestep_spacing: str = "leading", steps_offset: int = 0, rescale_betas_zero_snr: bool = False):
+        # the remaining constructor arguments of the diffusers class are accepted at their documented defaults only: anything else
+        # would select arithmetic this restatement does not have (and cannot pin: diffusers is not in the reference's lockfile)
+        for name, val, default in (("trained_betas", trained_betas, None), ("thresholding", thresholding, False),
+                                   ("timestep_spacing", timestep_spacing, "leading"), ("steps_offset", steps_offset, 0),
+                                   ("rescale_betas_zero_snr", rescale_betas_zero_snr, False)):
+            if val != default:
+                raise NotImplementedError(f"DDPMScheduler({name}={val!r}): only the default ({default!r}) is restated")
         if beta_schedule != "linear":
             raise NotImplementedError("only the linear beta schedule (the class default) is restated")
         if prediction_type not in ("epsilon", "sample"):
@@ -102,21 +111,23 @@ class DDPMScheduler:
             sigma = 0.0
         return math.sqrt(beta_prod_t), 1.0 / math.sqrt(abar_t), coef_x0, coef_xt, sigma
 
-    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, noise: torch.Tensor = None):
-        """``noise``: the step's N(0, I) draw (tests inject it); default: drawn here, as the reference's scheduler does."""
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, noise: torch.Tensor = None, generator=None,
+             return_dict: bool = True):
+        """``noise``: the step's N(0, I) draw (tests inject it); default: drawn here -- from ``generator`` when given -- as the
+        reference's scheduler does."""
         engine.require_device(sample)
         t = int(timestep)
         s1, inv, c0, ct, sigma = self.step_coefficients(t)
         x, mo = sample.contiguous().float(), model_output.contiguous().float()
         if sigma > 0.0 and noise is None:
-            noise = torch.randn_like(x)
+            noise = torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=generator)
         z = noise.contiguous().float() if (sigma > 0.0 and noise is not None) else None
         out = torch.empty_like(x)
         clip = float(self.config.clip_sample_range) if self.config.clip_sample else 0.0
         stream = torch.cuda.current_stream(x.device).cuda_stream
         check(_lib.load().tq_ddpm_step(_p(x), _p(mo), _p(z), _p(out), x.numel(), int(self.config.prediction_type == "epsilon"),
                                        s1, inv, clip, c0, ct, sigma, stream), "ddpm step")
-        return SimpleNamespace(prev_sample=out)
+        return SimpleNamespace(prev_sample=out) if return_dict else (out,)
 
 
 def get_cosine_schedule_with_warmup(optimizer, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5):
@@ -139,7 +150,7 @@ class _DDPMLossFn(torch.autograd.Function):
         dev = signal.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         noisy = module.noise_scheduler.add_noise(signal, noise, timesteps)
-        x_in = torch.cat((cond_signal, noisy), dim=1).contiguous() if module.cond_signal_input else noisy
+        x_in = torch.cat((cond_signal.float(), noisy), dim=1).contiguous() if module.cond_signal_input else noisy
         B, _, T = x_in.shape
         eng = module.net._engine(B, T, dev)
         train = module.training

@@ -280,15 +280,14 @@ class LightningEDM(LightningModule):
 
         ``use_graph``: True replays the WHOLE integration (every network evaluation and every fp64 update of all steps) from one
         HIP graph captured on first use -- one host call per sample instead of ~100 launches per network evaluation; "denoiser" is
-        round 1's form (one captured network evaluation, replayed per NFE); False launches eagerly.  Default (None): the whole-loop
-        graph for launch-bound batches (B <= 16: a tiny-UNet evaluation at B = 4 is ~90 launches of a few microseconds each, the
-        host cannot issue them as fast as the GPU retires them), eager otherwise (TQDNE_SAMPLER_GRAPH=0 / 1 overrides)."""
+        round 1's form (one captured network evaluation, replayed per NFE); False launches eagerly.  Default (None): eager, unless
+        TQDNE_SAMPLER_GRAPH=1.  Opt-in since round 4: measured neutral even for launch-bound batches (tiny UNet, B = 4: the GPU-side
+        kernel boundaries bound the loop, not the host), and a capture on first use inside a validation loop is exposed to whatever
+        other threads do with the device meanwhile (the capture is thread-local for that reason)."""
         if not eps.is_cuda:
             raise RuntimeError("tqdne_amd samples on MI355X HIP kernels only; got a CPU start state")
         if use_graph is None:
-            env = os.environ.get("TQDNE_SAMPLER_GRAPH")
-            use_graph = (env == "1") if env in ("0", "1") else (eps.shape[0] <= 16 and lanes is None
-                                                                 and not th.cuda.is_current_stream_capturing())
+            use_graph = os.environ.get("TQDNE_SAMPLER_GRAPH") == "1" and lanes is None and not th.cuda.is_current_stream_capturing()
         out = self._sample_det(eps, sigmas, cond_sample, cond, use_graph, lanes)
         # range guard of the fp16-range conv scheme: one flag read per sample call; if a tensor came near the fp16 range the plans
         # have been moved to bf16x3 and the integration is repeated
@@ -423,8 +422,9 @@ class LightningEDM(LightningModule):
         nsig = int(sigmas.numel())
         key = (nsig, None if cond is None else tuple(cond.shape), None if cond_sample is None else tuple(cond_sample.shape),
                eng.plan_epoch, self.num_sampling_steps)
-        g = bufs.get("loop_graph")
-        if g is None or g["key"] != key:
+        cache = bufs.setdefault("loop_graphs", {})   # one captured loop per key (a sweep over step counts re-uses them)
+        g = cache.get(key)
+        if g is None:
             st = dict(key=key, sig=th.empty(nsig, dtype=th.float32, device=dev), start=th.empty_like(bufs["x"]),
                       cond=None if cond is None else th.empty(cond.shape, dtype=th.float32, device=dev),
                       cs=None if cond_sample is None else th.empty(cond_sample.shape, dtype=th.float32, device=dev))
@@ -440,17 +440,22 @@ class LightningEDM(LightningModule):
             run.release()
             th.cuda.synchronize(dev)
             graph = th.cuda.CUDAGraph()
-            with th.cuda.graph(graph):
+            # thread-local capture: other threads of the process (a DataLoader's pin-memory thread, RCCL's watchdog) may allocate
+            # or record events meanwhile without invalidating it
+            with th.cuda.graph(graph, capture_error_mode="thread_local"):
                 run = self._heun_lane(st["start"], st["sig"], st["cs"], st["cond"], False)
                 for _ in run:
                     pass
                 st["out"] = run.result
                 run.release()
             st["graph"] = graph
-            bufs["loop_graph"] = g = st
+            while len(cache) >= 4:   # (each graph owns a private pool: keep a handful, drop the oldest)
+                cache.pop(next(iter(cache)))
+            cache[key] = g = st
         # the captured launches read the model's packed weight fragments at fixed addresses: bring them up to date with the parameters
         # (an optimizer step since the last call) BEFORE the replay -- inside a forward this is the first thing eng.forward does
-        eng.repack(th.cuda.current_stream(dev).cuda_stream)
+        stream = th.cuda.current_stream(dev).cuda_stream
+        eng.repack(stream)
         g["sig"].copy_(sigmas)
         g["start"].copy_(eps)
         if cond is not None:
@@ -458,6 +463,7 @@ class LightningEDM(LightningModule):
         if cond_sample is not None:
             g["cs"].copy_(cond_sample)
         g["graph"].replay()
+        eng._mark_use(stream)   # (a repack issued on another stream must wait for this replay's reads of the fragments)
         return g["out"].clone()
 
     def _graph_denoiser(self, bufs, x32, cond, cond_sample=None):
@@ -472,7 +478,7 @@ class LightningEDM(LightningModule):
             self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample, infer=True)  # warm-up outside capture (plan build, packing)
             th.cuda.synchronize(x32.device)
             graph = th.cuda.CUDAGraph()
-            with th.cuda.graph(graph):
+            with th.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample, infer=True)
             g = (graph, slot, out)
             bufs["graph"], bufs["graph_cond"] = g, key
@@ -481,9 +487,11 @@ class LightningEDM(LightningModule):
 
         def run(sig_ptr):
             # (packed weights first: see _graph_sample) device-to-device copy of the 4-byte sigma into the captured slot, then replay
-            eng.repack(th.cuda.current_stream(slot.device).cuda_stream)
-            _lib_memcpy_d2d(slot.data_ptr(), sig_ptr, elem, th.cuda.current_stream(slot.device).cuda_stream)
+            stream = th.cuda.current_stream(slot.device).cuda_stream
+            eng.repack(stream)
+            _lib_memcpy_d2d(slot.data_ptr(), sig_ptr, elem, stream)
             graph.replay()
+            eng._mark_use(stream)
             return out
 
         return run

@@ -112,7 +112,6 @@ def reserve_side_streams(dev, n: int = 3):
         main.wait_stream(s)
 
 
-_ABL_SKIP_EMBED = os.environ.get("TQDNE_ABL_SKIP_EMBED") == "1"
 _PACK_TABLES: dict = {}
 PACK_BATCH = os.environ.get("TQDNE_PACK_BATCH", "1") != "0"   # A/B switch: 0 = one launch per tensor (rounds 1-2 behaviour)
 
@@ -227,14 +226,12 @@ def _recorded_event():
 
 
 def _check_head_limits(C_in: int, C_out: int, k: int):
-    """The limits of tq_head_conv_fwd (csrc/small_ops.hip), checked when the plan is built so that an unsupported model fails
-    at construction with a message rather than at its first forward with TQ_ERR_SHAPE."""
-    maxco = 4 if C_out <= 4 else 16
-    lds = 4 * (C_in * k * maxco + (128 + k - 1) * k * maxco)
-    if C_in < 16 or C_in % 16 or C_in > 128 or not (1 <= C_out <= 16) or k not in (1, 3, 5) or lds > 64 * 1024:
+    """The limits of tq_head_conv_fwd, asked of the library itself (tq_head_conv_lds_bytes: 0 = not built for the shape) when the
+    plan is built, so that an unsupported model fails at construction with a message rather than at its first forward."""
+    if _lib.load().tq_head_conv_lds_bytes(C_in, C_out, k) == 0:
         raise NotImplementedError(
             f"output conv {C_in} -> {C_out} channels, k = {k}: the HIP head kernel takes 16 | C_in <= 128, C_out <= 16, k in (1, 3, 5) "
-            f"and <= 64 KB of LDS (this shape: {lds} bytes)")
+            "and <= 64 KB of LDS")
 
 
 def shared_range_flag(model, device) -> torch.Tensor:
@@ -844,20 +841,17 @@ class UNetEngine:
         ev = (lambda: _recorded_event()) if trace is not None else None
         e0 = ev() if ev else None
         tm, cm = m.time_mlp, (m.cond_mlp if m.cond_features is not None else None)
-        # (TQDNE_ABL_SKIP_EMBED=1: measurement switch -- what do the two embedding launches cost the sampler?  wrong results)
-        if not (_ABL_SKIP_EMBED and infer and getattr(self, "_fwd_count_abl", 0) > 2):
-          check(lib.tq_embed_fwd(
+        check(lib.tq_embed_fwd(
             _p(timesteps), _p(cond), _p(m.time_embed.W), _p(tm[0].weight), _p(tm[0].bias), _p(tm[2].weight), _p(tm[2].bias),
             _p(cm[0].weight) if cm else None, _p(cm[0].bias) if cm else None, _p(cm[2].weight) if cm else None,
             _p(cm[2].bias) if cm else None, _p(self.emb), _p(self.silu_emb), _p(self.emb_hidden), B, m.model_channels,
             ncond, stream), "embed")
-          if self.emb_desc is not None:
+        if self.emb_desc is not None:
             check(lib.tq_conv1d_fwd(C.byref(self.emb_desc), _p(self.silu_emb), None, None, None, _p(self.emb_packed), _p(self.emb_b),
                                     None, None, _p(self.emb_all), None, stream), "emb projections")
-          else:
+        else:
             check(lib.tq_linear_fwd(_p(self.silu_emb), _p(self.emb_w), _p(self.emb_b), _p(self.emb_all), B, self.E,
                                     self.emb_total, stream), "emb projections")
-        self._fwd_count_abl = getattr(self, "_fwd_count_abl", 0) + 1
         if ev:
             e1 = ev()
             trace.append(("embed", 2 * B * self.E * (self.emb_total + 2 * self.E), 4 * (self.emb_total * self.E + B * self.emb_total), e0, e1))

@@ -379,7 +379,8 @@ class BackwardPlan:
         # second-generation kernels (D = 32 / 64) take a scratch buffer for the bf16 planes of Q, K, V, dO: one per shape, shared by
         # the blocks of the sweep (2 * tq_attention_workspace_bytes = 16 H Tp D bytes per sample)
         Tp = (T + 63) // 64 * 64
-        ws = self.scratch("attn_bwd_ws", 4 * ab.num_heads * Tp * t["D"])
+        # (D = 128 falls through to the first-generation kernels, which never touch it: no buffer, NULL)
+        ws = self.scratch("attn_bwd_ws", 4 * ab.num_heads * Tp * t["D"]) if t["D"] in (32, 64) else None
         self.ops.append([self.lib.tq_attention_bwd_ws, [_p(qkv.buf), _p(att.buf), _p(datt), _p(t["lse"]), _p(delta), _p(dqkv), _p(ws),
                                                         B, T, ab.num_heads, t["D"]], "attention bwd"])
         self._wgrad(t["rec_qkv"], dqkv)

@@ -132,7 +132,9 @@ def attention_bwd(qkv, out, dout, lse, heads, workspace=True):
     D = C3 // (3 * heads)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, heads, T, device=qkv.device)
-    ws = torch.empty(2 * lib.tq_attention_workspace_bytes(B, T, heads, D), dtype=torch.uint8, device=qkv.device) if workspace else None
+    # (the second-generation kernels exist for D = 32 / 64; D = 128 falls through to the first generation, which takes no scratch)
+    ws = (torch.empty(2 * lib.tq_attention_workspace_bytes(B, T, heads, D), dtype=torch.uint8, device=qkv.device)
+          if (workspace and D in (32, 64)) else None)
     check(lib.tq_attention_bwd_ws(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(ws), B, T, heads, D,
                                   _stream(qkv.device)), "attention bwd")
     return dqkv

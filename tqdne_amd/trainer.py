@@ -136,31 +136,55 @@ class DataParallelTrainer:
         self.scheduler.step()
         return loss
 
+    AGREE_EVERY = 64   # steps between the (host-synchronous) checks whether every rank has left the fp16-range scheme
+
+    def _local_range_flag(self):
+        """(device int32[1] range-guard flag of this rank's model | None, is this rank still on the fp16-range scheme?)"""
+        unet = getattr(self.module, "unet", None)
+        if not self.fused or unet is None or getattr(unet, "dims", 1) != 1:
+            return None, False
+        dev = next(self.module.parameters()).device
+        from .engine import shared_range_flag
+        return shared_range_flag(unet, dev), getattr(unet, "_conv_scheme", "auto") == "auto"
+
     def _range_skip_flag(self):
         """Device predicate of the optimizer launch (fused optimizer only): the range-guard flag of the fp16-range forward scheme.
         The host learns of a raised flag one or more steps late (engine._range_poll does not synchronise), so the step whose
         forward raised it -- activations within a factor two of the fp16 range, possibly inf / NaN gradients -- is dropped ON
         THE DEVICE, and so is every later step until the host has moved the plans to bf16x3.  With several ranks the flag is
-        max-reduced first (a rank that skipped alone would leave the replicas different); a rank already on bf16x3 contributes 0
-        (its kernels still raise the flag for large activations, which that scheme handles)."""
-        unet = getattr(self.module, "unet", None)
-        if not self.fused or unet is None or getattr(unet, "dims", 1) != 1:
+        summed over the ranks first (a rank that skipped alone would leave the replicas different); a rank already on bf16x3
+        contributes 0 (its kernels still raise the flag for large activations, which that scheme handles).
+
+        Bookkeeping of a dropped step: only the device-side update is skipped.  The host-side counters move on -- Adam's step count
+        (bias corrections), the cosine schedule, the parameters' version counters (one redundant re-pack) -- exactly as if the step had
+        produced a zero update; at most a handful of steps per run are affected (the host switches the plans to bf16x3 within a
+        step or two of the flag).
+
+        The exchange ends by agreement: the second word of the exchanged pair counts the ranks that are off the fp16-range scheme;
+        every ``AGREE_EVERY`` steps all ranks read it (the same step on every rank, so they stop together) and, once it equals the
+        world size, no rank issues the collective any more."""
+        flag, auto = self._local_range_flag()
+        if flag is None:
             return None
-        dev = next(self.module.parameters()).device
-        from .engine import shared_range_flag
-        flag = shared_range_flag(unet, dev)
-        auto = getattr(unet, "_conv_scheme", "auto") == "auto"
         if self.world == 1:
             return flag if auto else None
-        # (summed as a float through the same exchange path as the gradients; the kernel tests the word for "non-zero", and a sum of
+        if getattr(self, "_skip_done", False):
+            return None
+        # (summed as floats through the same exchange path as the gradients; the kernel tests word 0 for "non-zero", and a sum of
         # 0 / 1 flags has a non-zero bit pattern exactly when some rank raised its flag)
         if getattr(self, "_skip", None) is None:
-            self._skip = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._skip = torch.zeros(2, dtype=torch.float32, device=flag.device)
+            self._skip_steps = 0
         if auto:
-            self._skip.copy_(flag)
+            self._skip[0:1].copy_(flag)
+            self._skip[1:2].zero_()
         else:
-            self._skip.zero_()
+            self._skip[0:1].zero_()
+            self._skip[1:2].fill_(1.0)
         self._allreduce_async(self._skip).wait()
+        self._skip_steps += 1
+        if self._skip_steps % self.AGREE_EVERY == 0 and float(self._skip[1].item()) >= self.world:
+            self._skip_done = True
         return self._skip
 
     def ema_state(self):
