@@ -115,6 +115,15 @@ typedef struct TqConvBwdDesc {
     uint32_t dropout_site;
     float dropout_p;
     uint64_t dropout_seed;
+    /* ABI 5.  Contraction scheme of the data gradient: TQ_WFMT_BF16X3 (0: fp32 range, packed_w_t from pack mode 1) or
+     * TQ_WFMT_F16_MX6 (packed_w_t from pack mode 5; 64 | C_dy and 128 | C_dx0 + C_dx1): dy is staged times the exact power of two
+     * that brings max|dy| into [2^13, 2^14) -- gradients are far below fp16's normal range otherwise -- and the accumulators are
+     * multiplied by its inverse, so the result has the accuracy of the forward scheme (~2^-15 relative) at half the MFMA cycles of
+     * bf16x3.  dy_amax: DEVICE pointer to the IEEE bit pattern of max|dy| over the whole tensor (any upper bound within a factor 8 will do), e.g.
+     * written by tq_colsum(..., amax_out) on the same dy; required for TQ_WFMT_F16_MX6. */
+    int32_t wfmt;
+    int32_t reserved;
+    const uint32_t* dy_amax;
 } TqConvBwdDesc;
 
 int tq_abi_version(void);
@@ -127,7 +136,8 @@ int tq_build_flags(void);
 /* ---- weights -------------------------------------------------------------------------------------------- */
 /* Pack a torch Conv1d weight (C_out, C_in, K) fp32 into per-lane MFMA fragments.
  * mode 0: forward operand, TQ_WFMT_BF16X3; mode 1: data-gradient operand (transposed + tap-flipped), TQ_WFMT_BF16X3;
- * mode 2: forward operand, TQ_WFMT_F16_MX8; mode 3: forward operand, TQ_WFMT_F16_MX6. */
+ * mode 2: forward operand, TQ_WFMT_F16_MX8; mode 3: forward operand, TQ_WFMT_F16_MX6; mode 5 (ABI 5): data-gradient operand,
+ * TQ_WFMT_F16_MX6.  (mode 4 is a plain copy job of tq_pack_jobs.) */
 size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode);
 int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* packed, hipStream_t stream);
 int tq_conv_tile_co(int C_out);
@@ -216,6 +226,13 @@ int tq_gn_bwd_finalize(const float* gstats_partial, const float* mean_rstd, cons
 int tq_gn_bwd_apply(const float* g, const float* x, const float* r, const float* coef_a, const float* coef_b,
                     const float* coef_c, float* dx, int B, int T, int C_src, int C_total, int c_offset, int accumulate,
                     hipStream_t stream);
+/* step 2 with the column sums of the tensor it writes fused in (ABI 5): what tq_colsum(dx, ...) would add to colsum_bc / colsum_c /
+ * colsum_c2 / amax_out afterwards, from the values while they are in registers (`dx` must then be COMPLETE after this launch: the
+ * last writer of an accumulated gradient).  All four outputs NULL = tq_gn_bwd_apply. */
+int tq_gn_bwd_apply_colsum(const float* g, const float* x, const float* r, const float* coef_a, const float* coef_b,
+                           const float* coef_c, float* dx, int B, int T, int C_src, int C_total, int c_offset, int accumulate,
+                           float* colsum_bc, int bc_stride, float* colsum_c, float* colsum_c2, uint32_t* amax_out,
+                           hipStream_t stream);
 /* out_bc[b*bc_stride + c] += bscale[b] * sum_t dy[b,t,c];  out_c[c], out_c2[c] += sum_{b,t} (...)  (each optional; bias and
  * embedding gradients: two biases fed by the same tensor are served by one pass) */
 /* Small fp32 GEMMs of the embedding-MLP backward (unet.py:91-97,210-227,383-388; the autograd of blocks.py:15-26): one launch runs
@@ -237,8 +254,10 @@ int tq_gemm_f32_jobs(const TqGemmJob* jobs_device, int njobs, int total_tiles, h
 /* GaussianFourierProjection features (blocks.py:15-26): out (B, 2 half) = [sin(2 pi t W) | cos(2 pi t W)] */
 int tq_fourier_features(const float* t, const float* W, float* out, int B, int half, hipStream_t stream);
 
+/* amax_out (ABI 5, nullable): *amax_out = max(*amax_out, bit pattern of max|dy|) by atomic max -- zero it first; non-negative floats
+ * order like their bit patterns, NaN sorts above everything: a poisoned tensor stays visible.  Feeds TqConvBwdDesc.dy_amax. */
 int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, float* out_c2,
-              const float* bscale, hipStream_t stream);
+              const float* bscale, uint32_t* amax_out, hipStream_t stream);
 /* gradient plumbing of the strided / upsampled convs: out[b,u,:] = (u even) ? dy[b,u/2,:] : 0 for u < T_in;
  * dx[b,t,:] (+)= d_up[b,2t,:] + d_up[b,2t+1,:] */
 int tq_zero_stuff(const float* dy, float* out, int B, int T_out, int T_in, int C, hipStream_t stream);

@@ -254,3 +254,91 @@ def test_attention_backward(H, D, T):
         got = ncw(ops.attention_bwd(x, out, cl(dout), lse, H, workspace=ws))
         for name, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, 2 * H * D)), ("dv", slice(2 * H * D, 3 * H * D))):
             assert rel_err(got[:, sl], qkv.grad[:, sl]) < TOL, (name, ws)
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 4
+@pytest.mark.parametrize("cin,cout,k,T,scale", [(128, 256, 5, 200, 1e-6), (256, 256, 5, 333, 3e-5), (256, 128, 3, 127, 1.0),
+                                                (512, 256, 1, 100, 1e-9), (384, 256, 5, 130, 2e3), (128, 768, 1, 256, 1e-6)])
+def test_dgrad_f16_mx6_on_gradient_scale_inputs(cin, cout, k, T, scale):
+    """the fp16 + MX-fp6 data gradient: dy at the magnitudes gradients have (1e-9 ... 1e3, far outside fp16's normal range unscaled),
+    heavy-tailed, scaled inside the kernel by the power of two that tq_colsum's amax output selects -- vs fp64"""
+    from tqdne_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin + cout + k + T)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    dy = torch.randn(2, cout, T, generator=g)
+    dy = torch.where(torch.rand(dy.shape, generator=g) < 0.02, dy * 30.0, dy) * scale     # heavy tails
+    ref = F.conv_transpose1d(dy.double(), w.double(), padding=k // 2)
+    g0, _, _ = ops.conv1d_bwd_data(cl(dy), w.to(dev()), wfmt=_lib.TQ_WFMT_F16_MX6)
+    e = rel_err(ncw(g0), ref)
+    gb, _, _ = ops.conv1d_bwd_data(cl(dy), w.to(dev()))
+    eb = rel_err(ncw(gb), ref)
+    print(f"dgrad {cin}->{cout} k{k} at |dy| ~ {scale:g}: f16+mx6 {e:.2e}, bf16x3 {eb:.2e}")
+    assert e < TOL
+
+
+def test_dgrad_f16_mx6_chain_concat_stats_and_accumulate():
+    from tqdne_amd import _lib, ops
+    g = torch.Generator().manual_seed(21)
+    B, C0, C1, Co, T = 2, 256, 128, 128, 333
+    x0, x1 = torch.randn(B, C0, T, generator=g), torch.randn(B, C1, T, generator=g) + 0.5
+    a, s = torch.randn(B, C0 + C1, generator=g), torch.randn(B, C0 + C1, generator=g)
+    w = torch.randn(Co, C0 + C1, 5, generator=g) / 30
+    dy = torch.randn(B, Co, T, generator=g) * 1e-5
+    x = torch.cat([x0, x1], 1)
+    u = (x * a[:, :, None] + s[:, :, None]).double().requires_grad_(True)
+    F.conv1d(F.silu(u), w.double(), None, padding=2).backward(dy.double())
+    d = dev()
+    g0, g1, st = ops.conv1d_bwd_data(cl(dy), w.to(d), x0=cl(x0), x1=cl(x1), gscale=a.to(d), gshift=s.to(d), silu=True,
+                                     stats=True, split=C0, wfmt=_lib.TQ_WFMT_F16_MX6)
+    got = torch.cat([ncw(g0), ncw(g1)], 1)
+    assert rel_err(got, u.grad) < TOL
+    assert rel_err(st.cpu(), ref_slot_sums(u.grad.float(), x)) < TOL
+    base0, base1 = torch.full_like(g0, 1e-5), torch.full_like(g1, 1e-5)
+    ops.conv1d_bwd_data(cl(dy), w.to(d), x0=cl(x0), x1=cl(x1), gscale=a.to(d), gshift=s.to(d), silu=True, split=C0,
+                        accumulate_into=(base0, base1), wfmt=_lib.TQ_WFMT_F16_MX6)
+    assert rel_err(torch.cat([ncw(base0), ncw(base1)], 1), u.grad + 1e-5) < TOL
+
+
+def test_dgrad_f16_mx6_refuses_unsupported_shapes_and_missing_amax():
+    import ctypes as C
+    from tqdne_amd import _lib, ops
+    lib = _lib.load()
+    d = _lib.TqConvBwdDesc()
+    d.B, d.T, d.C_dy, d.C_dx0, d.C_dx1, d.ktaps, d.wfmt = 1, 64, 64, 128, 0, 5, _lib.TQ_WFMT_F16_MX6
+    x = torch.zeros(64 * 128, device=dev())
+    assert lib.tq_conv1d_bwd_data(C.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), None, None, None) == -1  # no amax
+    am = torch.zeros(1, dtype=torch.int32, device=dev())
+    d.dy_amax = am.data_ptr()
+    d.C_dx0 = 64      # 128 does not divide the produced channels
+    assert lib.tq_conv1d_bwd_data(C.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), None, None, None) == -2
+    d.C_dx0, d.C_dy = 128, 32
+    assert lib.tq_conv1d_bwd_data(C.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), None, None, None) == -2
+
+
+@pytest.mark.parametrize("C,T,B", [(64, 4096, 2), (256, 300, 3), (192, 130, 2), (512, 64, 2)])
+def test_gn_bwd_apply_with_fused_column_sums_and_amax(C, T, B):
+    """tq_gn_bwd_apply_colsum = tq_gn_bwd_apply followed by tq_colsum of its output (bit-identical dx; sums to rounding; exact max)"""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(C + T)
+    d = dev()
+    G, x, r = (torch.randn(B, T, C, generator=g).to(d) for _ in range(3))
+    coefs = tuple(torch.randn(B, C, generator=g).to(d) for _ in range(3))
+    ref = ops.gn_bwd_apply(G, x, coefs, C, r=r)
+    am = torch.zeros(1, dtype=torch.int32, device=d)
+    dx, obc, oc = ops.gn_bwd_apply_colsum(G, x, coefs, C, r=r, amax=am)
+    assert torch.equal(dx, ref)
+    assert rel_err(obc.cpu(), ref.double().sum(1).cpu()) < 1e-5 and rel_err(oc.cpu(), ref.double().sum((0, 1)).cpu()) < 1e-5
+    assert am.view(torch.float32).item() == float(ref.abs().max())
+    # accumulate form on a source of a concat (coefficient offset), no residual
+    C2 = C // 2
+    G2, x2 = G[:, :, :C2].contiguous(), x[:, :, :C2].contiguous()
+    base = torch.randn(B, T, C2, generator=g).to(d)
+    ref2 = ops.gn_bwd_apply(G2, x2, coefs, C, c_offset=C - C2, accumulate_into=base.clone())
+    dx2, obc2, _ = ops.gn_bwd_apply_colsum(G2, x2, coefs, C, c_offset=C - C2, accumulate_into=base.clone(), total=False)
+    assert torch.equal(dx2, ref2) and rel_err(obc2.cpu(), ref2.double().sum(1).cpu()) < 1e-5
+    # the stand-alone pass reports the same maximum; a NaN anywhere is carried as +inf
+    am2 = torch.zeros(1, dtype=torch.int32, device=d)
+    ops.colsum(ref, amax=am2)
+    assert am2.item() == am.item()
+    bad = ref.clone(); bad[B - 1, T // 2, C - 3] = float("nan")
+    assert math.isinf(ops.amax_bits(bad).view(torch.float32).item())

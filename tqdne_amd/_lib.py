@@ -20,6 +20,7 @@ TQ_CONV_GN, TQ_CONV_SILU, TQ_CONV_EMB, TQ_CONV_RES, TQ_CONV_STATS, TQ_CONV_DROPO
 TQ_CONV_POLY2 = 64
 TQ_WFMT_BF16X3, TQ_WFMT_F16_MX8, TQ_WFMT_F16_MX6 = 0, 1, 2
 PACK_MODE = {TQ_WFMT_BF16X3: 0, TQ_WFMT_F16_MX8: 2, TQ_WFMT_F16_MX6: 3}   # tq_pack_conv_weight mode of a forward weight format
+PACK_MODE_T = {TQ_WFMT_BF16X3: 1, TQ_WFMT_F16_MX6: 5}                      # ... of a data-gradient (transposed) weight format
 
 
 DEFAULT_SCHEME = "f16mx6"
@@ -86,7 +87,7 @@ class TqConvBwdDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T", C.c_int32), ("C_dy", C.c_int32), ("C_dx0", C.c_int32), ("C_dx1", C.c_int32),
         ("ktaps", C.c_int32), ("flags", C.c_int32), ("dropout_site", C.c_uint32), ("dropout_p", C.c_float),
-        ("dropout_seed", C.c_uint64),
+        ("dropout_seed", C.c_uint64), ("wfmt", C.c_int32), ("reserved", C.c_int32), ("dy_amax", C.c_void_p),
     ]
 
 
@@ -136,12 +137,13 @@ _PROTOS = {
     "tq_conv1d_bwd_weight_colsum": (I, [VP] * 8 + [SZ, VP, I, VP, VP, VP]),
     "tq_gn_bwd_finalize": (I, [VP, VP, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
     "tq_gn_bwd_apply": (I, [VP] * 7 + [I] * 6 + [VP]),
+    "tq_gn_bwd_apply_colsum": (I, [VP] * 7 + [I] * 6 + [VP, I, VP, VP, VP, VP]),
     "tq_pack_job_blocks": (I, [I, I, I, I]),
     "tq_pack_jobs": (I, [VP, I, I, VP]),
     "tq_gemm_tiles": (I, [I, I]),
     "tq_gemm_f32_jobs": (I, [VP, I, I, VP]),
     "tq_fourier_features": (I, [VP, VP, VP, I, I, VP]),
-    "tq_colsum": (I, [VP, I, I, I, VP, I, VP, VP, VP, VP]),
+    "tq_colsum": (I, [VP, I, I, I, VP, I, VP, VP, VP, VP, VP]),
     "tq_zero_stuff": (I, [VP, VP, I, I, I, I, VP]),
     "tq_pair_sum": (I, [VP, VP, I, I, I, I, VP]),
     "tq_stem_conv_bwd_weight": (I, [VP] * 4 + [I] * 5 + [VP]),

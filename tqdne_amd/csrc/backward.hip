@@ -322,15 +322,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
                 }
 }
 
-// dw[i*KT + k] = sum_s slab[s][k][i].  One workgroup (64 x 4 threads) owns 256 consecutive i for ALL taps: thread (x, y) sums the
-// splits s = y, y + 4, ... of the four elements 4x .. 4x + 3 of every tap with 16-byte loads, 2 KT of them in flight; the four
-// partitions meet in LDS and the 256 KT results leave as one contiguous run of dw.  (Rounds 1-3: one 4-byte element per thread and
-// tap, two loads in flight, 4-byte stores KT floats apart -- 27 us per launch on average, 76 launches per training step.)
+// dw[i*KT + k] = sum_s slab[s][k][i].  One workgroup (16 x 16 threads) owns 64 consecutive i for ALL taps: thread (x, y) sums the
+// splits s = y, y + 16, ... of the four elements 4x .. 4x + 3 of every tap with 16-byte loads -- for the usual <= 32 splits that is ONE
+// round of <= 2 KT independent loads per thread, n / 64 workgroups (>= 1024 for the 256-channel layers) -- the sixteen partitions
+// meet in LDS and the 64 KT results leave as one contiguous run of dw.  (Rounds 1-3: one 4-byte element per thread and tap, two
+// loads in flight, 4-byte stores KT floats apart.  A first round-4 form with 256 i per workgroup had n / 256 workgroups of four
+// latency-bound waves and measured slower than that.)
 template <int KT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, size_t n) {
-    __shared__ __attribute__((aligned(16))) float red[4][KT][260];   // (260: 16-byte rows whose taps sit 4 banks apart)
+    __shared__ __attribute__((aligned(16))) float red[16][KT][68];   // (68: 16-byte rows whose taps sit 4 banks apart)
     const int x = threadIdx.x, y = threadIdx.y;
-    const size_t i0 = (size_t)blockIdx.x * 256;
+    const size_t i0 = (size_t)blockIdx.x * 64;
     const size_t i = i0 + 4 * x;
     float4 acc[KT];
 #pragma unroll
@@ -338,12 +340,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (i < n) {
         const float* base = slab + i;
         int sidx = y;
-        for (; sidx + 4 < nsplit; sidx += 8) {
+        for (; sidx + 16 < nsplit; sidx += 32) {
             float4 v0[KT], v1[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 v0[k] = *reinterpret_cast<const float4*>(base + ((size_t)sidx * KT + k) * n);
-                v1[k] = *reinterpret_cast<const float4*>(base + ((size_t)(sidx + 4) * KT + k) * n);
+                v1[k] = *reinterpret_cast<const float4*>(base + ((size_t)(sidx + 16) * KT + k) * n);
             }
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
@@ -362,11 +364,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < KT; ++k) *reinterpret_cast<float4*>(&red[y][k][4 * x]) = acc[k];
     __syncthreads();
-    const int tid = y * 64 + x;
-    const size_t nleft = n - i0 < 256 ? n - i0 : 256;   // (n is a multiple of 4, not necessarily of 256)
+    const int tid = y * 16 + x;
+    const size_t nleft = n - i0 < 64 ? n - i0 : 64;   // (n is a multiple of 4, not necessarily of 64)
     for (int o = tid; o < (int)nleft * KT; o += 256) {
         const int il = o / KT, k = o - il * KT;
-        dw[i0 * KT + o] = (red[0][k][il] + red[1][k][il]) + (red[2][k][il] + red[3][k][il]);
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][k][il];
+        dw[i0 * KT + o] = t;
     }
 }
 
@@ -497,7 +502,7 @@ extern "C" int tq_conv1d_bwd_weight_colsum(const TqConvDesc* d, const float* dy,
     }
     if (rc) return rc;
     const size_t n = (size_t)d->C_out * (d->C_in0 + d->C_in1);
-    const dim3 rgrid((unsigned)((n + 255) / 256)), rblock(64, 4);
+    const dim3 rgrid((unsigned)((n + 63) / 64)), rblock(16, 16);
     if (d->ktaps == 5) hipLaunchKernelGGL(wgrad_reduce_kernel<5>, rgrid, rblock, 0, stream, a.slab, dw, a.nsplit, n);
     else if (d->ktaps == 3) hipLaunchKernelGGL(wgrad_reduce_kernel<3>, rgrid, rblock, 0, stream, a.slab, dw, a.nsplit, n);
     else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, rgrid, rblock, 0, stream, a.slab, dw, a.nsplit, n);
@@ -613,10 +618,40 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     }
 }
 
+// Epilogue shared by colsum_kernel and gn_bwd_apply_cs_kernel: the workgroup's per-thread partial column sums `a` (float4 column c4,
+// row lane tr) and partial max|v| `mx` -> out_bc[b*stride + c] / out_c[c] / out_c2[c] (atomic adds into zeroed buffers) and
+// *amax_out (atomic max of bit patterns: non-negative floats order like their bits; NaN sorts above everything).
+__device__ __forceinline__ void colsum_finish(float* red, const float4& a, float mx, bool active, int c4n, int nrow, int c4, int tr, int C,
+                                              int b, float sc, float* __restrict__ out_bc, int bc_stride, float* __restrict__ out_c,
+                                              float* __restrict__ out_c2, unsigned* __restrict__ amax_out) {
+    if (active) *reinterpret_cast<float4*>(red + (tr * c4n + c4) * 4) = a;
+    if (amax_out) {
+        unsigned m = __float_as_uint(mx);   // (mx >= 0 or NaN)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(amax_out, m);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int r2 = 0; r2 < nrow; ++r2) s += red[(r2 * c4n + (c >> 2)) * 4 + (c & 3)];
+        s *= sc;
+        if (out_bc) atomicAdd(out_bc + (size_t)b * bc_stride + c, s);
+        if (out_c) atomicAdd(out_c + c, s);
+        if (out_c2) atomicAdd(out_c2 + c, s);
+    }
+}
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+    // (fmaxf drops NaN operands; a NaN gradient must stay visible in the scale: carried as +inf, which scales the tensor to ~0 / NaN)
+    const float t = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const bool bad = (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+    return bad ? __builtin_inff() : fmaxf(m, t);
+}
+
 // out_bc[b*stride + c] += sum_t dy[b,t,c];  out_c[c] += sum_{b,t} dy   (both optional; atomics into zeroed buffers)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int T, int C, float* __restrict__ out_bc,
                                                      int bc_stride, float* __restrict__ out_c, float* __restrict__ out_c2,
-                                                     const float* __restrict__ bscale, int rpw) {
+                                                     const float* __restrict__ bscale, unsigned* __restrict__ amax_out, int rpw) {
     // rpw: rows (positions) per workgroup
     extern __shared__ float red[];
     const int nsl = (T + rpw - 1) / rpw;
@@ -625,7 +660,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
     const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
     const int c4 = threadIdx.x % c4n, tr = threadIdx.x / c4n;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tr < nrow && threadIdx.x < nrow * c4n) {
+    float mx = 0.f;
+    const bool active = tr < nrow && threadIdx.x < nrow * c4n;
+    if (active) {
         const int nvalid = min(rpw, T - slot * rpw);
         const float* src = dy + ((size_t)b * T + (size_t)slot * rpw) * C + 4 * c4;
         int tl = tr;
@@ -636,23 +673,83 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
             for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(src + (size_t)(tl + q * nrow) * C);
 #pragma unroll
             for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+            if (amax_out) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mx = amax4(mx, v[q]);
+            }
         }
         for (; tl < nvalid; tl += nrow) {
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)tl * C);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            if (amax_out) mx = amax4(mx, v);
         }
-        *reinterpret_cast<float4*>(red + (tr * c4n + c4) * 4) = a;
     }
-    __syncthreads();
-    const float sc = bscale ? bscale[b] : 1.0f;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int r2 = 0; r2 < nrow; ++r2) s += red[(r2 * c4n + (c >> 2)) * 4 + (c & 3)];
-        s *= sc;
-        if (out_bc) atomicAdd(out_bc + (size_t)b * bc_stride + c, s);
-        if (out_c) atomicAdd(out_c + c, s);
-        if (out_c2) atomicAdd(out_c2 + c, s);
+    colsum_finish(red, a, mx, active, c4n, nrow, c4, tr, C, b, bscale ? bscale[b] : 1.0f, out_bc, bc_stride, out_c, out_c2, amax_out);
+}
+
+// gn_bwd_apply with the column sums (and max|.|) of the tensor it writes fused in: the consumers of dx -- the bias / time-embedding
+// gradients of the conv whose output gradient dx is, and the power-of-two scale of that conv's fp16-range data gradient -- otherwise
+// need a pass of their own over dx (63 tq_colsum launches per training step, 1.3 ms at B = 64).  Same tiling as colsum_kernel: a
+// workgroup owns `rpw` rows of one sample, thread = (float4 column, row lane).
+__global__ __launch_bounds__(256) void gn_bwd_apply_cs_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              const float* __restrict__ r, const float* __restrict__ cA,
+                                                              const float* __restrict__ cB, const float* __restrict__ cC,
+                                                              float* __restrict__ dx, int T, int Cs, int Ctot, int coff, int accum,
+                                                              float* __restrict__ out_bc, int bc_stride, float* __restrict__ out_c,
+                                                              float* __restrict__ out_c2, unsigned* __restrict__ amax_out, int rpw) {
+    extern __shared__ float red[];
+    const int nsl = (T + rpw - 1) / rpw;
+    const int slot = blockIdx.x % nsl, b = blockIdx.x / nsl;
+    const int c4n = Cs >> 2;
+    const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
+    const int c4 = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mx = 0.f;
+    const bool active = tr < nrow && threadIdx.x < nrow * c4n;
+    if (active) {
+        const int nvalid = min(rpw, T - slot * rpw);
+        const size_t ko = (size_t)b * Ctot + coff + 4 * c4;
+        const float4 ka = *reinterpret_cast<const float4*>(cA + ko);
+        const float4 kb = *reinterpret_cast<const float4*>(cB + ko);
+        const float4 kc = *reinterpret_cast<const float4*>(cC + ko);
+        const size_t base = ((size_t)b * T + (size_t)slot * rpw) * Cs + 4 * c4;
+        auto one = [&](const float4& gv, const float4& xv, const float4& rv, const float4& ov) -> float4 __attribute__((always_inline)) {
+            float4 o = make_float4(ka.x * gv.x + kb.x * xv.x + kc.x, ka.y * gv.y + kb.y * xv.y + kc.y,
+                                   ka.z * gv.z + kb.z * xv.z + kc.z, ka.w * gv.w + kb.w * xv.w + kc.w);
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+            o.x += ov.x; o.y += ov.y; o.z += ov.z; o.w += ov.w;
+            return o;
+        };
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int tl = tr;
+        for (; tl + 3 * nrow < nvalid; tl += 4 * nrow) {   // 4 rows = 8-16 loads in flight per thread
+            float4 gv[4], xv[4], rv[4], ov[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t o = base + (size_t)(tl + q * nrow) * Cs;
+                gv[q] = *reinterpret_cast<const float4*>(g + o);
+                xv[q] = *reinterpret_cast<const float4*>(x + o);
+                rv[q] = r ? *reinterpret_cast<const float4*>(r + o) : z4;
+                ov[q] = accum ? *reinterpret_cast<const float4*>(dx + o) : z4;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 o4 = one(gv[q], xv[q], rv[q], ov[q]);
+                *reinterpret_cast<float4*>(dx + base + (size_t)(tl + q * nrow) * Cs) = o4;
+                a.x += o4.x; a.y += o4.y; a.z += o4.z; a.w += o4.w;
+                mx = amax4(mx, o4);
+            }
+        }
+        for (; tl < nvalid; tl += nrow) {
+            const size_t o = base + (size_t)tl * Cs;
+            const float4 o4 = one(*reinterpret_cast<const float4*>(g + o), *reinterpret_cast<const float4*>(x + o),
+                                  r ? *reinterpret_cast<const float4*>(r + o) : z4, accum ? *reinterpret_cast<const float4*>(dx + o) : z4);
+            *reinterpret_cast<float4*>(dx + o) = o4;
+            a.x += o4.x; a.y += o4.y; a.z += o4.z; a.w += o4.w;
+            mx = amax4(mx, o4);
+        }
     }
+    colsum_finish(red, a, mx, active, c4n, nrow, c4, tr, Cs, b, 1.0f, out_bc, bc_stride, out_c, out_c2, amax_out);
 }
 
 __global__ void zero_stuff_kernel(const float* __restrict__ dy, float* __restrict__ out, int T_out, int T_in, int C, size_t n4) {
@@ -719,21 +816,46 @@ extern "C" int tq_gn_bwd_apply(const float* g, const float* x, const float* r, c
     return 0;
 }
 
-extern "C" int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, float* out_c2,
-                         const float* bscale, hipStream_t stream) {
-    if (!dy || (!out_bc && !out_c && !out_c2)) return TQ_ERR_ARG;
-    if (B <= 0 || T <= 0 || C < 4 || C % 4 || C > 1024) return TQ_ERR_SHAPE;
-    // Every workgroup ends in C atomic adds onto the same C addresses (plus its sample's): those, not the loads, bound the
-    // kernel (more, smaller workgroups measured SLOWER).  So: as many rows per workgroup as still leaves >= 512 workgroups.
+// rows per workgroup of the column-sum tilings: every workgroup ends in C atomic adds onto the same C addresses (plus its sample's):
+// those, not the loads, bound the kernel (more, smaller workgroups measured SLOWER).  So: as many rows per workgroup as still
+// leaves >= 512 workgroups.
+static int colsum_rows(int B, int T) {
     static const int forced = [] { const char* e = getenv("TQDNE_COLSUM_ROWS"); return e ? atoi(e) : 0; }();   // (A/B switch)
     int rpw = STAT_SLOT;
     while (rpw < 1024 && (size_t)B * ((T + 2 * rpw - 1) / (2 * rpw)) >= 512) rpw <<= 1;
-    if (forced > 0) rpw = forced;
+    return forced > 0 ? forced : rpw;
+}
+
+extern "C" int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, float* out_c2,
+                         const float* bscale, uint32_t* amax_out, hipStream_t stream) {
+    if (!dy || (!out_bc && !out_c && !out_c2 && !amax_out)) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C < 4 || C % 4 || C > 1024) return TQ_ERR_SHAPE;
+    const int rpw = colsum_rows(B, T);
     const int nsl = (T + rpw - 1) / rpw;
     const int c4n = C / 4;
     const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
     const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float);
-    hipLaunchKernelGGL(colsum_kernel, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, out_c2, bscale, rpw);
+    hipLaunchKernelGGL(colsum_kernel, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, out_c2, bscale, amax_out, rpw);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tq_gn_bwd_apply_colsum(const float* g, const float* x, const float* r, const float* coef_a, const float* coef_b,
+                                      const float* coef_c, float* dx, int B, int T, int C_src, int C_total, int c_offset, int accumulate,
+                                      float* colsum_bc, int bc_stride, float* colsum_c, float* colsum_c2, uint32_t* amax_out,
+                                      hipStream_t stream) {
+    if (!g || !x || !coef_a || !coef_b || !coef_c || !dx) return TQ_ERR_ARG;
+    if (colsum_c2 && !colsum_c) return TQ_ERR_ARG;
+    if (B <= 0 || T <= 0 || C_src <= 0 || C_src % 4 || C_src > 1024 || c_offset % 4 || c_offset + C_src > C_total) return TQ_ERR_SHAPE;
+    if (!colsum_bc && !colsum_c && !amax_out)
+        return tq_gn_bwd_apply(g, x, r, coef_a, coef_b, coef_c, dx, B, T, C_src, C_total, c_offset, accumulate, stream);
+    const int rpw = colsum_rows(B, T);
+    const int nsl = (T + rpw - 1) / rpw;
+    const int c4n = C_src / 4;
+    const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
+    const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float);
+    hipLaunchKernelGGL(gn_bwd_apply_cs_kernel, dim3(B * nsl), dim3(256), sh, stream, g, x, r, coef_a, coef_b, coef_c, dx, T, C_src, C_total,
+                       c_offset, accumulate, colsum_bc, bc_stride, colsum_c, colsum_c2, amax_out, rpw);
     TQ_CHECK_LAUNCH();
     return 0;
 }

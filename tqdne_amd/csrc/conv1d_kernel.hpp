@@ -125,7 +125,8 @@ struct Cfg {
 // the same rows by 3 channel-tile workgroups (qkv).
 template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false, int TBW = 8>
 __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_kernel(const ConvArgs p) {
-    static_assert(SCH == 0 || (EPI != 1 && STRIDE == 1), "the fp16-range scheme serves stride-1 forward launches");
+    static_assert(SCH == 0 || STRIDE == 1, "the fp16-range schemes serve stride-1 launches");
+    static_assert(EPI != 1 || SCH == 0 || (SCH == 2 && ACT == 0 && !FUSE && !PW), "data gradients: bf16x3, or fp16 + MX-fp6 on a dy scaled into the fp16 range");
     static_assert(TBW == 8 || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW), "slim tile: bf16x3 forward, 2 x 2 waves");
     static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH >= 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, fp16-range schemes");
     static_assert(SCH != 2 || WN == 1, "scheme 2 tiles are 128 positions wide");
@@ -163,6 +164,20 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
     const int tt = tile % n_ttiles;
     const int b = tile / n_ttiles;
     const int t0 = tt * C::NT;
+    // Data gradient in the fp16 + MX-fp6 scheme (EPI == 1, SCH == 2): gradients are tiny (1e-6 ... 1e-3 at the bench's loss scale)
+    // and fp16 starts losing bits below 6e-5, so dy is staged times an exact power of two 2^k that puts the tensor's largest
+    // magnitude (p.in_amax: bit pattern of max|dy|, written by the column-sum pass that precedes every data gradient) into
+    // [2^13, 2^14), and the accumulators are multiplied by 2^-k in the epilogue.  Both products are exact (no rounding, |k| <= 126).
+    float dy_scale = 1.f, dy_unscale = 1.f;
+    if constexpr (EPI == 1 && SCH == 2) {
+        if (p.in_amax) {
+            const int e = (int)((*p.in_amax >> 23) & 0xFFu);     // biased exponent of max|dy| (0: zero / denormal, 255: inf / NaN)
+            int k = 140 - e;                                      // 2^13 <= max|dy| * 2^k < 2^14
+            k = k > 126 ? 126 : (k < -126 ? -126 : k);
+            dy_scale = __uint_as_float((unsigned)(127 + k) << 23);
+            dy_unscale = __uint_as_float((unsigned)(127 - k) << 23);
+        }
+    }
     // per-sample key of the dropout hash (scalar unit; only the dropout prologue / the data gradient's dropout chain read it)
     const uint32_t dkey = (ACT == 3 || EPI == 1) ? drop_key(p.drop_seed, p.drop_site, (uint32_t)b) : 0u;
     int co_wave = ct * C::MT + wm * 32;
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
                 u[j] = uu.x; u[j + 1] = uu.y;
             }
         }
-        const float mm = (ACT >= 2 && act) ? 1.f : msk;  // (skip stages and un-activated inputs: the plain mask)
+        const float mm = (ACT >= 2 && act) ? 1.f : msk * dy_scale;  // (skip stages and un-activated inputs: the plain mask; data gradients: x 2^k)
         if (ACT == 3 && act) {
             const int pc = pos < 0 ? 0 : pos;
             const uint32_t e0 = (uint32_t)pc * (uint32_t)Cin + (uint32_t)(chunk * C::CH + 16 * m2);
@@ -1033,6 +1048,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                     const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
                     const size_t o = ((size_t)b * p.T_out + t) * cs[cbk] + cc[cbk];
                     float v[4] = {acc[cbk][tb][0], acc[cbk][tb][1], acc[cbk][tb][2], acc[cbk][tb][3]};
+                    if constexpr (SCH == 2) { v[0] *= dy_unscale; v[1] *= dy_unscale; v[2] *= dy_unscale; v[3] *= dy_unscale; }
                     float xv[4] = {0.f, 0.f, 0.f, 0.f};
                     if (p.bflags & (TQ_BWD_GN | TQ_BWD_SILU | TQ_BWD_STATS)) {
                         const float4 x4 = *reinterpret_cast<const float4*>(fx[cbk] + o);
@@ -1136,6 +1152,12 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     if (a.wfmt == TQ_WFMT_F16_MX6) {  // same shapes as TQ_WFMT_F16_MX8 (below), fp6 block-scaled corrections
+        if constexpr (STRIDE == 1 && UPS == 0 && EPI == 1 && ACT == 0 && !FUSE) {   // data gradient (dy scaled by a power of two)
+            if (a.C0 % 64 || a.C1) return TQ_ERR_SHAPE;
+            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
+            if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 2>(a, s);
+            return TQ_ERR_SHAPE;
+        }
         if constexpr (STRIDE == 1 && EPI != 1) {
             if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
             if constexpr (KT == 1 && UPS == 0 && ACT <= 1) {

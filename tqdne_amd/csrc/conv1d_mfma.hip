@@ -97,6 +97,7 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.wfmt = d->wfmt;
     a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale;
     a.range_flag = d->range_flag;
+    a.in_amax = nullptr;
     a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
     a.gf_gamma = a.gf_beta = nullptr; a.gf_gscale = a.gf_gshift = a.gf_mean_rstd = nullptr;
 #ifndef TQ_BUILD_EXPERIMENTS
@@ -166,7 +167,18 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.drop_scale = 1.0f / (1.0f - pdrop);
     a.fx0 = x0; a.fx1 = x1; a.fgs = gscale; a.fgh = gshift; a.y1 = dx1; a.OC0 = d->C_dx0;
     a.sx0 = a.sx1 = a.sbias = nullptr; a.sC0 = a.sC1 = 0;
-    a.wfmt = TQ_WFMT_BF16X3;  // gradients keep fp32 range
+    // contraction scheme: bf16x3 (fp32 range), or fp16 + MX-fp6 on dy scaled by the power of two that *dy_amax selects (1.5 instead of
+    // 3 MFMA products per multiply-add); the packed weights must be in the matching format (pack mode 1 / 5)
+    a.wfmt = TQ_WFMT_BF16X3;
+    a.in_amax = nullptr;
+    if (d->wfmt == TQ_WFMT_F16_MX6) {
+        if (!d->dy_amax) return TQ_ERR_ARG;
+        if (d->C_dy % 64 || a.C_out % 128) return TQ_ERR_SHAPE;
+        a.wfmt = TQ_WFMT_F16_MX6;
+        a.in_amax = d->dy_amax;
+    } else if (d->wfmt != TQ_WFMT_BF16X3) {
+        return TQ_ERR_ARG;
+    }
     a.kv = nullptr; a.kvH = a.kvD = a.kvTp = 0; a.kvscale = 1.f;
     a.range_flag = nullptr;
     a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
@@ -234,9 +246,13 @@ __global__ void pack_conv_weight_mx_kernel(const float* __restrict__ w, int C_ou
     pack_mx_body(w, C_out, C_in, K, ncob_pad, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// TRANSPOSED (mode 5, data gradient): A[row = ci][k = co] = W[co][ci][K - 1 - tap], i.e. rows run over the forward conv's input
+// channels and the contraction over its output channels
+template <bool TRANSPOSED = false>
 __device__ __forceinline__ void pack_mx6_body(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
                                               uint4* __restrict__ out, size_t gid) {
-    const int nchunks = (C_in + 63) / 64;
+    const int rows = TRANSPOSED ? C_in : C_out, kdim = TRANSPOSED ? C_out : C_in;
+    const int nchunks = (kdim + 63) / 64;
     const size_t total = (size_t)nchunks * K * ncob_pad * 64;
     if (gid >= total) return;
     const int lane = gid & 63;
@@ -246,7 +262,8 @@ __device__ __forceinline__ void pack_mx6_body(const float* __restrict__ w, int C
     const int chunk = r / K;
     const int row = cob * 16 + (lane & 15), kq = lane >> 4;
     auto wv = [&](int ch) -> float {
-        return (row < C_out && ch < C_in) ? w[((size_t)row * C_in + ch) * K + tap] : 0.f;
+        if (!(row < rows && ch < kdim)) return 0.f;
+        return TRANSPOSED ? w[((size_t)ch * C_in + row) * K + (K - 1 - tap)] : w[((size_t)row * C_in + ch) * K + tap];
     };
     f16x8 m0, m1;
 #pragma unroll
@@ -273,8 +290,9 @@ __device__ __forceinline__ void pack_mx6_body(const float* __restrict__ w, int C
 }
 
 __global__ void pack_conv_weight_mx6_kernel(const float* __restrict__ w, int C_out, int C_in, int K, int ncob_pad,
-                                            uint4* __restrict__ out) {
-    pack_mx6_body(w, C_out, C_in, K, ncob_pad, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+                                            uint4* __restrict__ out, int transposed) {
+    if (transposed) pack_mx6_body<true>(w, C_out, C_in, K, ncob_pad, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    else pack_mx6_body<false>(w, C_out, C_in, K, ncob_pad, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 __device__ __forceinline__ void pack_bf16_body(const float* __restrict__ w, int C_out, int C_in, int K, int mode, int rows, int kdim,
@@ -328,27 +346,30 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const TqPackJob* __restr
         if (gid < (size_t)jb.C_out) reinterpret_cast<float*>(jb.dst)[gid] = w[gid];
         return;
     }
-    const int rows = jb.mode != 1 ? jb.C_out : jb.C_in;
-    const int kdim = jb.mode != 1 ? jb.C_in : jb.C_out;
+    const bool tr = jb.mode == 1 || jb.mode == 5;
+    const int rows = tr ? jb.C_in : jb.C_out;
+    const int kdim = tr ? jb.C_out : jb.C_in;
     const int tile = (rows % 128 == 0) ? 128 : ((rows % 64 == 0) ? 64 : 32);   // = tq_conv_tile_co
     const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
     uint4* out = reinterpret_cast<uint4*>(jb.dst);
     if (jb.mode == 2) pack_mx_body(w, jb.C_out, jb.C_in, jb.K, ncob_pad, out, gid);
-    else if (jb.mode == 3) pack_mx6_body(w, jb.C_out, jb.C_in, jb.K, ncob_pad, out, gid);
+    else if (jb.mode == 3) pack_mx6_body<false>(w, jb.C_out, jb.C_in, jb.K, ncob_pad, out, gid);
+    else if (jb.mode == 5) pack_mx6_body<true>(w, jb.C_out, jb.C_in, jb.K, ncob_pad, out, gid);
     else pack_bf16_body(w, jb.C_out, jb.C_in, jb.K, jb.mode, rows, kdim, ncob_pad, out, gid);
 }
 }  // namespace
 
 extern "C" int tq_pack_job_blocks(int C_out, int C_in, int K, int mode) {
-    if (C_out <= 0 || mode < 0 || mode > 4) return 0;
+    if (C_out <= 0 || mode < 0 || mode > 5) return 0;
     if (mode == 4) return (C_out + 255) / 256;
     if (C_in <= 0 || K <= 0) return 0;
-    const int rows = mode != 1 ? C_out : C_in;
-    const int kdim = mode != 1 ? C_in : C_out;
+    const bool tr = mode == 1 || mode == 5;
+    const int rows = tr ? C_in : C_out;
+    const int kdim = tr ? C_out : C_in;
     const int tile = tq_conv_tile_co(rows);
     const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
-    const size_t total = (mode == 2 || mode == 3) ? (size_t)((C_in + 63) / 64) * K * ncob_pad * 64
-                                                  : (size_t)((kdim + 31) / 32) * K * ncob_pad * 64;
+    const size_t total = (mode == 2 || mode == 3 || mode == 5) ? (size_t)((kdim + 63) / 64) * K * ncob_pad * 64
+                                                               : (size_t)((kdim + 31) / 32) * K * ncob_pad * 64;
     return (int)((total + 255) / 256);
 }
 
@@ -360,32 +381,30 @@ extern "C" int tq_pack_jobs(const TqPackJob* jobs_device, int njobs, int total_b
 }
 
 extern "C" size_t tq_conv_weight_pack_bytes(int C_out, int C_in, int K, int mode) {
-    if (mode == 2 || mode == 3) {
-        const int tile2 = tq_conv_tile_co(C_out);
-        return (size_t)((C_in + 63) / 64) * K * (((C_out + tile2 - 1) / tile2) * tile2 / 16) * 4 * 64 * 16;
-    }
-    const int rows = mode == 0 ? C_out : C_in;
-    const int kdim = mode == 0 ? C_in : C_out;
+    const bool tr = mode == 1 || mode == 5;
+    const int rows = tr ? C_in : C_out;
+    const int kdim = tr ? C_out : C_in;
     const int tile = tq_conv_tile_co(rows);
     const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
-    const int nchunks = (kdim + 31) / 32;
-    return (size_t)nchunks * K * ncob_pad * 2 * 64 * 16;
+    if (mode == 2 || mode == 3 || mode == 5) return (size_t)((kdim + 63) / 64) * K * ncob_pad * 4 * 64 * 16;
+    return (size_t)((kdim + 31) / 32) * K * ncob_pad * 2 * 64 * 16;
 }
 
 extern "C" int tq_pack_conv_weight(const float* w, int C_out, int C_in, int K, int mode, void* out, hipStream_t stream) {
-    if (!w || !out || C_out <= 0 || C_in <= 0 || K <= 0 || mode < 0 || mode > 3) return TQ_ERR_ARG;
-    const int rows = mode != 1 ? C_out : C_in;
-    const int kdim = mode != 1 ? C_in : C_out;
+    if (!w || !out || C_out <= 0 || C_in <= 0 || K <= 0 || mode < 0 || mode > 5 || mode == 4) return TQ_ERR_ARG;
+    const bool tr = mode == 1 || mode == 5;
+    const int rows = tr ? C_in : C_out;
+    const int kdim = tr ? C_out : C_in;
     const int tile = tq_conv_tile_co(rows);
     const int ncob_pad = ((rows + tile - 1) / tile) * tile / 16;
-    if (mode == 2 || mode == 3) {
-        const size_t total2 = (size_t)((C_in + 63) / 64) * K * ncob_pad * 64;
+    if (mode == 2 || mode == 3 || mode == 5) {
+        const size_t total2 = (size_t)((kdim + 63) / 64) * K * ncob_pad * 64;
         if (mode == 2) {
             hipLaunchKernelGGL(pack_conv_weight_mx_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, w, C_out,
                                C_in, K, ncob_pad, reinterpret_cast<uint4*>(out));
         } else {
             hipLaunchKernelGGL(pack_conv_weight_mx6_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, stream, w, C_out,
-                               C_in, K, ncob_pad, reinterpret_cast<uint4*>(out));
+                               C_in, K, ncob_pad, reinterpret_cast<uint4*>(out), mode == 5 ? 1 : 0);
         }
         TQ_CHECK_LAUNCH();
         return 0;

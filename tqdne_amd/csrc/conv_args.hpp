@@ -41,6 +41,7 @@ struct ConvArgs {
     int kvH, kvD, kvTp;
     float kvscale;
     int* range_flag;  // see TqConvDesc.range_flag
+    const uint32_t* in_amax;  // data gradient, TQ_WFMT_F16_MX6: bit pattern of max|dy| over the whole tensor (see TqConvBwdDesc.dy_amax)
     // fused GroupNorm finalisation (TqConvDesc.gn_fuse): the workgroup that completes a sample's statistics folds them
     unsigned long long* gf_counters;   // nullptr: off
     const float* gf_partner;

@@ -197,7 +197,7 @@ def get_store(model, device) -> PackedStore:
 class ConvSite:
     """One convolution's weights: torch parameter + packed bf16 hi/lo MFMA fragments (a buffer of the model's PackedStore)."""
 
-    __slots__ = ("weight", "bias", "packed", "packed_t", "C_out", "C_in", "K", "version", "name", "pack_mode", "entry", "tail")
+    __slots__ = ("weight", "bias", "packed", "packed_t", "pack_mode_t", "C_out", "C_in", "K", "version", "name", "pack_mode", "entry", "tail")
 
     def __init__(self, name, weight, bias, device, lib, packed=None, tail_bytes=0, store=None):
         self.name = name
@@ -216,6 +216,7 @@ class ConvSite:
             self.packed = torch.empty(nbytes + tail_bytes, dtype=torch.uint8, device=device)
         self.pack_mode = 0     # tq_pack_conv_weight mode of `packed` (2: TQ_WFMT_F16_MX8), set by the plan builder
         self.packed_t = None  # transposed / tap-flipped fragments for the data gradient (training only)
+        self.pack_mode_t = 1  # their tq_pack_conv_weight mode: 1 bf16x3, 5 fp16 + MX-fp6 (set by the backward plan)
         self.version = -1
 
 
@@ -803,11 +804,11 @@ class UNetEngine:
 
     def repack_transposed(self, stream: int):
         """Transposed / tap-flipped fragments for the data-gradient launches (training only)."""
-        v = sum(s.weight._version for s in self.dgrad_sites)
+        v = (sum(s.weight._version for s in self.dgrad_sites), sum(s.pack_mode_t for s in self.dgrad_sites))
         if v == self._wt_version:
             return
-        pack_batch(self.lib, self.dev, [(s.weight.data_ptr(), s.packed_t.data_ptr(), s.C_out, s.C_in, s.K, 1) for s in self.dgrad_sites],
-                   stream, torch.cuda.is_current_stream_capturing())
+        pack_batch(self.lib, self.dev, [(s.weight.data_ptr(), s.packed_t.data_ptr(), s.C_out, s.C_in, s.K, s.pack_mode_t)
+                                        for s in self.dgrad_sites], stream, torch.cuda.is_current_stream_capturing())
         self._wt_version = v
 
     # ------------------------------------------------------------------ run

@@ -21,7 +21,8 @@ from typing import Dict, List
 
 import torch
 
-from ._lib import (TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_STATS, STAT_SLOT, TqConvBwdDesc, check)
+from ._lib import (PACK_MODE_T, TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_STATS, TQ_WFMT_BF16X3, TQ_WFMT_F16_MX6, STAT_SLOT,
+                   TqConvBwdDesc, check)
 
 
 def _p(t):
@@ -37,6 +38,14 @@ FUSE_COLSUM = __import__("os").environ.get("TQDNE_FUSE_COLSUM", "0") != "0"
 # Weight-gradient launches on a second HIP stream next to the rest of the sweep (see BackwardPlan.run): measured -0.9 ms on the
 # 27 ms training step of the paper UNet at B = 64 (same box, twice).  TQDNE_BWD_STREAMS=1: everything on one stream.
 BWD_STREAMS = int(__import__("os").environ.get("TQDNE_BWD_STREAMS", "2"))
+
+# Round 4.  (1) Column sums (and max|.|) of a gradient tensor inside the tq_gn_bwd_apply launch that writes it last, instead of a
+# tq_colsum pass of their own (TQDNE_FUSE_APPLY_COLSUM=0: separate passes).  (2) Data gradients in the fp16 + MX-fp6 scheme on dy
+# scaled by a power of two taken from that max (TqConvBwdDesc.wfmt / dy_amax), where the shape allows (64 | C_dy, 128 | C_dx);
+# TQDNE_DGRAD_SCHEME=bf16x3 keeps round 3's three-product scheme everywhere.
+FUSE_APPLY_COLSUM = __import__("os").environ.get("TQDNE_FUSE_APPLY_COLSUM", "1") != "0"
+DGRAD_SCHEME = __import__("os").environ.get("TQDNE_DGRAD_SCHEME", "f16mx6").lower()
+N_AMAX = 256   # slots for max|dy| (one per gradient tensor that feeds a data gradient), kept in the tail of the flat buffer
 
 
 def _nslots(T):
@@ -142,7 +151,13 @@ class BackwardPlan:
         total = (total + 63) // 64 * 64
         self.off_demb = total
         total += self.B * e.emb_total
+        total = (total + 63) // 64 * 64
+        off_amax = total
+        total += N_AMAX            # (zeroed with the buffer at the start of every sweep)
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.amax = self.flat[off_amax:off_amax + N_AMAX].view(torch.int32)   # bit patterns of max|dy|, written by atomic max
+        self._amax_slot = {}       # data_ptr of a gradient tensor -> index of its slot
+        self._mx6_dgrads = []      # (descriptor, site) of the data gradients planned in the fp16 + MX-fp6 scheme
         self.gview = {id(p): self.flat[offs[id(p)]:offs[id(p)] + p.numel()].view_as(p) for p in swept + emb_w + emb_b + tail}
         self.demb_all = self.flat[self.off_demb:self.off_demb + self.B * e.emb_total].view(self.B, e.emb_total)
         o = self.off_emb
@@ -185,6 +200,15 @@ class BackwardPlan:
             out.append((lo_, hi_, run_max))
         return out
 
+    def amax_ptr(self, dy_ptr: int, create: bool = True):
+        """device address of the slot holding max|dy| of the gradient tensor at ``dy_ptr`` (None if it has none and not ``create``)"""
+        i = self._amax_slot.get(dy_ptr)
+        if i is None:
+            if not create or len(self._amax_slot) >= N_AMAX:
+                return None
+            i = self._amax_slot[dy_ptr] = len(self._amax_slot)
+        return self.amax.data_ptr() + 4 * i
+
     def g(self, param):
         """the gradient view of ``param``; called while an op is being assembled, so it also records that op (the next one
         appended to self.ops) as the last writer of that gradient"""
@@ -209,9 +233,20 @@ class BackwardPlan:
             colsum = (None, 0, site.bias, None)
         bc, stride, c1, c2 = colsum if colsum is not None else (None, 0, None, None)
         if FUSE_COLSUM is False and colsum is not None:   # A/B switch: the column sums as their own pass over dy
-            self.ops.append([lib.tq_colsum, [_p(dy), self.B, rec.out.T if rec.out is not None else rec.desc.T_out, site.C_out, bc, stride,
-                                             _p(self.g(c1)) if c1 is not None else None, _p(self.g(c2)) if c2 is not None else None, None],
-                             "colsum:" + site.name])
+            T_dy = rec.out.T if rec.out is not None else rec.desc.T_out
+            amax = self.amax_ptr(dy.data_ptr())
+            wr = self._grad_writer.get(dy.data_ptr())
+            if FUSE_APPLY_COLSUM and wr is not None and wr[0][0] is lib.tq_gn_bwd_apply:
+                # the launch that writes dy last is a tq_gn_bwd_apply: it forms the sums from its registers (its op is rewritten in
+                # place; the gradients are final no earlier than before, so g() still records the current position)
+                op = wr[0]
+                op[0] = lib.tq_gn_bwd_apply_colsum
+                op[1] = op[1] + [bc, stride, _p(self.g(c1)) if c1 is not None else None, _p(self.g(c2)) if c2 is not None else None, amax]
+                op[2] = "gn_bwd_apply+colsum:" + site.name
+            else:
+                self.ops.append([lib.tq_colsum, [_p(dy), self.B, T_dy, site.C_out, bc, stride,
+                                                 _p(self.g(c1)) if c1 is not None else None, _p(self.g(c2)) if c2 is not None else None, None, amax],
+                                 "colsum:" + site.name])
             bc, stride, c1, c2 = None, 0, None, None
             self._wgrad_ops[-1] = len(self.ops)
         self.op_flops[len(self.ops)] = 2 * site.C_in * site.C_out * site.K * rec.desc.T_out * self.B
@@ -221,15 +256,31 @@ class BackwardPlan:
                                                            _p(self.g(c1)) if c1 is not None else None,
                                                            _p(self.g(c2)) if c2 is not None else None], "wgrad:" + site.name])
 
-    def _dgrad(self, rec, dy, T, dsts, accumulate, chain=True, stats=True):
+    def _dgrad(self, rec, dy, T, dsts, accumulate, chain=True, stats=True, amax_of=None):
         """dy (B,T,C_out of the forward conv) -> gradient wrt the forward conv's (activated) inputs.
-        chain=True applies the forward prologue's derivative and emits GN sums; returns the gstats buffer (or None)."""
+        chain=True applies the forward prologue's derivative and emits GN sums; returns the gstats buffer (or None).
+        ``amax_of``: the tensor whose max|.| slot bounds dy (default dy itself; the zero-stuffed copy of a Downsample's gradient
+        has the maximum of the tensor it was made from)."""
         lib, site = self.lib, rec.site
+        # scheme: fp16 + MX-fp6 on the scaled dy where the kernel is built for the shape and a max|dy| slot exists (filled by the
+        # column-sum pass that every conv with a bias has ahead of its data gradient)
+        amax = self.amax_ptr((amax_of if amax_of is not None else dy).data_ptr(), create=False)
+        mx6 = (DGRAD_SCHEME == "f16mx6" and amax is not None and site.C_out % 64 == 0 and site.C_in % 128 == 0
+               and getattr(self.e, "scheme", "auto") == "auto" and getattr(self.m, "_conv_scheme", "auto") == "auto")
+        want = 5 if mx6 else 1
         if site.packed_t is None:
-            site.packed_t = torch.empty(lib.tq_conv_weight_pack_bytes(site.C_out, site.C_in, site.K, 1), dtype=torch.uint8,
-                                        device=self.dev)
+            nb = max(lib.tq_conv_weight_pack_bytes(site.C_out, site.C_in, site.K, 1),
+                     lib.tq_conv_weight_pack_bytes(site.C_out, site.C_in, site.K, 5) if site.C_out % 64 == 0 else 0)
+            site.packed_t = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+            site.pack_mode_t = want
             self.e.dgrad_sites.append(site)
+        elif site.pack_mode_t != want:
+            raise RuntimeError(f"{site.name}: data gradient planned twice with different weight formats")
         d = TqConvBwdDesc()
+        d.wfmt = TQ_WFMT_F16_MX6 if mx6 else TQ_WFMT_BF16X3
+        d.dy_amax = amax if mx6 else None
+        if mx6:
+            self._mx6_dgrads.append((d, site))
         d.B, d.T, d.C_dy = self.B, T, site.C_out
         d.C_dx0 = dsts[0].shape[2]
         d.C_dx1 = dsts[1].shape[2] if len(dsts) > 1 else 0
@@ -258,6 +309,8 @@ class BackwardPlan:
                                                   _p(rec.gn[0]) if (chain and rec.gn) else None,
                                                   _p(rec.gn[1]) if (chain and rec.gn) else None, _p(dsts[0]),
                                                   _p(dsts[1]) if len(dsts) > 1 else None, _p(gst)], "dgrad:" + site.name])
+        for t_ in dsts:
+            self._wrote(t_)
         return gst
 
     def _gn_bwd(self, gst, gn, norm, T, Ctot):
@@ -271,12 +324,19 @@ class BackwardPlan:
         dx = self.grad(act)
         self.ops.append([self.lib.tq_gn_bwd_apply, [_p(G), _p(act.buf), _p(r), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dx), self.B,
                                                     act.T, act.C, Ctot, coff, int(act.gw)], "gn_bwd_apply"])
+        self._wrote(dx)
         act.gw = True
+
+    def _wrote(self, grad_tensor):
+        """the op just appended is (so far) the last writer of ``grad_tensor``: a later consumer that needs the tensor's column
+        sums may fold them into it (see _wgrad)"""
+        self._grad_writer[grad_tensor.data_ptr()] = (self.ops[-1],)
 
     # ------------------------------------------------------------------ plan
     def _build(self):
         e, m, lib, B = self.e, self.m, self.lib, self.B
         self._wgrad_ops = []
+        self._grad_writer = {}   # data_ptr of a gradient tensor -> (op entry of its last writer so far,)
         if not hasattr(e, "dgrad_sites"):
             e.dgrad_sites = []
         for a in e.acts:
@@ -318,7 +378,7 @@ class BackwardPlan:
             self._wgrad_ops.append(len(self.ops))
             self.ops.append([lib.tq_conv1d_bwd_weight, [C.byref(d), _p(so.grad), _p(self.stem_x_btc), None, None, None,
                                                         _p(self.dw_stem32), None, 0], "wgrad:stem (generic)"])
-        self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None, None], "colsum:stem"])
+        self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None, None, None], "colsum:stem"])
         # shared workspace of the weight-gradient slabs
         self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=self.dev)
         for i in self._wgrad_ops:
@@ -383,6 +443,7 @@ class BackwardPlan:
         ws = self.scratch("attn_bwd_ws", 4 * ab.num_heads * Tp * t["D"]) if t["D"] in (32, 64) else None
         self.ops.append([self.lib.tq_attention_bwd_ws, [_p(qkv.buf), _p(att.buf), _p(datt), _p(t["lse"]), _p(delta), _p(dqkv), _p(ws),
                                                         B, T, ab.num_heads, t["D"]], "attention bwd"])
+        self._wrote(dqkv)
         self._wgrad(t["rec_qkv"], dqkv)
         G = self.scratch("G", T, Cc)
         gst = self._dgrad(t["rec_qkv"], dqkv, T, [G], accumulate=False)
@@ -396,7 +457,7 @@ class BackwardPlan:
         self._wgrad(rec, dout)
         dyz = self.scratch("dyz", x.T, out.C)
         self.ops.append([self.lib.tq_zero_stuff, [_p(dout), _p(dyz), self.B, out.T, x.T, out.C], "zero_stuff"])
-        self._dgrad(rec, dyz, x.T, [self.grad(x)], accumulate=x.gw, chain=False)
+        self._dgrad(rec, dyz, x.T, [self.grad(x)], accumulate=x.gw, chain=False, amax_of=dout)
         x.gw = True
 
     def _bwd_up(self, t):
@@ -407,6 +468,7 @@ class BackwardPlan:
         dup = self.scratch("dup", out.T, x.C)
         self._dgrad(rec, dout, out.T, [dup], accumulate=False, chain=False)
         self.ops.append([self.lib.tq_pair_sum, [_p(dup), _p(self.grad(x)), self.B, x.T, x.C, int(x.gw)], "pair_sum"])
+        self._wrote(x.grad)
         x.gw = True
 
     # ------------------------------------------------------------------ run
@@ -420,6 +482,7 @@ class BackwardPlan:
         if last.get("infer", False):
             raise RuntimeError("the last forward of this plan was an inference forward (infer=True): it kept nothing for a backward")
         stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self._follow_scheme()
         e.repack_transposed(stream)
         self.flat.zero_()
         p, seed = float(last["dropout_p"]), int(last["dropout_seed"])
@@ -514,6 +577,15 @@ class BackwardPlan:
                 o = self.offs[id(p_)]
                 res.append(out[o:o + p_.numel()].view_as(p_))
         return res
+
+    def _follow_scheme(self):
+        """the forward plan left the fp16-range scheme (range guard, or bf16x3 on request): the data gradients follow -- descriptors
+        edited in place, the transposed fragments re-packed as bf16x3 on the next repack_transposed"""
+        if self._mx6_dgrads and (self.e.scheme != "auto" or getattr(self.m, "_conv_scheme", "auto") != "auto"):
+            for d, site in self._mx6_dgrads:
+                d.wfmt, d.dy_amax = TQ_WFMT_BF16X3, None
+                site.pack_mode_t = 1
+            self._mx6_dgrads = []
 
     def _fire_points(self, bucket_elems):
         key = int(bucket_elems)
@@ -622,6 +694,7 @@ class SeqBackwardPlan(BackwardPlan):
         from .engine import Act, ConvRec, ConvSite
         e, m, lib, B = self.e, self.m, self.lib, self.B
         self._wgrad_ops = []
+        self._grad_writer = {}   # data_ptr of a gradient tensor -> (op entry of its last writer so far,)
         if not hasattr(e, "dgrad_sites"):
             e.dgrad_sites = []
         for a in e.acts:
@@ -660,7 +733,7 @@ class SeqBackwardPlan(BackwardPlan):
         self._wgrad_ops.append(len(self.ops))
         self.ops.append([lib.tq_conv1d_bwd_weight, [C.byref(d), _p(so.grad), _p(self.x_btc.buf), None, None, None,
                                                     _p(self.dw_stem32), None, 0], "wgrad:input_layer"])
-        self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None, None], "colsum:stem"])
+        self.ops.append([lib.tq_colsum, [_p(so.grad), B, so.T, so.C, None, 0, _p(self.g(stem.bias)), None, None, None], "colsum:stem"])
         # d input (only run on request): transposed conv into a 32-channel channels-last buffer
         self.dx_btc = self._empty(B, so.T, 32)
         n0 = len(self.ops)
@@ -681,6 +754,7 @@ class SeqBackwardPlan(BackwardPlan):
         e, m, lib = self.e, self.m, self.lib
         last = e._last
         stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self._follow_scheme()
         e.repack_transposed(stream)
         stem = m.input_layer
         cin, K = stem.in_channels, stem.kernel_size[0]

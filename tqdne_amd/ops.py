@@ -154,8 +154,10 @@ from ._lib import TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_S
 
 
 def conv1d_bwd_data(dy, weight, *, x0=None, x1=None, gscale=None, gshift=None, silu=False, stats=False, split=None,
-                    accumulate_into=None, dropout_p=0.0, dropout_seed=0, dropout_site=0):
-    """dy (B,T,C_out); weight (C_out, C_in, K) torch layout.  Returns (g0, g1|None, gstats|None)."""
+                    accumulate_into=None, dropout_p=0.0, dropout_seed=0, dropout_site=0, wfmt=0, dy_amax=None):
+    """dy (B,T,C_out); weight (C_out, C_in, K) torch layout.  Returns (g0, g1|None, gstats|None).
+    ``wfmt``: TQ_WFMT_BF16X3 (0) or TQ_WFMT_F16_MX6 (2: dy scaled into the fp16 range by the power of two that ``dy_amax`` selects --
+    an int32[1] device tensor holding the bit pattern of max|dy|; default: computed here with tq_colsum's amax output)."""
     lib = _lib.load()
     B, T, C_dy = dy.shape
     C_out, C_in, K = weight.shape
@@ -183,7 +185,12 @@ def conv1d_bwd_data(dy, weight, *, x0=None, x1=None, gscale=None, gshift=None, s
         f |= TQ_BWD_DROPOUT
     d.flags = f
     d.dropout_site, d.dropout_p, d.dropout_seed = dropout_site, dropout_p, dropout_seed
-    wp = pack_conv_weight(weight, 1)
+    d.wfmt = wfmt
+    if wfmt == _lib.TQ_WFMT_F16_MX6:
+        if dy_amax is None:
+            dy_amax = amax_bits(dy)
+        d.dy_amax = dy_amax.data_ptr()
+    wp = pack_conv_weight(weight, _lib.PACK_MODE_T[wfmt])
     check(lib.tq_conv1d_bwd_data(C.byref(d), _p(dy), _p(wp), _p(x0), _p(x1), _p(gscale), _p(gshift), _p(g0), _p(g1), _p(st),
                                  _stream(dy.device)), "conv1d_bwd_data")
     return g0, g1, st
@@ -235,13 +242,36 @@ def gn_bwd_apply(g, x, coefs, c_total, c_offset=0, r=None, accumulate_into=None)
     return dx
 
 
-def colsum(dy, per_sample=True, total=True, bscale=None):
+def colsum(dy, per_sample=True, total=True, bscale=None, amax=None):
+    """``amax``: optional zeroed int32[1] device tensor that receives the bit pattern of max|dy| (atomic max)"""
     lib = _lib.load()
     B, T, Cn = dy.shape
     obc = torch.zeros(B, Cn, device=dy.device) if per_sample else None
     oc = torch.zeros(Cn, device=dy.device) if total else None
-    check(lib.tq_colsum(_p(dy), B, T, Cn, _p(obc), Cn, _p(oc), None, _p(bscale), _stream(dy.device)), "colsum")
+    check(lib.tq_colsum(_p(dy), B, T, Cn, _p(obc), Cn, _p(oc), None, _p(bscale), _p(amax), _stream(dy.device)), "colsum")
     return obc, oc
+
+
+def amax_bits(dy):
+    """int32[1] device tensor with the IEEE bit pattern of max|dy| (what TqConvBwdDesc.dy_amax points at), from tq_colsum"""
+    lib = _lib.load()
+    B, T, Cn = dy.shape
+    out = torch.zeros(1, dtype=torch.int32, device=dy.device)
+    check(lib.tq_colsum(_p(dy), B, T, Cn, None, 0, None, None, None, _p(out), _stream(dy.device)), "colsum (amax)")
+    return out
+
+
+def gn_bwd_apply_colsum(g, x, coefs, c_total, c_offset=0, r=None, accumulate_into=None, per_sample=True, total=True, amax=None):
+    """tq_gn_bwd_apply_colsum: dx as gn_bwd_apply, plus (per-sample column sums | None, total column sums | None) of dx"""
+    lib = _lib.load()
+    B, T, Cs = g.shape
+    dx = accumulate_into if accumulate_into is not None else torch.empty_like(g)
+    obc = torch.zeros(B, Cs, device=g.device) if per_sample else None
+    oc = torch.zeros(Cs, device=g.device) if total else None
+    check(lib.tq_gn_bwd_apply_colsum(_p(g), _p(x), _p(r), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]), _p(dx), B, T, Cs, c_total, c_offset,
+                                     int(accumulate_into is not None), _p(obc), Cs, _p(oc), None, _p(amax), _stream(g.device)),
+          "gn_bwd_apply_colsum")
+    return dx, obc, oc
 
 
 def zero_stuff(dy, T_in):
