@@ -119,8 +119,9 @@ typedef struct TqConvBwdDesc {
      * TQ_WFMT_F16_MX6 (packed_w_t from pack mode 5; 64 | C_dy and 128 | C_dx0 + C_dx1): dy is staged times the exact power of two
      * that brings max|dy| into [2^13, 2^14) -- gradients are far below fp16's normal range otherwise -- and the accumulators are
      * multiplied by its inverse, so the result has the accuracy of the forward scheme (~2^-15 relative) at half the MFMA cycles of
-     * bf16x3.  dy_amax: DEVICE pointer to the IEEE bit pattern of max|dy| over the whole tensor (any upper bound within a factor 8 will do), e.g.
-     * written by tq_colsum(..., amax_out) on the same dy; required for TQ_WFMT_F16_MX6. */
+     * bf16x3.  dy_amax: DEVICE pointer to a TQ_AMAX_WORDS block as tq_colsum(..., amax_out) / tq_gn_bwd_apply_colsum fill it for the same
+     * dy (the maximum over its TQ_AMAX_WAYS words = IEEE bit pattern of max|dy|; any upper bound within a factor 8 will do); required for
+     * TQ_WFMT_F16_MX6. */
     int32_t wfmt;
     int32_t reserved;
     const uint32_t* dy_amax;
@@ -254,8 +255,13 @@ int tq_gemm_f32_jobs(const TqGemmJob* jobs_device, int njobs, int total_tiles, h
 /* GaussianFourierProjection features (blocks.py:15-26): out (B, 2 half) = [sin(2 pi t W) | cos(2 pi t W)] */
 int tq_fourier_features(const float* t, const float* W, float* out, int B, int half, hipStream_t stream);
 
-/* amax_out (ABI 5, nullable): *amax_out = max(*amax_out, bit pattern of max|dy|) by atomic max -- zero it first; non-negative floats
- * order like their bit patterns, NaN sorts above everything: a poisoned tensor stays visible.  Feeds TqConvBwdDesc.dy_amax. */
+/* amax_out (ABI 5, nullable): a block of TQ_AMAX_WORDS uint32 that receives the bit pattern of max|dy| by atomic max -- zero it first.
+ * The maximum is SPREAD over TQ_AMAX_WAYS words TQ_AMAX_STRIDE apart (one per 128-byte line; a workgroup updates word (its index mod
+ * TQ_AMAX_WAYS): atomics on one address serialise at ~11 ns each); the maximum of those words is max|dy|.  Non-negative floats order
+ * like their bit patterns; a NaN in dy is recorded as +inf, so a poisoned tensor stays visible.  Feeds TqConvBwdDesc.dy_amax. */
+#define TQ_AMAX_WAYS 16
+#define TQ_AMAX_STRIDE 32
+#define TQ_AMAX_WORDS (TQ_AMAX_WAYS * TQ_AMAX_STRIDE)
 int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, float* out_c2,
               const float* bscale, uint32_t* amax_out, hipStream_t stream);
 /* gradient plumbing of the strided / upsampled convs: out[b,u,:] = (u even) ? dy[b,u/2,:] : 0 for u < T_in;

@@ -307,7 +307,7 @@ def test_dgrad_f16_mx6_refuses_unsupported_shapes_and_missing_amax():
     d.B, d.T, d.C_dy, d.C_dx0, d.C_dx1, d.ktaps, d.wfmt = 1, 64, 64, 128, 0, 5, _lib.TQ_WFMT_F16_MX6
     x = torch.zeros(64 * 128, device=dev())
     assert lib.tq_conv1d_bwd_data(C.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), None, None, None) == -1  # no amax
-    am = torch.zeros(1, dtype=torch.int32, device=dev())
+    am = torch.zeros(_lib.TQ_AMAX_WORDS, dtype=torch.int32, device=dev())
     d.dy_amax = am.data_ptr()
     d.C_dx0 = 64      # 128 does not divide the produced channels
     assert lib.tq_conv1d_bwd_data(C.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), None, None, None) == -2
@@ -318,17 +318,17 @@ def test_dgrad_f16_mx6_refuses_unsupported_shapes_and_missing_amax():
 @pytest.mark.parametrize("C,T,B", [(64, 4096, 2), (256, 300, 3), (192, 130, 2), (512, 64, 2)])
 def test_gn_bwd_apply_with_fused_column_sums_and_amax(C, T, B):
     """tq_gn_bwd_apply_colsum = tq_gn_bwd_apply followed by tq_colsum of its output (bit-identical dx; sums to rounding; exact max)"""
-    from tqdne_amd import ops
+    from tqdne_amd import _lib, ops
     g = torch.Generator().manual_seed(C + T)
     d = dev()
     G, x, r = (torch.randn(B, T, C, generator=g).to(d) for _ in range(3))
     coefs = tuple(torch.randn(B, C, generator=g).to(d) for _ in range(3))
     ref = ops.gn_bwd_apply(G, x, coefs, C, r=r)
-    am = torch.zeros(1, dtype=torch.int32, device=d)
+    am = torch.zeros(_lib.TQ_AMAX_WORDS, dtype=torch.int32, device=d)
     dx, obc, oc = ops.gn_bwd_apply_colsum(G, x, coefs, C, r=r, amax=am)
     assert torch.equal(dx, ref)
     assert rel_err(obc.cpu(), ref.double().sum(1).cpu()) < 1e-5 and rel_err(oc.cpu(), ref.double().sum((0, 1)).cpu()) < 1e-5
-    assert am.view(torch.float32).item() == float(ref.abs().max())
+    assert ops.amax_value(am) == float(ref.abs().max())
     # accumulate form on a source of a concat (coefficient offset), no residual
     C2 = C // 2
     G2, x2 = G[:, :, :C2].contiguous(), x[:, :, :C2].contiguous()
@@ -337,8 +337,8 @@ def test_gn_bwd_apply_with_fused_column_sums_and_amax(C, T, B):
     dx2, obc2, _ = ops.gn_bwd_apply_colsum(G2, x2, coefs, C, c_offset=C - C2, accumulate_into=base.clone(), total=False)
     assert torch.equal(dx2, ref2) and rel_err(obc2.cpu(), ref2.double().sum(1).cpu()) < 1e-5
     # the stand-alone pass reports the same maximum; a NaN anywhere is carried as +inf
-    am2 = torch.zeros(1, dtype=torch.int32, device=d)
+    am2 = torch.zeros(_lib.TQ_AMAX_WORDS, dtype=torch.int32, device=d)
     ops.colsum(ref, amax=am2)
-    assert am2.item() == am.item()
+    assert ops.amax_value(am2) == ops.amax_value(am)
     bad = ref.clone(); bad[B - 1, T // 2, C - 3] = float("nan")
-    assert math.isinf(ops.amax_bits(bad).view(torch.float32).item())
+    assert math.isinf(ops.amax_value(ops.amax_bits(bad)))

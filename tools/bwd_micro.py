@@ -30,9 +30,10 @@ def med(fn, n=9, warm=3):
     return sorted(ts)[n // 2]
 
 
+ONLY = os.environ.get("MICRO_ONLY", "")
 print(f"# B = {B}; us per launch")
 print("## data gradient: C_dy -> C_dx, k, T: bf16x3 | f16+mx6 | ratio")
-for (cdy, cdx, k, T) in [(256, 256, 5, 1024), (256, 512, 5, 1024), (256, 256, 5, 512), (128, 128, 5, 2048), (256, 384, 5, 1024),
+for (cdy, cdx, k, T) in [] if ONLY not in ("", "dgrad") else [(256, 256, 5, 1024), (256, 512, 5, 1024), (256, 256, 5, 512), (128, 128, 5, 2048), (256, 384, 5, 1024),
                          (128, 256, 5, 2048), (768, 256, 1, 512), (256, 256, 1, 512), (256, 128, 3, 1024)]:
     dy = torch.randn(B, T, cdy, device=dev) * 1e-5
     w = torch.randn(cdy, cdx, k, device=dev) / (k * cdx) ** 0.5
@@ -51,7 +52,7 @@ for (cdy, cdx, k, T) in [(256, 256, 5, 1024), (256, 512, 5, 1024), (256, 256, 5,
     print(f"{cdy:4d} -> {cdx:4d} k{k} T{T:5d}: {res[0]:7.1f} | {res[1]:7.1f} | {res[1] / res[0]:.2f}")
 
 print("## weight gradient (+ slab reduce): C_in -> C_out, k, T")
-for (ci, co, k, T) in [(256, 256, 5, 1024), (512, 256, 5, 1024), (256, 256, 5, 512), (128, 128, 5, 2048), (64, 64, 5, 4096), (256, 768, 1, 512),
+for (ci, co, k, T) in [] if ONLY not in ("", "wgrad") else [(256, 256, 5, 1024), (512, 256, 5, 1024), (256, 256, 5, 512), (128, 128, 5, 2048), (64, 64, 5, 4096), (256, 768, 1, 512),
                        (512, 256, 1, 1024)]:
     x = torch.randn(B, T, ci, device=dev)
     dy = torch.randn(B, T, co, device=dev)
@@ -59,12 +60,12 @@ for (ci, co, k, T) in [(256, 256, 5, 1024), (512, 256, 5, 1024), (256, 256, 5, 5
     print(f"{ci:4d} -> {co:4d} k{k} T{T:5d}: {med(lambda: ops.conv1d_bwd_weight(dy, x, (co, ci, k), gscale=gs, gshift=gh, silu=True)):7.1f}  (incl. the wrapper's allocations)")
 
 print("## GroupNorm backward apply (+ column sums): C, T: apply | colsum | apply + colsum | fused")
-for (Cc, T) in [(64, 4096), (128, 2048), (256, 1024), (256, 512), (512, 1024)]:
+for (Cc, T) in [] if ONLY not in ("", "gn") else [(64, 4096), (128, 2048), (256, 1024), (256, 512), (512, 1024)]:
     G, x, r = (torch.randn(B, T, Cc, device=dev) for _ in range(3))
     coefs = tuple(torch.randn(B, Cc, device=dev) for _ in range(3))
     dx = torch.empty_like(G)
     obc, oc = torch.zeros(B, Cc, device=dev), torch.zeros(Cc, device=dev)
-    am = torch.zeros(1, dtype=torch.int32, device=dev)
+    am = torch.zeros(_lib.TQ_AMAX_WORDS, dtype=torch.int32, device=dev)
     def apply():
         assert lib.tq_gn_bwd_apply(p(G), p(x), p(r), p(coefs[0]), p(coefs[1]), p(coefs[2]), p(dx), B, T, Cc, Cc, 0, 0, stream()) == 0
     def cs():
@@ -74,4 +75,9 @@ for (Cc, T) in [(64, 4096), (128, 2048), (256, 1024), (256, 512), (512, 1024)]:
     def fused():
         assert lib.tq_gn_bwd_apply_colsum(p(G), p(x), p(r), p(coefs[0]), p(coefs[1]), p(coefs[2]), p(dx), B, T, Cc, Cc, 0, 0, p(obc), Cc, p(oc),
                                           None, p(am), stream()) == 0
-    print(f"{Cc:4d} x {T:5d}: {med(apply):7.1f} | {med(cs):7.1f} | {med(both):7.1f} | {med(fused):7.1f}")
+    def cs_rows():     # per-sample sums only (no cross-sample same-address atomics)
+        assert lib.tq_colsum(p(dx), B, T, Cc, p(obc), Cc, None, None, None, p(am), stream()) == 0
+    def fused_rows():
+        assert lib.tq_gn_bwd_apply_colsum(p(G), p(x), p(r), p(coefs[0]), p(coefs[1]), p(coefs[2]), p(dx), B, T, Cc, Cc, 0, 0, p(obc), Cc, None,
+                                          None, p(am), stream()) == 0
+    print(f"{Cc:4d} x {T:5d}: {med(apply):7.1f} | {med(cs):7.1f} | {med(both):7.1f} | {med(fused):7.1f}   per-sample sums only: colsum {med(cs_rows):7.1f}, fused {med(fused_rows):7.1f}")

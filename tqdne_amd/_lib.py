@@ -43,6 +43,8 @@ def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, f
     return TQ_WFMT_F16_MX6 if v == "f16mx6" else TQ_WFMT_F16_MX8
 TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_DROPOUT, TQ_BWD_ACCUM, TQ_BWD_STATS = 1, 2, 4, 8, 16
 STAT_SLOT = 128
+TQ_AMAX_WAYS, TQ_AMAX_STRIDE = 16, 32           # include/tqdne_hip.h: max|dy| blocks of the column-sum kernels
+TQ_AMAX_WORDS = TQ_AMAX_WAYS * TQ_AMAX_STRIDE
 
 
 class TqGnFuse(C.Structure):

@@ -618,21 +618,36 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     }
 }
 
+// max|.| of a gradient tensor (feeds TqConvBwdDesc.dy_amax) is collected by atomic max into AMAX_WAYS words, one per 128-byte line,
+// the workgroup picking its word by index: atomics on ONE address serialise at the memory side at ~11 ns each (measured: with one
+// atomic per wave on a single word the 2048 atomics of a launch cost more than streaming the 67 MB tensor did), so one atomic per
+// WORKGROUP on one of 16 lines; the consumer takes the maximum of the 16 words.
+constexpr int AMAX_WAYS = TQ_AMAX_WAYS;
+constexpr int AMAX_STRIDE = TQ_AMAX_STRIDE;   // words between the ways (128 bytes)
+
 // Epilogue shared by colsum_kernel and gn_bwd_apply_cs_kernel: the workgroup's per-thread partial column sums `a` (float4 column c4,
 // row lane tr) and partial max|v| `mx` -> out_bc[b*stride + c] / out_c[c] / out_c2[c] (atomic adds into zeroed buffers) and
 // *amax_out (atomic max of bit patterns: non-negative floats order like their bits; NaN sorts above everything).
+template <int NT>
 __device__ __forceinline__ void colsum_finish(float* red, const float4& a, float mx, bool active, int c4n, int nrow, int c4, int tr, int C,
                                               int b, float sc, float* __restrict__ out_bc, int bc_stride, float* __restrict__ out_c,
                                               float* __restrict__ out_c2, unsigned* __restrict__ amax_out) {
     if (active) *reinterpret_cast<float4*>(red + (tr * c4n + c4) * 4) = a;
+    unsigned* wmax = reinterpret_cast<unsigned*>(red + (size_t)nrow * c4n * 4);   // [NT / 64] per-wave maxima behind the sums
     if (amax_out) {
-        unsigned m = __float_as_uint(mx);   // (mx >= 0 or NaN)
+        unsigned m = __float_as_uint(mx);   // (mx >= 0 or +inf)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(amax_out, m);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    if (amax_out && threadIdx.x == 0) {
+        unsigned m = wmax[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) m = max(m, wmax[w]);
+        if (m != 0u) atomicMax(amax_out + (blockIdx.x % AMAX_WAYS) * AMAX_STRIDE, m);
+    }
+    for (int c = threadIdx.x; c < C; c += NT) {
         float s = 0.f;
         for (int r2 = 0; r2 < nrow; ++r2) s += red[(r2 * c4n + (c >> 2)) * 4 + (c & 3)];
         s *= sc;
@@ -649,7 +664,8 @@ __device__ __forceinline__ float amax4(float m, const float4& v) {
 }
 
 // out_bc[b*stride + c] += sum_t dy[b,t,c];  out_c[c] += sum_{b,t} dy   (both optional; atomics into zeroed buffers)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int T, int C, float* __restrict__ out_bc,
+template <int NT>
+__global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ dy, int T, int C, float* __restrict__ out_bc,
                                                      int bc_stride, float* __restrict__ out_c, float* __restrict__ out_c2,
                                                      const float* __restrict__ bscale, unsigned* __restrict__ amax_out, int rpw) {
     // rpw: rows (positions) per workgroup
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
     const int nsl = (T + rpw - 1) / rpw;
     const int slot = blockIdx.x % nsl, b = blockIdx.x / nsl;
     const int c4n = C >> 2;
-    const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
+    const int nrow = NT / c4n > 0 ? NT / c4n : 1;
     const int c4 = threadIdx.x % c4n, tr = threadIdx.x / c4n;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     float mx = 0.f;
@@ -684,14 +700,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
             if (amax_out) mx = amax4(mx, v);
         }
     }
-    colsum_finish(red, a, mx, active, c4n, nrow, c4, tr, C, b, bscale ? bscale[b] : 1.0f, out_bc, bc_stride, out_c, out_c2, amax_out);
+    colsum_finish<NT>(red, a, mx, active, c4n, nrow, c4, tr, C, b, bscale ? bscale[b] : 1.0f, out_bc, bc_stride, out_c, out_c2, amax_out);
 }
 
 // gn_bwd_apply with the column sums (and max|.|) of the tensor it writes fused in: the consumers of dx -- the bias / time-embedding
 // gradients of the conv whose output gradient dx is, and the power-of-two scale of that conv's fp16-range data gradient -- otherwise
 // need a pass of their own over dx (63 tq_colsum launches per training step, 1.3 ms at B = 64).  Same tiling as colsum_kernel: a
 // workgroup owns `rpw` rows of one sample, thread = (float4 column, row lane).
-__global__ __launch_bounds__(256) void gn_bwd_apply_cs_kernel(const float* __restrict__ g, const float* __restrict__ x,
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_apply_cs_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                               const float* __restrict__ r, const float* __restrict__ cA,
                                                               const float* __restrict__ cB, const float* __restrict__ cC,
                                                               float* __restrict__ dx, int T, int Cs, int Ctot, int coff, int accum,
@@ -701,7 +718,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_cs_kernel(const float* __res
     const int nsl = (T + rpw - 1) / rpw;
     const int slot = blockIdx.x % nsl, b = blockIdx.x / nsl;
     const int c4n = Cs >> 2;
-    const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
+    const int nrow = NT / c4n > 0 ? NT / c4n : 1;
     const int c4 = threadIdx.x % c4n, tr = threadIdx.x / c4n;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     float mx = 0.f;
@@ -749,7 +766,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_cs_kernel(const float* __res
             mx = amax4(mx, o4);
         }
     }
-    colsum_finish(red, a, mx, active, c4n, nrow, c4, tr, Cs, b, 1.0f, out_bc, bc_stride, out_c, out_c2, amax_out);
+    colsum_finish<NT>(red, a, mx, active, c4n, nrow, c4, tr, Cs, b, 1.0f, out_bc, bc_stride, out_c, out_c2, amax_out);
 }
 
 __global__ void zero_stuff_kernel(const float* __restrict__ dy, float* __restrict__ out, int T_out, int T_in, int C, size_t n4) {
@@ -816,26 +833,39 @@ extern "C" int tq_gn_bwd_apply(const float* g, const float* x, const float* r, c
     return 0;
 }
 
-// rows per workgroup of the column-sum tilings: every workgroup ends in C atomic adds onto the same C addresses (plus its sample's):
-// those, not the loads, bound the kernel (more, smaller workgroups measured SLOWER).  So: as many rows per workgroup as still
-// leaves >= 512 workgroups.
-static int colsum_rows(int B, int T) {
-    static const int forced = [] { const char* e = getenv("TQDNE_COLSUM_ROWS"); return e ? atoi(e) : 0; }();   // (A/B switch)
+// Tiling of the column-sum kernels (colsum_kernel, gn_bwd_apply_cs_kernel): NT threads per workgroup, `rows` rows of one sample per
+// workgroup -- as many rows as still leaves `min_wgs` workgroups.  A/B switches: TQDNE_COLSUM_THREADS (256 | 1024), TQDNE_COLSUM_ROWS,
+// TQDNE_COLSUM_WGS.
+struct CsTiling { int nt, rows; };
+static CsTiling colsum_tiling(int B, int T) {
+    static const int f_nt = [] { const char* e = getenv("TQDNE_COLSUM_THREADS"); return e ? atoi(e) : 0; }();
+    static const int f_rows = [] { const char* e = getenv("TQDNE_COLSUM_ROWS"); return e ? atoi(e) : 0; }();
+    static const int f_wgs = [] { const char* e = getenv("TQDNE_COLSUM_WGS"); return e ? atoi(e) : 0; }();
+    CsTiling t;
+    t.nt = f_nt == 1024 ? 1024 : 256;
+    // (measured, tools/bwd_micro.py with the switches above, B = 64: 256 workgroups of 256 threads beat 512 / 1024 / 2048 and the
+    // 1024-thread form on every level -- fused apply 47 us next to 44 us for the plain apply; each workgroup ends in C atomic adds, and
+    // the total sums' addresses are shared by ALL workgroups)
+    const size_t min_wgs = f_wgs > 0 ? (size_t)f_wgs : 256;
     int rpw = STAT_SLOT;
-    while (rpw < 1024 && (size_t)B * ((T + 2 * rpw - 1) / (2 * rpw)) >= 512) rpw <<= 1;
-    return forced > 0 ? forced : rpw;
+    while (rpw < 4096 && (size_t)B * ((T + 2 * rpw - 1) / (2 * rpw)) >= min_wgs) rpw <<= 1;
+    t.rows = f_rows > 0 ? f_rows : rpw;
+    return t;
 }
 
 extern "C" int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride, float* out_c, float* out_c2,
                          const float* bscale, uint32_t* amax_out, hipStream_t stream) {
     if (!dy || (!out_bc && !out_c && !out_c2 && !amax_out)) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || C < 4 || C % 4 || C > 1024) return TQ_ERR_SHAPE;
-    const int rpw = colsum_rows(B, T);
-    const int nsl = (T + rpw - 1) / rpw;
+    const CsTiling tl = colsum_tiling(B, T);
+    const int nsl = (T + tl.rows - 1) / tl.rows;
     const int c4n = C / 4;
-    const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
-    const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float);
-    hipLaunchKernelGGL(colsum_kernel, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, out_c2, bscale, amax_out, rpw);
+    const int nrow = tl.nt / c4n > 0 ? tl.nt / c4n : 1;
+    const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float) + (tl.nt / 64) * sizeof(unsigned);
+    if (tl.nt == 1024)
+        hipLaunchKernelGGL(colsum_kernel<1024>, dim3(B * nsl), dim3(1024), sh, stream, dy, T, C, out_bc, bc_stride, out_c, out_c2, bscale, amax_out, tl.rows);
+    else
+        hipLaunchKernelGGL(colsum_kernel<256>, dim3(B * nsl), dim3(256), sh, stream, dy, T, C, out_bc, bc_stride, out_c, out_c2, bscale, amax_out, tl.rows);
     TQ_CHECK_LAUNCH();
     return 0;
 }
@@ -849,13 +879,17 @@ extern "C" int tq_gn_bwd_apply_colsum(const float* g, const float* x, const floa
     if (B <= 0 || T <= 0 || C_src <= 0 || C_src % 4 || C_src > 1024 || c_offset % 4 || c_offset + C_src > C_total) return TQ_ERR_SHAPE;
     if (!colsum_bc && !colsum_c && !amax_out)
         return tq_gn_bwd_apply(g, x, r, coef_a, coef_b, coef_c, dx, B, T, C_src, C_total, c_offset, accumulate, stream);
-    const int rpw = colsum_rows(B, T);
-    const int nsl = (T + rpw - 1) / rpw;
+    const CsTiling tl = colsum_tiling(B, T);
+    const int nsl = (T + tl.rows - 1) / tl.rows;
     const int c4n = C_src / 4;
-    const int nrow = 256 / c4n > 0 ? 256 / c4n : 1;
-    const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float);
-    hipLaunchKernelGGL(gn_bwd_apply_cs_kernel, dim3(B * nsl), dim3(256), sh, stream, g, x, r, coef_a, coef_b, coef_c, dx, T, C_src, C_total,
-                       c_offset, accumulate, colsum_bc, bc_stride, colsum_c, colsum_c2, amax_out, rpw);
+    const int nrow = tl.nt / c4n > 0 ? tl.nt / c4n : 1;
+    const size_t sh = (size_t)nrow * c4n * 4 * sizeof(float) + (tl.nt / 64) * sizeof(unsigned);
+    if (tl.nt == 1024)
+        hipLaunchKernelGGL(gn_bwd_apply_cs_kernel<1024>, dim3(B * nsl), dim3(1024), sh, stream, g, x, r, coef_a, coef_b, coef_c, dx, T, C_src,
+                           C_total, c_offset, accumulate, colsum_bc, bc_stride, colsum_c, colsum_c2, amax_out, tl.rows);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_cs_kernel<256>, dim3(B * nsl), dim3(256), sh, stream, g, x, r, coef_a, coef_b, coef_c, dx, T, C_src,
+                           C_total, c_offset, accumulate, colsum_bc, bc_stride, colsum_c, colsum_c2, amax_out, tl.rows);
     TQ_CHECK_LAUNCH();
     return 0;
 }

@@ -171,7 +171,10 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
     float dy_scale = 1.f, dy_unscale = 1.f;
     if constexpr (EPI == 1 && SCH == 2) {
         if (p.in_amax) {
-            const int e = (int)((*p.in_amax >> 23) & 0xFFu);     // biased exponent of max|dy| (0: zero / denormal, 255: inf / NaN)
+            uint32_t amx = 0u;   // the maximum arrives spread over TQ_AMAX_WAYS words, one per 128-byte line (see tq_colsum)
+#pragma unroll
+            for (int w = 0; w < TQ_AMAX_WAYS; ++w) amx = max(amx, p.in_amax[w * TQ_AMAX_STRIDE]);
+            const int e = (int)((amx >> 23) & 0xFFu);            // biased exponent of max|dy| (0: zero / denormal, 255: inf / NaN)
             int k = 140 - e;                                      // 2^13 <= max|dy| * 2^k < 2^14
             k = k > 126 ? 126 : (k < -126 ? -126 : k);
             dy_scale = __uint_as_float((unsigned)(127 + k) << 23);

@@ -21,7 +21,7 @@ from typing import Dict, List
 
 import torch
 
-from ._lib import (PACK_MODE_T, TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_STATS, TQ_WFMT_BF16X3, TQ_WFMT_F16_MX6, STAT_SLOT,
+from ._lib import (PACK_MODE_T, TQ_AMAX_WORDS, TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_STATS, TQ_WFMT_BF16X3, TQ_WFMT_F16_MX6, STAT_SLOT,
                    TqConvBwdDesc, check)
 
 
@@ -45,7 +45,7 @@ BWD_STREAMS = int(__import__("os").environ.get("TQDNE_BWD_STREAMS", "2"))
 # TQDNE_DGRAD_SCHEME=bf16x3 keeps round 3's three-product scheme everywhere.
 FUSE_APPLY_COLSUM = __import__("os").environ.get("TQDNE_FUSE_APPLY_COLSUM", "1") != "0"
 DGRAD_SCHEME = __import__("os").environ.get("TQDNE_DGRAD_SCHEME", "f16mx6").lower()
-N_AMAX = 256   # slots for max|dy| (one per gradient tensor that feeds a data gradient), kept in the tail of the flat buffer
+N_AMAX = 160   # blocks for max|dy| (one per gradient tensor that feeds a data gradient), kept in the tail of the flat buffer
 
 
 def _nslots(T):
@@ -153,9 +153,9 @@ class BackwardPlan:
         total += self.B * e.emb_total
         total = (total + 63) // 64 * 64
         off_amax = total
-        total += N_AMAX            # (zeroed with the buffer at the start of every sweep)
+        total += N_AMAX * TQ_AMAX_WORDS   # (zeroed with the buffer at the start of every sweep)
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
-        self.amax = self.flat[off_amax:off_amax + N_AMAX].view(torch.int32)   # bit patterns of max|dy|, written by atomic max
+        self.amax = self.flat[off_amax:off_amax + N_AMAX * TQ_AMAX_WORDS].view(torch.int32)   # bit patterns of max|dy|, written by atomic max
         self._amax_slot = {}       # data_ptr of a gradient tensor -> index of its slot
         self._mx6_dgrads = []      # (descriptor, site) of the data gradients planned in the fp16 + MX-fp6 scheme
         self.gview = {id(p): self.flat[offs[id(p)]:offs[id(p)] + p.numel()].view_as(p) for p in swept + emb_w + emb_b + tail}
@@ -207,7 +207,7 @@ class BackwardPlan:
             if not create or len(self._amax_slot) >= N_AMAX:
                 return None
             i = self._amax_slot[dy_ptr] = len(self._amax_slot)
-        return self.amax.data_ptr() + 4 * i
+        return self.amax.data_ptr() + 4 * TQ_AMAX_WORDS * i
 
     def g(self, param):
         """the gradient view of ``param``; called while an op is being assembled, so it also records that op (the next one

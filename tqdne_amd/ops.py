@@ -243,7 +243,7 @@ def gn_bwd_apply(g, x, coefs, c_total, c_offset=0, r=None, accumulate_into=None)
 
 
 def colsum(dy, per_sample=True, total=True, bscale=None, amax=None):
-    """``amax``: optional zeroed int32[1] device tensor that receives the bit pattern of max|dy| (atomic max)"""
+    """``amax``: optional zeroed int32[TQ_AMAX_WORDS] device block that receives the bit pattern of max|dy| (see amax_bits)"""
     lib = _lib.load()
     B, T, Cn = dy.shape
     obc = torch.zeros(B, Cn, device=dy.device) if per_sample else None
@@ -253,12 +253,18 @@ def colsum(dy, per_sample=True, total=True, bscale=None, amax=None):
 
 
 def amax_bits(dy):
-    """int32[1] device tensor with the IEEE bit pattern of max|dy| (what TqConvBwdDesc.dy_amax points at), from tq_colsum"""
+    """int32[TQ_AMAX_WORDS] device block whose maximum is the IEEE bit pattern of max|dy| (what TqConvBwdDesc.dy_amax points at), from
+    tq_colsum; ``amax_value`` decodes it"""
     lib = _lib.load()
     B, T, Cn = dy.shape
-    out = torch.zeros(1, dtype=torch.int32, device=dy.device)
+    out = torch.zeros(_lib.TQ_AMAX_WORDS, dtype=torch.int32, device=dy.device)
     check(lib.tq_colsum(_p(dy), B, T, Cn, None, 0, None, None, None, _p(out), _stream(dy.device)), "colsum (amax)")
     return out
+
+
+def amax_value(block) -> float:
+    """max|.| recorded in a TQ_AMAX_WORDS block (host float; synchronises)"""
+    return float(block.max().view(torch.float32).item()) if block.numel() > 1 else float(block.view(torch.float32).item())
 
 
 def gn_bwd_apply_colsum(g, x, coefs, c_total, c_offset=0, r=None, accumulate_into=None, per_sample=True, total=True, amax=None):
