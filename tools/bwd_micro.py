@@ -57,7 +57,14 @@ for (ci, co, k, T) in [] if ONLY not in ("", "wgrad") else [(256, 256, 5, 1024),
     x = torch.randn(B, T, ci, device=dev)
     dy = torch.randn(B, T, co, device=dev)
     gs, gh = torch.rand(B, ci, device=dev) + 0.5, torch.randn(B, ci, device=dev)
-    print(f"{ci:4d} -> {co:4d} k{k} T{T:5d}: {med(lambda: ops.conv1d_bwd_weight(dy, x, (co, ci, k), gscale=gs, gshift=gh, silu=True)):7.1f}  (incl. the wrapper's allocations)")
+    d = _lib.TqConvDesc()
+    d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T, T, ci, 0, co
+    d.ktaps, d.stride, d.pad, d.upsample, d.flags = k, 1, k // 2, 0, 3
+    ws = torch.empty(lib.tq_conv1d_bwd_weight_workspace(C.byref(d)), dtype=torch.uint8, device=dev)
+    dw = torch.empty(co, ci, k, device=dev)
+    def run():
+        assert lib.tq_conv1d_bwd_weight(C.byref(d), p(dy), p(x), None, p(gs), p(gh), p(dw), p(ws), ws.numel(), stream()) == 0
+    print(f"{ci:4d} -> {co:4d} k{k} T{T:5d}: {med(run):7.1f}")
 
 print("## GroupNorm backward apply (+ column sums): C, T: apply | colsum | apply + colsum | fused")
 for (Cc, T) in [] if ONLY not in ("", "gn") else [(64, 4096), (128, 2048), (256, 1024), (256, 512), (512, 1024)]:

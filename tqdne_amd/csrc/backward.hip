@@ -63,18 +63,30 @@ constexpr int WG_DY_STRIDE1 = 288;  // bytes per dy image row, 32-channel chunks
 constexpr int WG_DY_STRIDE2 = 272;  // 64-channel chunks (k = 1 only): the plain image -- 288-byte rows would cost the third resident workgroup
 template <int NCI> __device__ __forceinline__ int wg_dy_swz(int row) { return NCI == 1 ? ((row >> 3) & 1) << 7 : 0; }   // slot ^ 16
 __device__ __forceinline__ int wg_x_swz(int row) { return ((row >> 3) & 1) << 5; }    // byte offset XOR: slot ^ 4 (64-byte rows)
+// 128-byte xhat rows (W8): a 32-lane read touches rows {r .. r+3} and {r+8 .. r+11}, 4 slots of 8 bytes each; rows of equal parity
+// share their 32 banks, so the slot is XOR-ed with 4 * bit 1 and 8 * bit 3 of the row: r, r+2, r+8, r+10 land in four disjoint
+// slot groups
+__device__ __forceinline__ int wg_x_swz128(int row) { return (((row >> 1) & 1) << 5) | (((row >> 3) & 1) << 6); }
 
 // NCI: input-channel chunk of a workgroup in units of 32.  The dy tile (128 co) is staged, split and read once per workgroup and
 // unit whatever the chunk width, so the 64-channel chunk (NCI = 2) halves the number of times dy is re-read from L2 / HBM and
 // re-split (measured traffic-bound with 32: every conv's dy was read C_in / 32 times); 160 accumulator registers at k = 5.
-template <int KT, int STRIDE, int UPS, int NCI>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
+// W8 (round 4): EIGHT waves per workgroup, one workgroup per CU: waves 0-3 and 4-7 share the staged dy tile and take the two 32-channel
+// halves of a 64-channel xhat tile (accumulators as NCI = 1: 80 registers at k = 5, where the 64-channel chunk in ONE wave -- NCI = 2,
+// 160 registers -- spilled).  Every dy element is then fetched from L2, split and stored to LDS C_in / 64 instead of C_in / 32 times:
+// the kernel was moving ~6 TB/s from L2 at 38 % MFMA-busy (667 MB per 256 -> 256, k = 5 launch).
+template <int KT, int STRIDE, int UPS, int NCI, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const WgArgs p) {
+    static_assert(!W8 || NCI == 1, "W8: per-wave accumulators of a 32-channel chunk");
+    constexpr int NT = W8 ? 512 : 256;
+    constexpr int NCX = W8 ? 2 : NCI;        // width of the staged xhat tile in 32-channel units
     constexpr int PAD = (STRIDE == 1) ? KT / 2 : 1;
     constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
-    constexpr int WG_X_STRIDE = 64 * NCI;    // bytes per xhat image row (32 NCI ci * 2 B)
-    constexpr int XC4 = 8 * NCI;             // float4 columns of the xhat tile
-    constexpr int XIT = (XR * XC4 + 255) / 256;
-    constexpr int WG_DY_STRIDE = NCI == 1 ? WG_DY_STRIDE1 : WG_DY_STRIDE2;
+    constexpr int WG_X_STRIDE = 64 * NCX;    // bytes per xhat image row (32 NCX ci * 2 B)
+    constexpr int XC4 = 8 * NCX;             // float4 columns of the xhat tile
+    constexpr int XIT = (XR * XC4 + NT - 1) / NT;
+    constexpr int DYIT = 2048 / NT;          // float4 of the 64 x 128 dy tile per thread
+    constexpr int WG_DY_STRIDE = (NCI == 1) ? WG_DY_STRIDE1 : WG_DY_STRIDE2;
     constexpr int DY_PLANE = WG_TT * WG_DY_STRIDE;
     constexpr int X_PLANE = XR * WG_X_STRIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -84,7 +96,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
     unsigned char* x_lo = x_hi + X_PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = W8 ? (wave_id & 3) : wave_id;   // 32-channel block of the 128 output channels
+    const int wci = W8 ? (wave_id >> 2) : 0;         // W8: which 32-channel half of the xhat tile
     // Workgroups are dealt round-robin over the 8 XCDs (ids i and i + 8 share an L2).  The input-channel-chunk workgroups of one
     // (split, co-tile) pair all stage the same dy tile: keep a pair on ONE XCD, so its L2 serves the re-reads (with the plain
     // order every XCD fetched every dy tile: 404 MB from HBM for 134 MB of operands, 57 % L2 misses).
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         }
     }
     const int co0 = ct * 128;
-    const int cb = cc * 32 * NCI;
+    const int cb = cc * 32 * NCX;
     const int Cin = p.C0 + p.C1;
     const int T_src = UPS ? 2 * p.T_in : p.T_in;
     const int U = p.B * p.n_ttiles;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
     if (cb < p.C0) { xsrc = p.x0; xcs = p.C0; xoff = cb; } else { xsrc = p.x1; xcs = p.C1; xoff = cb - p.C0; }
     const int m = tid & (XC4 - 1);  // float4 column of the xhat tile owned by this thread
 
-    float4 dyr[8];
+    float4 dyr[DYIT];
     float4 xr[XIT];
     float4 g_a = make_float4(1.f, 1.f, 1.f, 1.f), g_s = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -138,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         if (u == u_begin)   // ablation (wrong numerics): the dy tile is loaded, split and stored for the first unit only
 #endif
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int task = tid + it * 256;
+        for (int it = 0; it < DYIT; ++it) {
+            const int task = tid + it * NT;
             const int row = task >> 5, c4 = task & 31;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t0 + row < p.T_out && c4 < cvalid4) v = *reinterpret_cast<const float4*>(dyb + (size_t)(t0 + row) * p.C_out + 4 * c4);
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         const float* xb = xsrc + (size_t)b * p.T_in * xcs + xoff + 4 * m;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            const int i = (tid + it * 256) / XC4;
+            const int i = (tid + it * NT) / XC4;
             const int pos = xpos(t0, i);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < XR && pos >= 0 && pos < T_src) v = *reinterpret_cast<const float4*>(xb + (size_t)(UPS ? (pos >> 1) : pos) * xcs);
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
     const bool do_cs = (cc == 0) && (p.cs_bc || p.cs_c);
     float* cs_lds = reinterpret_cast<float*>(x_lo + X_PLANE);   // [128]
     int cs_b = -1;
-    if (do_cs && tid < 128) cs_lds[tid] = 0.f;
+    if (do_cs && tid < 128) cs_lds[tid] = 0.f;   // (W8 launches never carry fused column sums: the host refuses the combination)
     auto cs_flush = [&]() __attribute__((always_inline)) {
         if (tid < 128) {
             const int c = co0 + tid;
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
             }
             float4 a4 = dyr[0];
 #pragma unroll
-            for (int it = 1; it < 8; ++it) { a4.x += dyr[it].x; a4.y += dyr[it].y; a4.z += dyr[it].z; a4.w += dyr[it].w; }
+            for (int it = 1; it < DYIT; ++it) { a4.x += dyr[it].x; a4.y += dyr[it].y; a4.z += dyr[it].z; a4.w += dyr[it].w; }
             float* dst = cs_lds + 4 * (tid & 31);
             atomicAdd(dst, a4.x); atomicAdd(dst + 1, a4.y); atomicAdd(dst + 2, a4.z); atomicAdd(dst + 3, a4.w);
         }
@@ -199,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         if (u == u_begin)
 #endif
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int task = tid + it * 256;
+        for (int it = 0; it < DYIT; ++it) {
+            const int task = tid + it * NT;
             const int row = task >> 5, c4 = task & 31;
             const float v[4] = {dyr[it].x, dyr[it].y, dyr[it].z, dyr[it].w};
             bf16x4 h, l;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            const int i = (tid + it * 256) / XC4;
+            const int i = (tid + it * NT) / XC4;
             if (i >= XR) continue;
             const int pos = xpos(t0, i);
             float v[4] = {xr[it].x, xr[it].y, xr[it].z, xr[it].w};
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
             bf16x4 h, l;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { __bf16 hh, ll; split_bf16(v[j], hh, ll); h[j] = hh; l[j] = ll; }
-            const int off = i * WG_X_STRIDE + (NCI == 1 ? ((m * 8) ^ wg_x_swz(i)) : m * 8);
+            const int off = i * WG_X_STRIDE + (W8 ? ((m * 8) ^ wg_x_swz128(i)) : (NCI == 1 ? ((m * 8) ^ wg_x_swz(i)) : m * 8));
             *reinterpret_cast<bf16x4*>(x_hi + off) = h;
             *reinterpret_cast<bf16x4*>(x_lo + off) = l;
         }
@@ -252,29 +266,95 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
 
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 
+    // xhat image offset of (row, 16-channel block nb, this lane's 8-byte slot)
+    auto x_off = [&](int xrow, int nb) -> int __attribute__((always_inline)) {
+        const int colx = ((wci * 2 + nb) * 16 + 4 * pp) * 2;
+        return xrow * WG_X_STRIDE + (W8 ? (colx ^ wg_x_swz128(xrow)) : (NCI == 1 ? (colx ^ wg_x_swz(xrow)) : colx));
+    };
+    auto a_frags = [&](int r0, Frag (&ah)[2], Frag (&al)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int col = (wave * 32 + mb * 16 + 4 * pp) * 2;
+            const int off = r0 * WG_DY_STRIDE + (col ^ wg_dy_swz<NCI>(r0));
+            const int off4 = off + 4 * WG_DY_STRIDE;   // (rows r0 and r0 + 4 share bit 3: r0 = 32 ks + 8 g + q, q < 4)
+            ah[mb].h[0] = lds_tr_read(dy_hi + off);
+            ah[mb].h[1] = lds_tr_read(dy_hi + off4);
+            al[mb].h[0] = lds_tr_read(dy_lo + off);
+            al[mb].h[1] = lds_tr_read(dy_lo + off4);
+        }
+    };
+#if !defined(TQ_WG_OLD_COMPUTE)
+    // Round 4.  The compute phase ran at 2.2x its MFMA time with staging and loads ablated (tools/bwd_micro.py, -DTQ_WG_ABL_*): per
+    // (tap, channel block) step hipcc issued the four transposed reads of the xhat fragment right in front of the six MFMAs that
+    // consume them -- an LDS round trip exposed twenty times per unit.  For the stride-1 convs the taps are row shifts of ONE image, so
+    // a lane's fragments for all KT taps are 8-element windows of the 8 + KT - 1 consecutive rows it can fetch with THREE transposed
+    // reads per plane (rows 8g .. 8g + 11): even shifts are register renames, odd ones five v_alignbit per plane.  LDS reads per wave
+    // and unit 96 -> 40, issued one (32-row step, channel block) group ahead of the 6 KT MFMAs that use them.
+    struct XWin { uint2 h[3], l[3]; };
+    auto x_window = [&](int r0, int nb, XWin& w) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int off = x_off(r0 + 4 * j, nb);
+            w.h[j] = lds_tr_read(x_hi + off);
+            w.l[j] = lds_tr_read(x_lo + off);
+        }
+    };
+    auto tap_frag = [&](const uint2 (&r)[3], const uint32_t (&al5)[5], int k, Frag& f) __attribute__((always_inline)) {
+        const uint32_t d[6] = {r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y};
+        if ((k & 1) == 0) f.u = make_uint4(d[k / 2], d[k / 2 + 1], d[k / 2 + 2], d[k / 2 + 3]);
+        else f.u = make_uint4(al5[k / 2], al5[k / 2 + 1], al5[k / 2 + 2], al5[k / 2 + 3]);
+    };
     auto compute = [&]() __attribute__((always_inline)) {
+        if constexpr (STRIDE == 1 && KT > 1) {
+            constexpr int NB = 2 * NCI, NG = (WG_TT / 32) * NB;   // groups = (32-row step, channel block)
+            XWin win[2];
+            Frag ah[2], al[2];
+            x_window(8 * g + q, 0, win[0]);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const int ks = gi / NB, nb = gi % NB;
+                const int r0 = ks * 32 + 8 * g + q;
+                if (nb == 0) a_frags(r0, ah, al);
+                if (gi + 1 < NG) x_window(((gi + 1) / NB) * 32 + 8 * g + q, (gi + 1) % NB, win[(gi + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const XWin& w = win[gi & 1];
+                const uint32_t dh[6] = {w.h[0].x, w.h[0].y, w.h[1].x, w.h[1].y, w.h[2].x, w.h[2].y};
+                const uint32_t dl[6] = {w.l[0].x, w.l[0].y, w.l[1].x, w.l[1].y, w.l[2].x, w.l[2].y};
+                uint32_t oh[5], ol[5];   // odd shifts: elements (2j + 1, 2j + 2)
+#pragma unroll
+                for (int j = 0; j < (KT == 5 ? 5 : 4); ++j) {
+                    oh[j] = __builtin_amdgcn_alignbit(dh[j + 1], dh[j], 16);
+                    ol[j] = __builtin_amdgcn_alignbit(dl[j + 1], dl[j], 16);
+                }
+                if (KT != 5) { oh[4] = 0; ol[4] = 0; }
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    Frag bh, bl;
+                    tap_frag(w.h, oh, k, bh);
+                    tap_frag(w.l, ol, k, bl);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+                        acc[mb][nb][k] = mfma_x3(ah[mb].v, al[mb].v, bh.v, bl.v, acc[mb][nb][k]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+#else
+    auto compute = [&]() __attribute__((always_inline)) {
+#endif
 #pragma unroll (NCI == 2 && KT == 5 ? 1 : 2)
         for (int ks = 0; ks < WG_TT / 32; ++ks) {
             const int r0 = ks * 32 + 8 * g + q;  // reduction row supplied by this lane (first read; +4 second)
             Frag ah[2], al[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int col = (wave * 32 + mb * 16 + 4 * pp) * 2;
-                const int off = r0 * WG_DY_STRIDE + (col ^ wg_dy_swz<NCI>(r0));
-                const int off4 = off + 4 * WG_DY_STRIDE;   // (rows r0 and r0 + 4 share bit 3: r0 = 32 ks + 8 g + q, q < 4)
-                ah[mb].h[0] = lds_tr_read(dy_hi + off);
-                ah[mb].h[1] = lds_tr_read(dy_hi + off4);
-                al[mb].h[0] = lds_tr_read(dy_lo + off);
-                al[mb].h[1] = lds_tr_read(dy_lo + off4);
-            }
+            a_frags(r0, ah, al);
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const int xrow = (STRIDE == 1) ? (r0 + k) : ((k & 1) * (WG_TT + 1) + r0 + (k >> 1));
 #pragma unroll
                 for (int nb = 0; nb < 2 * NCI; ++nb) {
-                    const int colx = (nb * 16 + 4 * pp) * 2;
-                    const int off = xrow * WG_X_STRIDE + (NCI == 1 ? (colx ^ wg_x_swz(xrow)) : colx);
-                    const int off4 = NCI == 1 ? (xrow + 4) * WG_X_STRIDE + (colx ^ wg_x_swz(xrow + 4)) : off + 4 * WG_X_STRIDE;
+                    const int off = x_off(xrow, nb);
+                    const int off4 = x_off(xrow + 4, nb);
                     Frag bh, bl;
                     bh.h[0] = lds_tr_read(x_hi + off);
                     bh.h[1] = lds_tr_read(x_hi + off4);
@@ -293,13 +373,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
     // leaves the latency to the co-resident workgroup.
     constexpr bool PREFETCH = !(NCI == 2 && KT == 5);
     if (PREFETCH && u_begin < u_end) load_unit(u_begin);
+    // (-DTQ_WG_ABL_*: timing ablations, wrong numerics, never in the shipped library: NOMMA = no MFMA phase, NOSTAGE = units after the
+    // first neither converted nor stored, NOLOAD = units after the first not loaded)
     for (int u = u_begin; u < u_end; ++u) {
+#ifdef TQ_WG_ABL_NOLOAD
+        if (!PREFETCH && u == u_begin) load_unit(u);
+#else
         if (!PREFETCH) load_unit(u);
+#endif
         __syncthreads();
+#ifdef TQ_WG_ABL_NOSTAGE
+        if (u == u_begin)
+#endif
         write_unit(u);
         __syncthreads();
+#ifndef TQ_WG_ABL_NOLOAD
         if (PREFETCH && u + 1 < u_end) load_unit(u + 1);
+#endif
+#ifndef TQ_WG_ABL_NOMMA
         if (wave_active) compute();
+#endif
     }
 
     if (do_cs) {
@@ -317,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + wave * 32 + mb * 16 + 4 * (lane >> 4) + r;
-                    const int ci = cb + nb * 16 + (lane & 15);
+                    const int ci = cb + (wci * 2 + nb) * 16 + (lane & 15);
                     p.slab[(((size_t)sp * KT + k) * p.C_out + co) * Cin + ci] = acc[mb][nb][k][r];
                 }
 }
@@ -386,47 +479,65 @@ int wgrad_nci(const TqConvDesc* d) {
     return (d->C_in0 % 64 == 0 && d->C_in1 % 64 == 0) ? 2 : 1;
 }
 
+// The 8-wave form (W8, see wgrad_kernel) serves the k = 3 / k = 5 launches whose sources are made of whole 64-channel chunks and whose
+// output channels fill the 128-channel tile; TQDNE_WGRAD_W8=0 keeps round 3's 4-wave kernel everywhere.
+bool wgrad_w8(const TqConvDesc* d) {
+    static const int sw = [] { const char* e = getenv("TQDNE_WGRAD_W8"); return e ? atoi(e) : 1; }();
+    if (!sw || d->ktaps == 1) return false;
+    return d->C_in0 % 64 == 0 && d->C_in1 % 64 == 0 && d->C_out % 128 == 0;
+}
+
 // Workgroups of the weight-gradient kernel the device holds at once (occupancy of the instantiation x compute units), per
 // (taps, stride, upsample, chunk width); queried once.  The (b, t) reduction is split over as many workgroups as fill ONE
 // residency round: with the former fixed target of 768 the paper UNet's launches were 1.46 rounds of 512 resident workgroups
 // (256 -> 256, k = 5: 752), i.e. the second round ran on half the chip (rocprofv3: 1.28 waves per SIMD on average).
-template <int KT, int STRIDE, int UPS, int NCI>
+template <int KT, int STRIDE, int UPS>
+size_t wgrad_lds(int nci, bool w8) {
+    constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
+    const int ncx = w8 ? 2 : nci;
+    return 2 * WG_TT * (nci == 1 ? WG_DY_STRIDE1 : WG_DY_STRIDE2) + 2 * XR * 64 * ncx + 128 * sizeof(float);   // (+ the fused column sums)
+}
+
+template <int KT, int STRIDE, int UPS, int NCI, bool W8>
 int wgrad_slots_of() {
     static const int slots = [] {
-        constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
-        const size_t sh = 2 * WG_TT * (NCI == 1 ? WG_DY_STRIDE1 : WG_DY_STRIDE2) + 2 * XR * 64 * NCI + 128 * sizeof(float);
+        const size_t sh = wgrad_lds<KT, STRIDE, UPS>(NCI, W8);
         int per_cu = 0, dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_kernel<KT, STRIDE, UPS, NCI>, 256, sh) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_kernel<KT, STRIDE, UPS, NCI, W8>, W8 ? 512 : 256, sh) != hipSuccess ||
             per_cu < 1 || cus < 1) {
             (void)hipGetLastError();
-            return 512;   // (no device: 2 workgroups x 256 compute units, what __launch_bounds__(256, 2) asks for on MI355X)
+            return W8 ? 256 : 512;   // (no device: what __launch_bounds__ asks for on MI355X's 256 compute units)
         }
         return per_cu * cus;
     }();
     return slots;
 }
 
-int wgrad_slots(const TqConvDesc* d, int nci) {
-    if (d->stride == 2) return nci == 2 ? wgrad_slots_of<3, 2, 0, 2>() : wgrad_slots_of<3, 2, 0, 1>();
-    if (d->upsample) {
-        if (d->ktaps == 5) return nci == 2 ? wgrad_slots_of<5, 1, 1, 2>() : wgrad_slots_of<5, 1, 1, 1>();
-        return nci == 2 ? wgrad_slots_of<3, 1, 1, 2>() : wgrad_slots_of<3, 1, 1, 1>();
-    }
-    if (d->ktaps == 5) return nci == 2 ? wgrad_slots_of<5, 1, 0, 2>() : wgrad_slots_of<5, 1, 0, 1>();
-    if (d->ktaps == 3) return nci == 2 ? wgrad_slots_of<3, 1, 0, 2>() : wgrad_slots_of<3, 1, 0, 1>();
-    return nci == 2 ? wgrad_slots_of<1, 1, 0, 2>() : wgrad_slots_of<1, 1, 0, 1>();
+template <int KT, int STRIDE, int UPS>
+int wgrad_slots_k(int nci, bool w8) {
+    if (w8) return wgrad_slots_of<KT, STRIDE, UPS, 1, true>();
+    return nci == 2 ? wgrad_slots_of<KT, STRIDE, UPS, 2, false>() : wgrad_slots_of<KT, STRIDE, UPS, 1, false>();
+}
+
+int wgrad_slots(const TqConvDesc* d, int nci, bool w8) {
+    if (d->stride == 2) return wgrad_slots_k<3, 2, 0>(nci, w8);
+    if (d->upsample) return d->ktaps == 5 ? wgrad_slots_k<5, 1, 1>(nci, w8) : wgrad_slots_k<3, 1, 1>(nci, w8);
+    if (d->ktaps == 5) return wgrad_slots_k<5, 1, 0>(nci, w8);
+    if (d->ktaps == 3) return wgrad_slots_k<3, 1, 0>(nci, w8);
+    return wgrad_slots_k<1, 1, 0>(nci, false);
 }
 
 void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_ttiles, int& nsplit, int& ups) {
     const int nci = wgrad_nci(d);
+    const bool w8 = wgrad_w8(d);
     n_cotiles = (d->C_out + 127) / 128;
-    n_cichunks = (d->C_in0 + d->C_in1) / (32 * nci);
+    n_cichunks = (d->C_in0 + d->C_in1) / (32 * (w8 ? 2 : nci));
     n_ttiles = (d->T_out + WG_TT - 1) / WG_TT;
     const int U = d->B * n_ttiles;
     const int ntiles = n_cotiles * n_cichunks;
     static const int forced = [] { const char* e = getenv("TQDNE_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();   // (A/B switch)
-    const int slots = forced > 0 ? forced : wgrad_slots(d, nci);
+    const int slots = forced > 0 ? forced : wgrad_slots(d, nci, w8);
     int want = slots / ntiles;   // splits per output tile: the grid fills one round of resident workgroups, not more
     if (want < 1) want = 1;
     if (want > U) want = U;
@@ -435,14 +546,20 @@ void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_tti
 }
 
 template <int KT, int STRIDE, int UPS>
-int launch_wgrad(const WgArgs& a, int nci, hipStream_t stream) {
-    constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
-    const size_t sh = 2 * WG_TT * (nci == 1 ? WG_DY_STRIDE1 : WG_DY_STRIDE2) + 2 * XR * 64 * nci + 128 * sizeof(float);   // (+ the fused column sums)
+int launch_wgrad(const WgArgs& a, int nci, bool w8, hipStream_t stream) {
+    const size_t sh = wgrad_lds<KT, STRIDE, UPS>(nci, w8);
     const unsigned grid = (unsigned)(a.n_cotiles * a.n_cichunks * a.nsplit);
-    if (nci == 2) {
-        hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 2>), dim3(grid), dim3(256), sh, stream, a);
+    if (w8) {
+        static const bool raised = [] {   // (the 8-wave form's LDS images exceed the 64 KB default of a dynamic allocation)
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<KT, STRIDE, UPS, 1, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        }();
+        (void)raised;
+        hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 1, true>), dim3(grid), dim3(512), sh, stream, a);
+    } else if (nci == 2) {
+        hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 2, false>), dim3(grid), dim3(256), sh, stream, a);
     } else {
-        hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 1>), dim3(grid), dim3(256), sh, stream, a);
+        hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 1, false>), dim3(grid), dim3(256), sh, stream, a);
     }
     TQ_CHECK_LAUNCH();
     return 0;
@@ -487,17 +604,19 @@ extern "C" int tq_conv1d_bwd_weight_colsum(const TqConvDesc* d, const float* dy,
     a.drop_scale = 1.0f / (1.0f - pdrop);
     int rc;
     const int nci = wgrad_nci(d);
+    bool w8 = wgrad_w8(d);
+    if (w8 && (colsum_bc || colsum_c)) w8 = false;   // (the fused column sums live in the 4-wave kernel's epilogue; never both)
     if (d->stride == 2) {
         if (d->ktaps != 3) return TQ_ERR_SHAPE;
-        rc = launch_wgrad<3, 2, 0>(a, nci, stream);
+        rc = launch_wgrad<3, 2, 0>(a, nci, w8, stream);
     } else if (d->upsample) {
-        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 1>(a, nci, stream);
-        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 1>(a, nci, stream);
+        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 1>(a, nci, w8, stream);
+        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 1>(a, nci, w8, stream);
         else return TQ_ERR_SHAPE;
     } else {
-        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 0>(a, nci, stream);
-        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 0>(a, nci, stream);
-        else if (d->ktaps == 1) rc = launch_wgrad<1, 1, 0>(a, nci, stream);
+        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 0>(a, nci, w8, stream);
+        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 0>(a, nci, w8, stream);
+        else if (d->ktaps == 1) rc = launch_wgrad<1, 1, 0>(a, nci, false, stream);
         else return TQ_ERR_SHAPE;
     }
     if (rc) return rc;
