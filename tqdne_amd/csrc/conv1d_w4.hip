@@ -65,11 +65,22 @@ struct W4 {
 
 __device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
+#ifdef TQ_W4_STAMP
+// diagnostic build only: per-workgroup clock stamps around the whole kernel body -- [0] / [1] s_memtime (shader
+// clock) at entry / exit, [2] / [3] s_memrealtime (100 MHz) at entry / exit; in-kernel clock = d[0,1] / d[2,3] * 100 MHz
+static __device__ unsigned long long tq_w4_stamps[4096 * 4];
+#define TQ_W4_T(i, j) if (threadIdx.x == 0 && blockIdx.x < 4096) { tq_w4_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); \
+                                                                    tq_w4_stamps[blockIdx.x * 4 + (j)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define TQ_W4_T(i, j)
+#endif
+
 // ACT: 0 none, 1 folded GroupNorm, 2 GroupNorm + SiLU.   FUSE: the ResBlock's 1x1 skip conv rides as extra single-tap chunks.
 template <int KT, int WM, int WN, int ACT, bool FUSE>
 __global__ __launch_bounds__(256, 1) void conv1d_w4_kernel(const ConvArgs p) {
     using C = W4<KT, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    TQ_W4_T(0, 2)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -467,6 +478,7 @@ __global__ __launch_bounds__(256, 1) void conv1d_w4_kernel(const ConvArgs p) {
             }
         }
     }
+    TQ_W4_T(1, 3)
 }
 
 template <int KT, int WM, int WN, int ACT, bool FUSE>
@@ -499,6 +511,12 @@ int pick_tile(const ConvArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef TQ_W4_STAMP
+extern "C" int tq_debug_read_w4_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tq_w4_stamps), sizeof(unsigned long long) * 4 * (n < 4096 ? n : 4096));
+}
+#endif
 
 namespace tq {
 int conv1d_w4_launch(const ConvArgs& a, int ktaps, hipStream_t stream) {
