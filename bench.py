@@ -672,7 +672,10 @@ def main():
     log(f"timed region done: {ms_per_step:.1f} ms/step")
     value = world * B / (dt / args.steps)
 
-    # separate timings of the two halves (reported, not the headline): median of 5 after one untimed call
+    # separate timings of the two halves (reported, not the headline).  `<half>_ms`: 5 calls back to back between two synchronisations,
+    # divided by 5 -- the half's throughput time, the way it runs inside the timed steps (no host synchronisation between launches);
+    # `<half>_ms_synced`: median of 5 calls each followed by a synchronisation (rounds 1-3's definition: includes the host's launch
+    # latency at the start and the drain at the end of every call, ~2 ms for the ~600 launches of a training step)
     parts = {}
     for name, fn in (("train", train_half if do_train else None), ("sample", sample_half if do_sample else None)):
         if fn is None or cm is not None:
@@ -684,7 +687,12 @@ def main():
             fn()
             sync()
             ts.append(1e3 * (time.perf_counter() - t1))
-        parts[name + "_ms"] = _median(ts)
+        parts[name + "_ms_synced"] = _median(ts)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        sync()
+        parts[name + "_ms"] = 1e3 * (time.perf_counter() - t1) / 5
 
     # exposed (non-overlapped) part of the gradient exchange, same run: train half with the all-reduce issued after the backward
     # minus the train half as benchmarked (issued from inside the sweep).  World 1: the exchange is a no-op, reported as 0.
