@@ -97,6 +97,15 @@ typedef struct TqConvDesc {
      * by the library. */
     int32_t* range_flag;
     const TqGnFuse* gn_fuse; /* reserved, NULL (experiment builds: host pointer, read at launch; see TqGnFuse) */
+    /* ABI 5.  Positions per workgroup along T: 0 = the default tiles (128 / 256); 32 = the small tile for launch-bound batches (a
+     * launch of the default tiling with far fewer workgroups than compute units: four times the workgroups, a quarter of the work
+     * each).  Built for tq_conv1d_fwd / tq_conv1d_fwd_skip with ktaps 5, stride 1, no upsampling, TQ_CONV_GN | TQ_CONV_SILU, in
+     * TQ_WFMT_BF16X3 and TQ_WFMT_F16_MX6 (128 | C_out); other launches return TQ_ERR_SHAPE.  With TQ_CONV_STATS the partial
+     * statistics then have one slot per 32 positions: stats_partial is (B, ceil(T_out / 32), C, 2), and tq_gn_finalize must be told
+     * (its slot arguments).  Convolution results are bit-identical to the default tiles'; the statistics are the same sums in another
+     * association order. */
+    int32_t t_tile;
+    int32_t reserved2;
 } TqConvDesc;
 
 /* flags of TqConvBwdDesc.flags: which stages the FORWARD conv applied to its input */
@@ -215,8 +224,10 @@ int tq_head_conv_fwd(const float* x, const float* gscale, const float* gshift, c
 /* ---- GroupNorm32 statistics -> folded scale/shift ---------------------------------------------------------- */
 /* The normalised tensor is the channel concat of up to two sources whose per-channel partial statistics were
  * emitted by their producers.  Writes scale/shift (B, C0+C1) and mean/rstd (B, 32, 2).  nn.py:11-13,90-105. */
+/* slot0 / slot1 (ABI 5): positions per statistics slot of each source -- 128 (0 = default) or 32 (a tensor written by a
+ * TqConvDesc.t_tile = 32 launch); stats_i is (B, ceil(T / slot_i), C_i, 2). */
 int tq_gn_finalize(const float* stats0, int C0, const float* stats1, int C1, int B, int T, const float* gamma,
-                   const float* beta, float* gscale, float* gshift, float* mean_rstd, hipStream_t stream);
+                   const float* beta, float* gscale, float* gshift, float* mean_rstd, int slot0, int slot1, hipStream_t stream);
 
 /* GroupNorm32 backward, step 1: per-channel partial sums {sum g, sum g*x} (from tq_conv1d_bwd_data / tq_head_conv_bwd)
  * + saved mean/rstd + gamma -> coefficients with dx = A*g + Bc*x + Cc, and dgamma/dbeta (atomically added: zero them first). */

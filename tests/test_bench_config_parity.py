@@ -324,9 +324,24 @@ def test_paper_config_consistency_sampling_b64_vs_oracle():
     e1, e2 = rel_err(y1[pick].cpu(), r1), rel_err(y2[pick].cpu(), r2)
     print(f"paper UNet, B=64, consistency sampling, samples {pick} vs oracle: 1-step {e1:.2e}, with one refinement step {e2:.2e}")
     assert e1 < TOL and e2 < TOL
-    # batch independence at the bench batch: the same four waveforms sampled alone must be bit-identical
+    # batch independence at the bench batch: the same four waveforms sampled alone.  A plan for <= 4 samples uses the small position
+    # tile for its ResBlock convs (engine.SMALL_TILE_B): same convolution arithmetic, the GroupNorm statistics summed in another
+    # association order -> equal to rounding (fp32 statistics over <= 128 positions, fp64 beyond); with the small tile off, bit-identical
     y1p = cm.sample_from(start[pick].to(dev()), [], [], cond=cond[pick].to(dev()))
-    assert torch.equal(y1p, y1[pick]), "a sample must not depend on what else is in the batch"
+    e_batch = rel_err(y1p.cpu(), y1[pick].cpu())
+    print(f"the same four samples alone vs inside the batch of 64: {e_batch:.2e}")
+    assert e_batch < 2e-6, "a sample must not depend on what else is in the batch"
+    import tqdne_amd.engine as E
+    old_b = E.SMALL_TILE_B
+    try:
+        E.SMALL_TILE_B = 0
+        net2 = UNetModel(**cfg)
+        net2.load_state_dict(sd)
+        cm2 = LithningConsistencyModel(net2).to(dev()).eval()
+        y1q = cm2.sample_from(start[pick].to(dev()), [], [], cond=cond[pick].to(dev()))
+    finally:
+        E.SMALL_TILE_B = old_b
+    assert torch.equal(y1q, y1[pick]), "same tiles: a sample must not depend on what else is in the batch, bit for bit"
 
 
 # ---------------------------------------------------------------------------------------------------------------- (vii)

@@ -450,3 +450,65 @@ print("OK")
                        text=True, timeout=600)
     print(r.stdout[-1500:])
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 4: small tile
+@pytest.mark.parametrize("cin0,cin1,cout,T,wf,p,skipc", [
+    (32, 0, 32, 300, 0, 0.0, 0), (64, 32, 64, 257, 0, 0.0, 0), (128, 64, 128, 130, 0, 0.0, 0), (128, 128, 128, 96, 2, 0.0, 0),
+    (128, 0, 256, 65, 2, 0.0, 0), (64, 0, 96, 31, 0, 0.0, 0), (128, 128, 128, 200, 2, 0.0, 256), (64, 32, 64, 100, 0, 0.0, 96),
+    (128, 0, 128, 160, 2, 0.1, 0), (32, 0, 64, 129, 0, 0.1, 32),
+])
+def test_conv_small_tile_equals_the_default_tile(cin0, cin1, cout, T, wf, p, skipc):
+    """TqConvDesc.t_tile = 32 (launch-bound batches): the convolution is BIT-identical to the default tiles' (same accumulation order
+    per output element), its 32-position statistics add up to the default 128-position ones, and tq_gn_finalize fed with them gives
+    the same coefficients to rounding.  ResBlock forms: GN + SiLU (+ dropout) prologue, emb, residual or fused skip conv, concat."""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(cin0 + cin1 + cout + T)
+    B, K = 2, 5
+    d = dev()
+    cin = cin0 + cin1
+    x0 = torch.randn(B, T, cin0, generator=g).to(d)
+    x1 = torch.randn(B, T, cin1, generator=g).to(d) if cin1 else None
+    w = (torch.randn(cout, cin, K, generator=g) / math.sqrt(cin * K)).to(d)
+    b = torch.randn(cout, generator=g).to(d)
+    emb = torch.randn(B, cout, generator=g).to(d)
+    gs, gh = (torch.rand(B, cin, generator=g) + 0.5).to(d), torch.randn(B, cin, generator=g).to(d)
+    kw = dict(x1=x1, gscale=gs, gshift=gh, silu=True, emb=emb, wfmt=wf, dropout_p=p, dropout_seed=77, dropout_site=3)
+    if skipc:
+        sx = torch.randn(B, T, skipc, generator=g).to(d)
+        kw["skip"] = (sx, None, (torch.randn(cout, skipc, 1, generator=g) / math.sqrt(skipc)).to(d), torch.randn(cout, generator=g).to(d))
+    else:
+        kw["residual"] = torch.randn(B, T, cout, generator=g).to(d)
+    y0, st0 = ops.conv1d(x0, w, b, **kw)
+    y1, st1 = ops.conv1d(x0, w, b, t_tile=32, **kw)
+    assert torch.equal(y0, y1)
+    assert st1.shape[1] == (T + 31) // 32
+    # 32-position slots summed four at a time = the 128-position slots
+    pad = (-st1.shape[1]) % 4
+    s1 = torch.cat([st1, torch.zeros(B, pad, cout, 2, device=d)], 1).double().view(B, -1, 4, cout, 2).sum(2)
+    assert rel_err(s1.cpu(), st0.double().cpu()) < 1e-5
+    gam, bet = (torch.rand(cout, generator=g) + 0.5).to(d), torch.randn(cout, generator=g).to(d)
+    a0, h0, m0 = ops.gn_finalize(st0, cout, T, gam, bet)
+    a1, h1, m1 = ops.gn_finalize(st1, cout, T, gam, bet, slot0=32)
+    assert rel_err(a1.cpu(), a0.cpu()) < 1e-5 and rel_err(h1.cpu(), h0.cpu()) < 1e-5 and rel_err(m1.cpu(), m0.cpu()) < 1e-5
+    # a concat of a 32-slot and a 128-slot source (an output block reading the stem's output through the skip stack)
+    if cout % 32 == 0:
+        a2, h2, _ = ops.gn_finalize(st1, cout, T, torch.cat([gam, gam]), torch.cat([bet, bet]), stats1=st0, C1=cout, slot0=32, slot1=128)
+        a3, h3, _ = ops.gn_finalize(st0, cout, T, torch.cat([gam, gam]), torch.cat([bet, bet]), stats1=st0, C1=cout)
+        assert rel_err(a2.cpu(), a3.cpu()) < 1e-5 and rel_err(h2.cpu(), h3.cpu()) < 1e-5
+
+
+def test_conv_small_tile_refuses_what_it_is_not_built_for():
+    import ctypes as C
+    from tqdne_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1 << 16, device=dev())
+    d = _lib.TqConvDesc()
+    d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = 1, 64, 64, 64, 0, 64
+    d.ktaps, d.stride, d.pad, d.upsample, d.flags, d.t_tile = 3, 1, 1, 0, 3, 32          # k = 3
+    p = x.data_ptr()
+    assert lib.tq_conv1d_fwd(C.byref(d), p, None, p, p, p, None, None, None, p, None, None) == -2
+    d.ktaps, d.pad, d.flags = 5, 2, 0                                                      # no GN + SiLU prologue
+    assert lib.tq_conv1d_fwd(C.byref(d), p, None, None, None, p, None, None, None, p, None, None) == -2
+    d.flags, d.t_tile = 3, 64                                                              # not a tile that exists
+    assert lib.tq_conv1d_fwd(C.byref(d), p, None, p, p, p, None, None, None, p, None, None) == -1

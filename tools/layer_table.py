@@ -5,23 +5,24 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from tqdne_amd import LightningEDM, paper_1d_unet_config
+from tqdne_amd import LightningEDM, paper_1d_unet_config, tiny_1d_unet_config
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 train = len(sys.argv) > 4 and sys.argv[4] == "train"
+tiny = os.environ.get("LAYER_TABLE_CONFIG", "paper") == "tiny"   # (BASELINE configs[0]: unconditioned, 32 base channels)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-edm = LightningEDM(paper_1d_unet_config(), {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
+edm = LightningEDM(tiny_1d_unet_config() if tiny else paper_1d_unet_config(), {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
 edm.unet.load_state_dict(bench.perturbed_state(edm.unet, 17))
 edm = edm.to(dev)
 g = torch.Generator().manual_seed(1)
 x = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev)
-cond = torch.randn(B, 5, generator=g).to(dev)
+cond = None if tiny else torch.randn(B, 5, generator=g).to(dev)
 sig = torch.full((B,), 0.7, device=dev)
 eng = edm.unet._engine(B, T, dev)
-batch = {"signal": x, "cond": cond}
+batch = {"signal": x} if tiny else {"signal": x, "cond": cond}
 acc = {}
 order = []
 for r in range(reps + 2):

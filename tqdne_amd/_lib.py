@@ -61,7 +61,7 @@ class TqConvDesc(C.Structure):
         ("upsample", C.c_int32), ("flags", C.c_int32), ("emb_stride", C.c_int32),
         ("dropout_site", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("C_skip0", C.c_int32), ("C_skip1", C.c_int32), ("wfmt", C.c_int32),
-        ("range_flag", C.c_void_p), ("gn_fuse", C.POINTER(TqGnFuse)),
+        ("range_flag", C.c_void_p), ("gn_fuse", C.POINTER(TqGnFuse)), ("t_tile", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -104,7 +104,7 @@ _PROTOS = {
     "tq_stem_conv_fwd": (I, [VP] * 6 + [I] * 5 + [VP]),
     "tq_head_conv_fwd": (I, [VP] * 9 + [I] * 5 + [VP]),
     "tq_head_conv_lds_bytes": (SZ, [I, I, I]),
-    "tq_gn_finalize": (I, [VP, I, VP, I, I, I, VP, VP, VP, VP, VP, VP]),
+    "tq_gn_finalize": (I, [VP, I, VP, I, I, I, VP, VP, VP, VP, VP, I, I, VP]),
     "tq_embed_fwd": (I, [VP] * 14 + [I, I, I, VP]),
     "tq_linear_fwd": (I, [VP] * 4 + [I, I, I, VP]),
     "tq_attention_fwd": (I, [VP, VP, VP, VP, I, I, I, I, VP]),

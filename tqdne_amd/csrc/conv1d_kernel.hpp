@@ -127,7 +127,9 @@ template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FU
 __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_kernel(const ConvArgs p) {
     static_assert(SCH == 0 || STRIDE == 1, "the fp16-range schemes serve stride-1 launches");
     static_assert(EPI != 1 || SCH == 0 || (SCH == 2 && ACT == 0 && !FUSE && !PW), "data gradients: bf16x3, or fp16 + MX-fp6 on a dy scaled into the fp16 range");
-    static_assert(TBW == 8 || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW), "slim tile: bf16x3 forward, 2 x 2 waves");
+    static_assert(TBW == 8 || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW) ||
+                  (TBW == 2 && (SCH == 0 || (SCH == 2 && WM == 4)) && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 1 && !PW),
+                  "slim tile: bf16x3 forward, 2 x 2 waves; small tile (32 positions per workgroup): stride-1 forward, one wave column");
     static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH >= 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, fp16-range schemes");
     static_assert(SCH != 2 || WN == 1, "scheme 2 tiles are 128 positions wide");
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW>;
@@ -433,7 +435,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
 
     // phase 2 (after them): transform + LDS write; iterations beyond PRE are loaded here in small batches
     auto stage_write = [&](int chunk, int buf) __attribute__((always_inline)) {
-        if constexpr (SCH == 2) {
+        if constexpr (SCH == 2 && C::NFULL == 0) {
+            // small tile (32 positions + halo = ROWS <= NTHR / 4 rows): every row, halo included, is one task of the single pass
+            static_assert(C::NFULL != 0 || C::ROWS * 4 <= C::NTHR, "small tile: one staging task per thread");
+            if ((tid >> 2) < C::ROWS) write16(chunk, buf, tid >> 2, raw2);
+            return;
+        } else if constexpr (SCH == 2) {
             int cs2;
             const float* base2 = chunk_base2(chunk, cs2);
             // the KT - 1 halo rows: loads issued first by every thread (tasks past the halo re-read its last row: an L1 hit),
@@ -885,7 +892,9 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
     const int Cr = poly ? (p.C_out >> 1) : p.C_out;
     const int ph = (poly && co_wave >= Cr) ? 1 : 0;
     const int co_real = co_wave - ph * Cr;
-    const int slot = poly ? 2 * ((t0 >> 7) + wn) + ph : (t0 >> 7) + (TBW == 8 ? wn : 0);
+    // statistics slot = the 128 positions of a wave column (TBW == 8), of the workgroup (slim tile), or the workgroup's 32 positions
+    // (small tile: the host sized the statistics tensor, p.nslots, for 32-position slots)
+    const int slot = poly ? 2 * ((t0 >> 7) + wn) + ph : (TBW == 2 ? (t0 >> 5) : (t0 >> 7) + (TBW == 8 ? wn : 0));
     const float* emb_b = (p.flags & TQ_CONV_EMB) ? p.emb + (size_t)b * p.emb_stride : nullptr;
     // The two 16-channel blocks of a wave are the two 64-byte halves of one 128-byte output line: they are stored back to back
     // (t-block outer, channel block inner).  With the channel block as the outer loop the halves reached L2 microseconds apart
@@ -1010,10 +1019,10 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                 const int ns = p.nslots;
                 double* sh = reinterpret_cast<double*>(lds);
                 if (p.gf_partner_first)
-                    gn_fold_sample<false, true>(sh, b, p.gf_partner, p.gf_Cp, p.stats, Cown, poly ? 2 * p.T_out : p.T_out, ns, p.gf_gamma,
+                    gn_fold_sample<false, true>(sh, b, p.gf_partner, p.gf_Cp, p.stats, Cown, poly ? 2 * p.T_out : p.T_out, ns, ns, p.gf_gamma,
                                                 p.gf_beta, p.gf_gscale, p.gf_gshift, p.gf_mean_rstd);
                 else
-                    gn_fold_sample<true, false>(sh, b, p.stats, Cown, p.gf_partner, p.gf_Cp, poly ? 2 * p.T_out : p.T_out, ns, p.gf_gamma,
+                    gn_fold_sample<true, false>(sh, b, p.stats, Cown, p.gf_partner, p.gf_Cp, poly ? 2 * p.T_out : p.T_out, ns, ns, p.gf_gamma,
                                                 p.gf_beta, p.gf_gscale, p.gf_gshift, p.gf_mean_rstd);
             }
         }
@@ -1154,6 +1163,23 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 
 template <int KT, int STRIDE, int UPS, int EPI, int ACT, bool FUSE = false>
 int dispatch_tile(const ConvArgs& a, hipStream_t s) {
+    if (a.t_tile == 32) {
+        // Small tile for launch-bound batches (TqConvDesc.t_tile): 32 positions per workgroup, four times the workgroups of the 128-
+        // position tiles at a quarter of the work each.  Built for the ResBlock convs (k = 5, GN + SiLU [+ dropout] prologue, with or
+        // without the fused skip conv) in bf16x3 and in fp16 + MX-fp6 (128-channel tile).
+        if constexpr (KT == 5 && STRIDE == 1 && UPS == 0 && EPI == 0 && ACT >= 2) {
+            if (a.flags & TQ_CONV_POLY2) return TQ_ERR_SHAPE;
+            if (a.wfmt == TQ_WFMT_F16_MX6) {
+                if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64 || a.C_out % 128) return TQ_ERR_SHAPE;
+                return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 2, false, 2>(a, s);
+            }
+            if (a.wfmt != TQ_WFMT_BF16X3) return TQ_ERR_SHAPE;
+            if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 0, false, 2>(a, s);
+            if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 1, EPI, ACT, FUSE, 0, false, 2>(a, s);
+            return launch<KT, STRIDE, UPS, 1, 1, EPI, ACT, FUSE, 0, false, 2>(a, s);
+        }
+        return TQ_ERR_SHAPE;
+    }
     if (a.wfmt == TQ_WFMT_F16_MX6) {  // same shapes as TQ_WFMT_F16_MX8 (below), fp6 block-scaled corrections
         if constexpr (STRIDE == 1 && UPS == 0 && EPI == 1 && ACT == 0 && !FUSE) {   // data gradient (dy scaled by a power of two)
             if (a.C0 % 64 || a.C1) return TQ_ERR_SHAPE;

@@ -80,6 +80,15 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     const int tile = tq_conv_tile_co(d->C_out);
     a.ncob_pad = ((d->C_out + tile - 1) / tile) * tile / 16;
     a.nslots = (d->T_out + STAT_SLOT - 1) / STAT_SLOT;
+    a.t_tile = 0;
+    if (d->t_tile) {   // the small tile: see TqConvDesc.t_tile for what it is built for (the dispatcher refuses the rest)
+        const int need = TQ_CONV_GN | TQ_CONV_SILU;
+        if (d->t_tile != 32) return TQ_ERR_ARG;
+        if (d->ktaps != 5 || d->stride != 1 || d->upsample || kv_planes || (d->flags & need) != need || (d->flags & TQ_CONV_POLY2) || d->gn_fuse)
+            return TQ_ERR_SHAPE;
+        a.t_tile = 32;
+        a.nslots = (d->T_out + 31) / 32;
+    }
     if (d->flags & TQ_CONV_POLY2) {
         if (d->ktaps != 3 || d->stride != 1 || d->upsample || (d->C_out & 63) || kv_planes || d->C_skip0 || d->C_skip1) return TQ_ERR_SHAPE;
         if ((d->flags & TQ_CONV_STATS) && d->T_out % STAT_SLOT) return TQ_ERR_SHAPE;
@@ -171,6 +180,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     // 3 MFMA products per multiply-add); the packed weights must be in the matching format (pack mode 1 / 5)
     a.wfmt = TQ_WFMT_BF16X3;
     a.in_amax = nullptr;
+    a.t_tile = 0;
     if (d->wfmt == TQ_WFMT_F16_MX6) {
         if (!d->dy_amax) return TQ_ERR_ARG;
         if (d->C_dy % 64 || a.C_out % 128) return TQ_ERR_SHAPE;

@@ -41,6 +41,7 @@ struct ConvArgs {
     int kvH, kvD, kvTp;
     float kvscale;
     int* range_flag;  // see TqConvDesc.range_flag
+    int t_tile;       // 0: the default tiles (128 / 256 positions per workgroup); 32: the small tile (TqConvDesc.t_tile)
     const uint32_t* in_amax;  // data gradient, TQ_WFMT_F16_MX6: bit pattern of max|dy| over the whole tensor (see TqConvBwdDesc.dy_amax)
     // fused GroupNorm finalisation (TqConvDesc.gn_fuse): the workgroup that completes a sample's statistics folds them
     unsigned long long* gf_counters;   // nullptr: off

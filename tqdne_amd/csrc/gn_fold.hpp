@@ -22,11 +22,11 @@ __device__ __forceinline__ float2 gn_load_pair(const float* p) {
     }
 }
 
-// sh: LDS, (2 C + 64) doubles.  st0 / st1: statistics (B, nslots, C0 | C1, 2) of the (up to two, concatenated) source tensors;
+// sh: LDS, (2 C + 64) doubles.  st0 / st1: statistics (B, nslots0 | nslots1, C0 | C1, 2) of the (up to two, concatenated) source tensors;
 // COH0 / COH1: see gn_load_pair.  Every thread of the workgroup calls this (it contains barriers); nthreads = blockDim.x.
 template <bool COH0, bool COH1>
 __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* __restrict__ st0, int C0, const float* __restrict__ st1,
-                                               int C1, int T, int nslots, const float* __restrict__ gamma,
+                                               int C1, int T, int nslots0, int nslots1, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, float* __restrict__ gscale,
                                                float* __restrict__ gshift, float* __restrict__ mean_rstd) {
     // Latency-bound (a few KB per sample): three dependent steps, so every global load is issued as early as possible -- a thread's
@@ -43,6 +43,7 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
         int cs, cc;
         const bool first = c < C0;
         if (first) { st = st0; cs = C0; cc = c; } else { st = st1; cs = C1; cc = c - C0; }
+        const int nslots = first ? nslots0 : nslots1;   // (the two sources may have been written with different position tiles)
         const float* pp = st + ((size_t)b * nslots * cs + cc) * 2;
         auto ld = [&](int s) -> float2 __attribute__((always_inline)) {
             const float* q = pp + (size_t)s * cs * 2;

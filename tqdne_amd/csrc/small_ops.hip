@@ -24,23 +24,27 @@ extern "C" int tq_build_flags(void) {
 // =================================================================================================
 namespace {
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ st0, int C0,
-                                                          const float* __restrict__ st1, int C1, int T, int nslots,
+                                                          const float* __restrict__ st1, int C1, int T, int nslots0, int nslots1,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ gscale, float* __restrict__ gshift,
                                                           float* __restrict__ mean_rstd) {
     extern __shared__ double sh[];  // [C][2] channel sums, then [32][2] group mean/rstd
-    gn_fold_sample<false, false>(sh, blockIdx.x, st0, C0, st1, C1, T, nslots, gamma, beta, gscale, gshift, mean_rstd);
+    gn_fold_sample<false, false>(sh, blockIdx.x, st0, C0, st1, C1, T, nslots0, nslots1, gamma, beta, gscale, gshift, mean_rstd);
 }
 }  // namespace
 
 extern "C" int tq_gn_finalize(const float* stats0, int C0, const float* stats1, int C1, int B, int T, const float* gamma,
-                              const float* beta, float* gscale, float* gshift, float* mean_rstd, hipStream_t stream) {
+                              const float* beta, float* gscale, float* gshift, float* mean_rstd, int slot0, int slot1,
+                              hipStream_t stream) {
     if (!stats0 || !gamma || !beta || !gscale || !gshift || (C1 > 0 && !stats1)) return TQ_ERR_ARG;
     const int C = C0 + C1;
     if (B <= 0 || T <= 0 || C <= 0 || C % GN_GROUPS || C > 3840) return TQ_ERR_SHAPE;  // (LDS: 16 C + 512 bytes <= 64 KB)
-    const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
+    if (slot0 == 0) slot0 = STAT_SLOT;
+    if (slot1 == 0) slot1 = STAT_SLOT;
+    if ((slot0 != STAT_SLOT && slot0 != 32) || (slot1 != STAT_SLOT && slot1 != 32)) return TQ_ERR_ARG;
+    const int nslots0 = (T + slot0 - 1) / slot0, nslots1 = (T + slot1 - 1) / slot1;
     const size_t shbytes = (size_t)(2 * C + 2 * GN_GROUPS) * sizeof(double);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), shbytes, stream, stats0, C0, stats1, C1, T, nslots, gamma,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), shbytes, stream, stats0, C0, stats1, C1, T, nslots0, nslots1, gamma,
                        beta, gscale, gshift, mean_rstd);
     TQ_CHECK_LAUNCH();
     return 0;

@@ -48,10 +48,11 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 class Act:
     """A channels-last activation (B, T, C) and, optionally, its per-channel partial statistics."""
 
-    __slots__ = ("buf", "stats", "C", "T", "grad", "gw", "prod")
+    __slots__ = ("buf", "stats", "C", "T", "grad", "gw", "prod", "slot")
 
-    def __init__(self, buf, stats, C, T):
+    def __init__(self, buf, stats, C, T, slot=STAT_SLOT):
         self.buf, self.stats, self.C, self.T = buf, stats, C, T
+        self.slot = slot   # positions per statistics slot (32 for the output of a small-tile conv, TqConvDesc.t_tile)
         self.prod = None   # descriptors (TqConvDesc) of the launches that write this tensor and its statistics, if they can fold them
         self.grad = None   # gradient buffer (training plans only)
         self.gw = False    # backward-plan construction: has some op already written the gradient?
@@ -65,6 +66,12 @@ FUSE_SKIP = os.environ.get("TQDNE_FUSE_SKIP", "1") != "0"  # A/B switch for the 
 # (an experiment since round 4: only libraries built with TQDNE_BUILD_EXPERIMENTS=1 carry it)
 GN_FUSE = os.environ.get("TQDNE_GN_FUSE", "0") == "1"
 FUSE_SKIP_CO = 32  # smallest output-channel multiple fused (measured: 128 -> +3.9 %, 64 -> +1.3 % more on the bench step)
+# Small position tile (TqConvDesc.t_tile = 32) for the ResBlock convs of launch-bound plans: a plan whose batch is at most SMALL_TILE_B
+# samples launches 16-64 workgroups of the default tiles per conv on 256 compute units (tiny UNet, B = 4: 12-30 us per conv launch).
+# The choice is a property of the PLAN (its batch), never of how many lanes run: lanes of a larger batch have >= 8 samples each, so
+# the lane-versus-one-lane bit-identity holds.  A sample computed in a small batch differs from the same sample in a large one at
+# rounding level only through the association order of the GroupNorm statistics.  TQDNE_SMALL_TILE=0 turns it off.
+SMALL_TILE_B = int(os.environ.get("TQDNE_SMALL_TILE_B", "4")) if os.environ.get("TQDNE_SMALL_TILE", "1") != "0" else 0
 
 
 class ConvRec:
@@ -309,8 +316,8 @@ class UNetEngine:
         self._keep.append(t)
         return t
 
-    def _act(self, C_: int, T_: int, stats: bool = True) -> Act:
-        a = Act(self._empty(self.B, T_, C_), self._empty(self.B, nslots(T_), C_, 2) if stats else None, C_, T_)
+    def _act(self, C_: int, T_: int, stats: bool = True, slot: int = STAT_SLOT) -> Act:
+        a = Act(self._empty(self.B, T_, C_), self._empty(self.B, (T_ + slot - 1) // slot, C_, 2) if stats else None, C_, T_, slot)
         self.acts.append(a)
         return a
 
@@ -371,7 +378,7 @@ class UNetEngine:
         for _ in range(2 if os.environ.get("TQDNE_DUP_GN") == "1" else 1):   # (measurement switch: what do these launches cost?)
             self._emit((self.lib.tq_gn_finalize, (
                 _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
-                _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd)), "gn_finalize", 0),
+                _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd), s0.slot, s1.slot if s1 else 0), "gn_finalize", 0),
                 nbytes=4 * self.B * (2 * nslots(s0.T) * C_ + 2 * C_))
         return gscale, gshift, mean_rstd
 
@@ -393,8 +400,14 @@ class UNetEngine:
         else:
             T_out = 2 * T_in if upsample else T_in
             pad = site.K // 2
-        out = self._act(site.C_out, T_out, stats) if launch else None
+        srcs_c = [s0.C, (s1.C if s1 else 0)] + ([a.C for a in skip[0]] if skip is not None else [])
+        wfmt = _lib.forward_wfmt(site.C_out, srcs_c, stride, upsample, fused_skip=skip is not None) if launch else 0
+        # the small tile where it is built (see SMALL_TILE_B): the ResBlock convs of a small-batch plan
+        small = (launch and self.B <= SMALL_TILE_B and stride == 1 and not upsample and site.K == 5 and gn is not None and silu
+                 and qkv_planes is None and wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX6) and not GN_FUSE)
+        out = self._act(site.C_out, T_out, stats, slot=32 if small else STAT_SLOT) if launch else None
         d = TqConvDesc()
+        d.t_tile = 32 if small else 0
         d.B, d.T_in, d.T_out = self.B, T_in, T_out
         d.C_in0, d.C_in1, d.C_out = s0.C, (s1.C if s1 else 0), site.C_out
         assert d.C_in0 + d.C_in1 == site.C_in, (site.name, d.C_in0, d.C_in1, site.C_in)
@@ -413,8 +426,7 @@ class UNetEngine:
             flags |= TQ_CONV_STATS
         d.flags = flags
         d.emb_stride = self.emb_total
-        srcs_c = [d.C_in0, d.C_in1] + ([a.C for a in skip[0]] if skip is not None else [])
-        d.wfmt = _lib.forward_wfmt(site.C_out, srcs_c, stride, upsample, fused_skip=skip is not None) if launch else 0
+        d.wfmt = wfmt
         if launch:
             site.pack_mode = _lib.PACK_MODE[d.wfmt]
             if skip is not None:

@@ -34,9 +34,10 @@ def pack_conv_weight(w: torch.Tensor, mode: int = 0) -> torch.Tensor:
 
 
 def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=False, emb=None, residual=None,
-           stride=1, upsample=False, stats=True, dropout_p=0.0, dropout_seed=0, dropout_site=0, skip=None, wfmt=None):
+           stride=1, upsample=False, stats=True, dropout_p=0.0, dropout_seed=0, dropout_site=0, skip=None, wfmt=None, t_tile=0):
     """x0/x1 (B, T, C) channels-last fp32; weight (C_out, C_in, K) torch layout.  Returns (y, stats|None).
-    skip=(sx0, sx1|None, w_skip (C_out, Cs, 1), b_skip|None): fused 1x1 conv of the un-activated sx (tq_conv1d_fwd_skip)."""
+    skip=(sx0, sx1|None, w_skip (C_out, Cs, 1), b_skip|None): fused 1x1 conv of the un-activated sx (tq_conv1d_fwd_skip).
+    t_tile=32: the small tile (TqConvDesc.t_tile); the statistics then have one slot per 32 positions."""
     lib = _lib.load()
     B, T_in, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[2]
@@ -44,10 +45,11 @@ def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=Fal
     assert C_in == C0 + C1
     T_out = (T_in + 2 * (K // 2) - K) // 2 + 1 if stride == 2 else (2 * T_in if upsample else T_in)
     y = torch.empty(B, T_out, C_out, device=x0.device)
-    st = torch.empty(B, nslots(T_out), C_out, 2, device=x0.device) if stats else None
+    st = torch.empty(B, (T_out + 31) // 32 if t_tile == 32 else nslots(T_out), C_out, 2, device=x0.device) if stats else None
     d = TqConvDesc()
     d.B, d.T_in, d.T_out, d.C_in0, d.C_in1, d.C_out = B, T_in, T_out, C0, C1, C_out
     d.ktaps, d.stride, d.pad, d.upsample = K, stride, K // 2, int(upsample)
+    d.t_tile = t_tile
     f = 0
     if gscale is not None:
         f |= TQ_CONV_GN
@@ -83,13 +85,14 @@ def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=Fal
     return y, st
 
 
-def gn_finalize(stats0, C0, T, gamma, beta, stats1=None, C1=0):
+def gn_finalize(stats0, C0, T, gamma, beta, stats1=None, C1=0, slot0=0, slot1=0):
+    """slot0 / slot1: positions per statistics slot of each source (0 = 128; 32 for the output of a t_tile = 32 conv)"""
     lib = _lib.load()
     B = stats0.shape[0]
     Cn = C0 + C1
     gs, gh = torch.empty(B, Cn, device=gamma.device), torch.empty(B, Cn, device=gamma.device)
     mr = torch.empty(B, 32, 2, device=gamma.device)
-    check(lib.tq_gn_finalize(_p(stats0), C0, _p(stats1), C1, B, T, _p(gamma), _p(beta), _p(gs), _p(gh), _p(mr),
+    check(lib.tq_gn_finalize(_p(stats0), C0, _p(stats1), C1, B, T, _p(gamma), _p(beta), _p(gs), _p(gh), _p(mr), slot0, slot1,
                              _stream(gamma.device)), "gn_finalize")
     return gs, gh, mr
 
