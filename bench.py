@@ -770,7 +770,8 @@ def main():
         import glob
         import hashlib
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_dominant_conv.json")))
-        src_hash = hashlib.sha256(open(os.path.join(ROOT, "tqdne_amd", "csrc", "conv1d_mfma.hip"), "rb").read()).hexdigest()[:16]
+        # (the kernel template lives in conv1d_kernel.hpp since round 4; the key keeps its round-1 name)
+        src_hash = hashlib.sha256(open(os.path.join(ROOT, "tqdne_amd", "csrc", "conv1d_kernel.hpp"), "rb").read()).hexdigest()[:16]
         if pmc and args.config == "paper" and B == 64 and T == 4096:
             try:
                 pj = json.load(open(pmc[-1]))

@@ -28,7 +28,7 @@ if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     out["hbm_traffic_bytes_per_launch"] = out["hbm_read_bytes_corrected"] + out["hbm_write_bytes"]
 out["algorithmic_bytes_per_launch"] = 4 * 64 * 1024 * (512 + 256)   # fp32 input (two sources) + output, weights excluded
 import hashlib
-out["conv1d_mfma_sha16"] = hashlib.sha256(open("$repo/tqdne_amd/csrc/conv1d_mfma.hip", "rb").read()).hexdigest()[:16]   # bench.py refuses a file recorded for another build
+out["conv1d_mfma_sha16"] = hashlib.sha256(open("$repo/tqdne_amd/csrc/conv1d_kernel.hpp", "rb").read()).hexdigest()[:16]   # bench.py refuses a file recorded for another build of the kernel template
 print(json.dumps(out, indent=1))
 json.dump(out, open("$repo/gpurun_out/pmc_$tag.json", "w"), indent=1)
 PY
