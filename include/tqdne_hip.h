@@ -282,6 +282,16 @@ int tq_pair_sum(const float* d_up, float* dx, int B, int T, int C, int accumulat
 /* stem conv weight gradient (atomically added into zeroed dw (C_out, C_in, K)) */
 int tq_stem_conv_bwd_weight(const float* dy, const float* x_nct, const float* in_scale, float* dw, int B, int C_in, int T,
                             int C_out, int ktaps, hipStream_t stream);
+/* ABI 5: the same two with a scratch buffer of tq_stem_head_bwd_workspace() bytes (own buffer per call site and stream): every
+ * workgroup's 960 partial sums go to its row of the scratch and a second small launch adds the rows into dw (db) -- the outputs share
+ * 30 cache lines, and atomics on one LINE serialise at ~11 ns each (512 workgroups: 180 us, the whole time of these kernels).
+ * workspace NULL or too small: the atomic form.  dw / db are still ADDED to (zero them first). */
+size_t tq_stem_head_bwd_workspace(void);
+int tq_stem_conv_bwd_weight_ws(const float* dy, const float* x_nct, const float* in_scale, float* dw, int B, int C_in, int T,
+                               int C_out, int ktaps, void* workspace, size_t ws_bytes, hipStream_t stream);
+int tq_head_conv_bwd_ws(const float* dpred_nct, const float* c_out, const float* x, const float* gscale, const float* gshift,
+                        const float* w, float* g_out, float* gstats_partial, float* dw, float* db, int B, int T, int C_in,
+                        int C_out, int ktaps, void* workspace, size_t ws_bytes, hipStream_t stream);
 /* head conv backward: dF = c_out[b]*dpred; g_out (B,T,C_in) = (W^T*dF)*silu'(gscale*x+gshift) with GN partial sums;
  * dw, db atomically added (zero them first) */
 int tq_head_conv_bwd(const float* dpred_nct, const float* c_out, const float* x, const float* gscale, const float* gshift,

@@ -88,3 +88,20 @@ for (Cc, T) in [] if ONLY not in ("", "gn") else [(64, 4096), (128, 2048), (256,
         assert lib.tq_gn_bwd_apply_colsum(p(G), p(x), p(r), p(coefs[0]), p(coefs[1]), p(coefs[2]), p(dx), B, T, Cc, Cc, 0, 0, p(obc), Cc, None,
                                           None, p(am), stream()) == 0
     print(f"{Cc:4d} x {T:5d}: {med(apply):7.1f} | {med(cs):7.1f} | {med(both):7.1f} | {med(fused):7.1f}   per-sample sums only: colsum {med(cs_rows):7.1f}, fused {med(fused_rows):7.1f}")
+
+print("## stem weight gradient | head backward (3 x 4096, 64 channels)   [TQDNE_STEM_HEAD_BWD=3: round 3's kernels]")
+if ONLY in ("", "stemhead"):
+    T = 4096
+    dy = torch.randn(B, T, 64, device=dev); xin = torch.randn(B, 3, T, device=dev); sc = torch.rand(B, device=dev) + 0.5
+    dw = torch.zeros(64, 3, 5, device=dev)
+    wsb = torch.empty(lib.tq_stem_head_bwd_workspace(), dtype=torch.uint8, device=dev)
+    use_ws = os.environ.get("MICRO_NO_WS") != "1"
+    def stem():
+        assert lib.tq_stem_conv_bwd_weight_ws(p(dy), p(xin), p(sc), p(dw), B, 3, T, 64, 5, p(wsb) if use_ws else None, wsb.numel() if use_ws else 0, stream()) == 0
+    hh = torch.randn(B, T, 64, device=dev); ga, gs = torch.rand(B, 64, device=dev) + 0.5, torch.randn(B, 64, device=dev)
+    wh = torch.randn(3, 64, 5, device=dev) / 10; dpred = torch.randn(B, 3, T, device=dev); co = torch.rand(B, device=dev) + 0.5
+    Gh = torch.empty_like(hh); gst = torch.empty(B, T // 128, 64, 2, device=dev); dwh = torch.zeros(3, 64, 5, device=dev); dbh = torch.zeros(3, device=dev)
+    def head():
+        assert lib.tq_head_conv_bwd_ws(p(dpred), p(co), p(hh), p(ga), p(gs), p(wh), p(Gh), p(gst), p(dwh), p(dbh), B, T, 64, 3, 5,
+                                       p(wsb) if use_ws else None, wsb.numel() if use_ws else 0, stream()) == 0
+    print(f"stem wgrad {med(stem):7.1f} | head bwd {med(head):7.1f}")

@@ -150,6 +150,9 @@ _PROTOS = {
     "tq_pair_sum": (I, [VP, VP, I, I, I, I, VP]),
     "tq_stem_conv_bwd_weight": (I, [VP] * 4 + [I] * 5 + [VP]),
     "tq_head_conv_bwd": (I, [VP] * 10 + [I] * 5 + [VP]),
+    "tq_stem_head_bwd_workspace": (SZ, []),
+    "tq_stem_conv_bwd_weight_ws": (I, [VP] * 4 + [I] * 5 + [VP, SZ, VP]),
+    "tq_head_conv_bwd_ws": (I, [VP] * 10 + [I] * 5 + [VP, SZ, VP]),
 }
 
 # entry points of later rounds are optional at load time but listed in the header check

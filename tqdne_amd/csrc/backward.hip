@@ -1030,6 +1030,230 @@ extern "C" int tq_pair_sum(const float* d_up, float* dx, int B, int T, int C, in
 }
 
 // =================================================================================================
+// Round 4: streaming forms of the stem weight gradient and of the head backward.  The round 1-3 kernels below (thread per output
+// element, both operands from LDS: two LDS reads per FMA; 512-2048 workgroups x 960 atomics) took 260 us and 188 us at B = 64 for
+// what is one pass over a 67 MB tensor.  Here a thread owns ONE wide-tensor channel and a run of positions: the wide tensor (dy /
+// the head's input) is read straight from HBM, a wave fetching 256-byte rows, several rows in flight; the narrow operand (the <= 8
+// input channels of the stem, the <= 4 output channels of the head) sits in LDS and is read as wave-uniform broadcasts through a
+// sliding register window; the KT x narrow-channel partial sums live in registers across all units of the workgroup, are combined over
+// the position segments in LDS and leave as ONE set of atomics per workgroup.
+// =================================================================================================
+namespace {
+// dW[co][ci][k] += sum_{b,t} dy[b,t,co] * in_scale[b] * x[b,ci,t+k-pad].  256 % C_out == 0, C_in <= CI.
+template <int KT, int CI>
+__global__ __launch_bounds__(256) void stem_wgrad_stream_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ in_scale, float* __restrict__ dw,
+                                                                float* __restrict__ part, int C_in, int T, int C_out, int nslots,
+                                                                int nunits, int upw) {
+    extern __shared__ float shm[];
+    constexpr int PAD = KT / 2, TW = STAT_SLOT + KT - 1, BLK = 16;
+    float* xs = shm;                  // [C_in][TW]
+    float* red = xs + CI * TW;        // [nseg][C_in * KT][C_out]
+    const int nseg = 256 / C_out, L = STAT_SLOT / nseg;
+    const int co = threadIdx.x % C_out, seg = threadIdx.x / C_out;
+    float acc[CI][KT];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[ci][k] = 0.f;
+    const int u0 = blockIdx.x * upw, u1 = min(nunits, u0 + upw);
+    for (int u = u0; u < u1; ++u) {
+        const int slot = u % nslots, b = u / nslots;
+        const int t0 = slot * STAT_SLOT;
+        const float sc = in_scale ? in_scale[b] : 1.0f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < C_in * TW; i += 256) {
+            const int c = i / TW, j = i % TW;
+            const int t = t0 - PAD + j;
+            xs[c * TW + j] = (t >= 0 && t < T) ? x[((size_t)b * C_in + c) * T + t] * sc : 0.f;
+        }
+        __syncthreads();
+        const int tb = t0 + seg * L;
+        for (int tl = 0; tl < L; tl += BLK) {
+            // (branch-free: rows past the signal load a clamped, valid row and are multiplied by 0 -- a predicated load puts control
+            // flow between the loads and hipcc then drains them one by one, s_waitcnt vmcnt(0) at every join: measured 209 us)
+            float d[BLK];
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                const int tj = tb + tl + j;
+                const int tc = tj < T ? tj : T - 1;
+                d[j] = dy[((size_t)b * T + tc) * C_out + co] * (tj < T ? 1.f : 0.f);
+            }
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                if (ci < C_in) {
+                    float xw[BLK + KT - 1];
+#pragma unroll
+                    for (int j = 0; j < BLK + KT - 1; ++j) xw[j] = xs[ci * TW + seg * L + tl + j];   // wave-uniform: broadcast
+#pragma unroll
+                    for (int j = 0; j < BLK; ++j)
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) acc[ci][k] = fmaf(d[j], xw[j + k], acc[ci][k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nck = C_in * KT;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+            if (ci < C_in) red[(seg * nck + ci * KT + k) * C_out + co] = acc[ci][k];
+    __syncthreads();
+    for (int o = threadIdx.x; o < nck * C_out; o += 256) {
+        float v = 0.f;
+        for (int sg = 0; sg < nseg; ++sg) v += red[sg * nck * C_out + o];
+        const int c = o % C_out, ck = o / C_out;   // ck = ci * KT + k
+        // `part` given: this workgroup's sums go to its own row of the scratch (plain stores), partial_rows_sum_kernel adds the rows.
+        // The 960 outputs share 30 cache lines, and atomics on one LINE serialise at ~11 ns each: 512 workgroups x 32 atomics per
+        // line = 180 us -- that, not the 67 MB pass, was the time of this kernel and of head_bwd (measured 209-236 us with atomics).
+        if (part) part[(size_t)blockIdx.x * (nck * C_out) + (size_t)c * nck + ck] = v;
+        else atomicAdd(dw + (size_t)c * nck + ck, v);
+    }
+}
+
+// out[i] += sum_r part[r][i]   (i < n, rows of n floats; a handful of workgroups: n is ~1000)
+__global__ __launch_bounds__(256) void partial_rows_sum_kernel(const float* __restrict__ part, int nrows, int stride, int n,
+                                                               float* __restrict__ out) {
+    __shared__ float red2[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float a = 0.f;
+    if (i < n) {
+        int r = q;
+        for (; r + 12 < nrows; r += 16)   // 4 loads in flight per thread
+            a += (part[(size_t)r * stride + i] + part[(size_t)(r + 4) * stride + i]) +
+                 (part[(size_t)(r + 8) * stride + i] + part[(size_t)(r + 12) * stride + i]);
+        for (; r < nrows; r += 4) a += part[(size_t)r * stride + i];
+    }
+    red2[q][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (q == 0 && i < n) out[i] += (red2[0][threadIdx.x] + red2[1][threadIdx.x]) + (red2[2][threadIdx.x] + red2[3][threadIdx.x]);   // (threadIdx.x < 64 here)
+}
+
+// Head backward, C_out <= 4 (the network's 3 output channels): thread = (input channel ci, position segment).
+//   dF = c_out[b] * dpred;   dW[co][ci][k] += sum_t dF[co][t] z[ci][t+k-pad];   db[co] += sum_t dF[co][t]
+//   G[t][ci] = (sum_{co,k} W[co][ci][k] dF[co][t+pad-k]) * silu'(a h + s),  GN partial sums {sum G, sum G h} per 128-position slot
+// Both sums pair the thread's own element z[ci][t] / G[t][ci] with the SAME 3 x KT values dF[co][t + pad - k].
+template <int KT>
+__global__ __launch_bounds__(256) void head_bwd_stream_kernel(const float* __restrict__ dpred, const float* __restrict__ c_out,
+                                                              const float* __restrict__ h, const float* __restrict__ gscale,
+                                                              const float* __restrict__ gshift, const float* __restrict__ w,
+                                                              float* __restrict__ G, float* __restrict__ gstats,
+                                                              float* __restrict__ dw, float* __restrict__ db, float* __restrict__ part,
+                                                              int T, int C_in, int C_out, int nslots, int nunits, int upw) {
+    extern __shared__ float shm[];
+    constexpr int PAD = KT / 2, TW = STAT_SLOT + 2 * PAD, MAXCO = 4, BLK = 8;
+    float* dfs = shm;                          // [MAXCO][TW]  dF of positions t0 - pad .. t0 + 127 + pad
+    float* red = dfs + MAXCO * TW;             // [nseg][max(2, MAXCO * KT)][C_in]
+    const int nseg = 256 / C_in, L = STAT_SLOT / nseg;
+    const int ci = threadIdx.x % C_in, seg = threadIdx.x / C_in;
+    float wr[MAXCO][KT], aw[MAXCO][KT];
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            wr[co][k] = co < C_out ? w[((size_t)co * C_in + ci) * KT + k] : 0.f;
+            aw[co][k] = 0.f;
+        }
+    float dbs = 0.f;   // thread co < C_out of segment 0 sums dF[co] over the slots' own positions
+    const int u0 = blockIdx.x * upw, u1 = min(nunits, u0 + upw);
+    for (int u = u0; u < u1; ++u) {
+        const int slot = u % nslots, b = u / nslots;
+        const int t0 = slot * STAT_SLOT;
+        const float cs = c_out ? c_out[b] : 1.0f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < C_out * TW; i += 256) {
+            const int c = i / TW, j = i % TW;
+            const int t = t0 - PAD + j;
+            dfs[c * TW + j] = (t >= 0 && t < T) ? dpred[((size_t)b * C_out + c) * T + t] * cs : 0.f;
+        }
+        for (int i = C_out * TW + threadIdx.x; i < MAXCO * TW; i += 256) dfs[i] = 0.f;   // (unused output channels)
+        __syncthreads();
+        if ((int)threadIdx.x < C_out) {
+            const int nv = min(STAT_SLOT, T - t0);
+            for (int j = 0; j < nv; ++j) dbs += dfs[threadIdx.x * TW + PAD + j];
+        }
+        float ga = 1.f, gs = 0.f;
+        if (gscale) { ga = gscale[(size_t)b * C_in + ci]; gs = gshift[(size_t)b * C_in + ci]; }
+        const int tb = t0 + seg * L;
+        const size_t rowb = ((size_t)b * T + tb) * C_in + ci;
+        float s1 = 0.f, s2 = 0.f;
+        for (int tl = 0; tl < L; tl += BLK) {
+            float hv[BLK];
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {   // (branch-free clamped loads, see stem_wgrad_stream_kernel)
+                const int tj = tb + tl + j;
+                const int tc = tj < T ? tj : T - 1;
+                hv[j] = h[((size_t)b * T + tc) * C_in + ci];
+            }
+            float g[BLK], z[BLK], ds[BLK];
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                g[j] = 0.f;
+                if (gscale) { const float uu = ga * hv[j] + gs; z[j] = silu_f(uu); ds[j] = dsilu_f(uu); }
+                else { z[j] = hv[j]; ds[j] = 1.f; }
+                if (tb + tl + j >= T) z[j] = 0.f;   // (positions past the signal contribute nothing)
+            }
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co) {
+                // window: dF[co] at slot-relative positions (seg L + tl) - pad .. + BLK - 1 + pad  ->  dfs index + PAD
+                float q[BLK + 2 * PAD];
+#pragma unroll
+                for (int j = 0; j < BLK + 2 * PAD; ++j) q[j] = dfs[co * TW + seg * L + tl + j];   // wave-uniform: broadcast
+#pragma unroll
+                for (int j = 0; j < BLK; ++j)
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        const float f = q[j + 2 * PAD - k];   // dF[co][t + pad - k]
+                        aw[co][k] = fmaf(z[j], f, aw[co][k]);
+                        g[j] = fmaf(wr[co][k], f, g[j]);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                if (tb + tl + j < T) {
+                    const float gv = g[j] * ds[j];
+                    G[rowb + (size_t)(tl + j) * C_in] = gv;
+                    s1 += gv; s2 += gv * hv[j];
+                }
+            }
+        }
+        if (gstats) {   // the slot's partial sums: combine the position segments through LDS
+            __syncthreads();
+            red[(seg * 2 + 0) * C_in + ci] = s1;
+            red[(seg * 2 + 1) * C_in + ci] = s2;
+            __syncthreads();
+            if (seg == 0) {
+                float a1 = 0.f, a2 = 0.f;
+                for (int sg = 0; sg < nseg; ++sg) { a1 += red[(sg * 2 + 0) * C_in + ci]; a2 += red[(sg * 2 + 1) * C_in + ci]; }
+                float* st = gstats + (((size_t)b * nslots + slot) * C_in + ci) * 2;
+                st[0] = a1; st[1] = a2;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) red[(seg * MAXCO * KT + co * KT + k) * C_in + ci] = aw[co][k];
+    __syncthreads();
+    for (int o = threadIdx.x; o < C_out * KT * C_in; o += 256) {
+        const int c = o % C_in, ck = o / C_in;   // ck = co * KT + k
+        float v = 0.f;
+        for (int sg = 0; sg < nseg; ++sg) v += red[(sg * MAXCO * KT + ck) * C_in + c];
+        const int co = ck / KT, k = ck % KT;
+        if (part) part[(size_t)blockIdx.x * (C_out * C_in * KT + MAXCO) + ((size_t)co * C_in + c) * KT + k] = v;   // (see the stem kernel)
+        else atomicAdd(dw + ((size_t)co * C_in + c) * KT + k, v);
+    }
+    if ((int)threadIdx.x < C_out) {
+        if (part) part[(size_t)blockIdx.x * (C_out * C_in * KT + MAXCO) + C_out * C_in * KT + threadIdx.x] = dbs;
+        else atomicAdd(db + threadIdx.x, dbs);
+    }
+}
+}  // namespace
+
+// =================================================================================================
 // Stem weight gradient: dW[co,ci,k] += sum_{b,t} dy[b,t,co] * in_scale[b]*x[b,ci,t+k-pad];  db via tq_colsum.
 // One workgroup per (b, 128-position slot); thread per output element; fp32 atomics into the zeroed gradient.
 // =================================================================================================
@@ -1193,14 +1417,54 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 }  // namespace
 
+// up to STEM_HEAD_WGS_MAX workgroups x <= 1024 partial sums.  Workgroups per launch (A/B switch TQDNE_STEM_HEAD_WGS), measured at B = 64
+// (tools/bwd_micro.py, us for 256 / 512 / 1024 / 2048): stem weight gradient 118 / 74 / 62 / 86 (118 registers: four workgroups per CU
+// cover each other's staging and load latencies), head backward 102 / 85 / 105 / 145 (157 registers: two per CU).
+constexpr int STEM_HEAD_WGS_MAX = 2048;
+static int stem_head_wgs(int dflt) {
+    static const int forced = [] { const char* e = getenv("TQDNE_STEM_HEAD_WGS"); return e ? atoi(e) : 0; }();
+    const int v = forced > 0 ? forced : dflt;
+    return v > STEM_HEAD_WGS_MAX ? STEM_HEAD_WGS_MAX : v;
+}
+extern "C" size_t tq_stem_head_bwd_workspace(void) { return (size_t)STEM_HEAD_WGS_MAX * 1024 * sizeof(float); }
+
 extern "C" int tq_stem_conv_bwd_weight(const float* dy, const float* x_nct, const float* in_scale, float* dw, int B, int C_in,
                                        int T, int C_out, int ktaps, hipStream_t stream) {
+    return tq_stem_conv_bwd_weight_ws(dy, x_nct, in_scale, dw, B, C_in, T, C_out, ktaps, nullptr, 0, stream);
+}
+
+extern "C" int tq_stem_conv_bwd_weight_ws(const float* dy, const float* x_nct, const float* in_scale, float* dw, int B, int C_in,
+                                          int T, int C_out, int ktaps, void* workspace, size_t ws_bytes, hipStream_t stream) {
     if (!dy || !x_nct || !dw) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || C_in <= 0 || C_in > 16 || C_out <= 0 || (ktaps != 1 && ktaps != 3 && ktaps != 5)) return TQ_ERR_SHAPE;
     const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
     const size_t sh = ((size_t)C_in * (STAT_SLOT + ktaps - 1) + (size_t)STAT_SLOT * (C_out + 1)) * sizeof(float);
     if (sh > 160 * 1024) return TQ_ERR_SHAPE;
     if (C_out * C_in * ktaps > 8 * 256) return TQ_ERR_SHAPE;
+    static const bool old_form = [] { const char* e = getenv("TQDNE_STEM_HEAD_BWD"); return e && atoi(e) == 3; }();   // (A/B switch: 3 = round 3's kernels)
+    if (!old_form && C_in <= 8 && C_out >= 32 && C_out <= 256 && 256 % C_out == 0 && ktaps == 5) {   // the streaming form (round 4)
+        const int nunits2 = B * nslots;
+        const int nwg2 = nunits2 < stem_head_wgs(1024) ? nunits2 : stem_head_wgs(1024);
+        const int upw2 = (nunits2 + nwg2 - 1) / nwg2;
+        const unsigned grid2 = (unsigned)((nunits2 + upw2 - 1) / upw2);
+        const int nout2 = C_out * C_in * 5;
+        float* part = (workspace && ws_bytes >= (size_t)grid2 * nout2 * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+        if (C_in <= 4) {
+            const size_t sh2 = ((size_t)4 * (STAT_SLOT + 4) + (size_t)256 * C_in * 5) * sizeof(float);
+            hipLaunchKernelGGL((stem_wgrad_stream_kernel<5, 4>), dim3(grid2), dim3(256), sh2, stream, dy, x_nct, in_scale, dw, part, C_in, T,
+                               C_out, nslots, nunits2, upw2);
+        } else {
+            const size_t sh2 = ((size_t)8 * (STAT_SLOT + 4) + (size_t)256 * C_in * 5) * sizeof(float);
+            hipLaunchKernelGGL((stem_wgrad_stream_kernel<5, 8>), dim3(grid2), dim3(256), sh2, stream, dy, x_nct, in_scale, dw, part, C_in, T,
+                               C_out, nslots, nunits2, upw2);
+        }
+        TQ_CHECK_LAUNCH();
+        if (part) {
+            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((nout2 + 63) / 64), dim3(256), 0, stream, part, (int)grid2, nout2, nout2, dw);
+            TQ_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     auto kern = stem_wgrad_kernel;
     if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int nunits = B * nslots;
@@ -1215,11 +1479,38 @@ extern "C" int tq_stem_conv_bwd_weight(const float* dy, const float* x_nct, cons
 extern "C" int tq_head_conv_bwd(const float* dpred_nct, const float* c_out, const float* x, const float* gscale,
                                 const float* gshift, const float* w, float* g_out, float* gstats, float* dw, float* db, int B,
                                 int T, int C_in, int C_out, int ktaps, hipStream_t stream) {
+    return tq_head_conv_bwd_ws(dpred_nct, c_out, x, gscale, gshift, w, g_out, gstats, dw, db, B, T, C_in, C_out, ktaps, nullptr, 0, stream);
+}
+
+extern "C" int tq_head_conv_bwd_ws(const float* dpred_nct, const float* c_out, const float* x, const float* gscale,
+                                   const float* gshift, const float* w, float* g_out, float* gstats, float* dw, float* db, int B,
+                                   int T, int C_in, int C_out, int ktaps, void* workspace, size_t ws_bytes, hipStream_t stream) {
     if (!dpred_nct || !x || !w || !g_out || !dw || !db) return TQ_ERR_ARG;
     if ((gscale == nullptr) != (gshift == nullptr)) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || C_in < 8 || C_in % 8 || 256 % (C_in / 4) || C_out < 1 || C_out > 16) return TQ_ERR_SHAPE;
     const int maxco = C_out <= 4 ? 4 : 16;
     const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
+    static const bool old_form = [] { const char* e = getenv("TQDNE_STEM_HEAD_BWD"); return e && atoi(e) == 3; }();   // (A/B switch: 3 = round 3's kernels)
+    if (!old_form && C_out <= 4 && ktaps == 5 && C_in >= 32 && C_in <= 256 && 256 % C_in == 0) {   // the streaming form (round 4)
+        const int nunits = B * nslots;
+        const int nwg = nunits < stem_head_wgs(512) ? nunits : stem_head_wgs(512);
+        const int upw = (nunits + nwg - 1) / nwg;
+        const size_t sh2 = ((size_t)4 * (STAT_SLOT + 4) + (size_t)256 * 4 * 5) * sizeof(float);
+        const unsigned grid2 = (unsigned)((nunits + upw - 1) / upw);
+        const int nout2 = C_out * C_in * 5 + 4;   // dw, then db padded to 4
+        float* part = (workspace && ws_bytes >= (size_t)grid2 * nout2 * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+        hipLaunchKernelGGL(head_bwd_stream_kernel<5>, dim3(grid2), dim3(256), sh2, stream, dpred_nct, c_out, x, gscale, gshift, w, g_out,
+                           gstats, dw, db, part, T, C_in, C_out, nslots, nunits, upw);
+        TQ_CHECK_LAUNCH();
+        if (part) {
+            // (dw's rows first: C_out C_in 5 floats; the bias sums sit behind them in every row)
+            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((nout2 - 4 + 63) / 64), dim3(256), 0, stream, part, (int)grid2, nout2, nout2 - 4, dw);
+            TQ_CHECK_LAUNCH();
+            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(1), dim3(256), 0, stream, part + (nout2 - 4), (int)grid2, nout2, C_out, db);
+            TQ_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     const int nrow = 256 / (C_in / 4);
     const size_t sh = ((size_t)maxco * (STAT_SLOT + ktaps - 1) + (size_t)C_in * (STAT_SLOT + ktaps) + (size_t)nrow * C_in * 2) * sizeof(float);
     if (sh > 160 * 1024) return TQ_ERR_SHAPE;

@@ -346,9 +346,13 @@ class BackwardPlan:
         head = m.out[2]
         Gh = self.scratch("G", final.T, final.C)
         gst = self._empty(B, _nslots(final.T), final.C, 2)
-        self.head_op = [lib.tq_head_conv_bwd, [None, None, _p(final.buf), _p(e.head_gn[0]), _p(e.head_gn[1]), _p(head.weight), _p(Gh),
-                                               _p(gst), _p(self.g(head.weight)), _p(self.g(head.bias)), B, final.T, final.C,
-                                               m.out_channels, head.kernel_size[0]], "head bwd"]
+        # (scratch for the two-stage sums of the head / stem weight gradients: one buffer each, see tq_stem_head_bwd_workspace)
+        nws = lib.tq_stem_head_bwd_workspace()
+        self._ws_head = torch.empty(nws, dtype=torch.uint8, device=self.dev)
+        self._ws_stem = torch.empty(nws, dtype=torch.uint8, device=self.dev)
+        self.head_op = [lib.tq_head_conv_bwd_ws, [None, None, _p(final.buf), _p(e.head_gn[0]), _p(e.head_gn[1]), _p(head.weight), _p(Gh),
+                                                  _p(gst), _p(self.g(head.weight)), _p(self.g(head.bias)), B, final.T, final.C,
+                                                  m.out_channels, head.kernel_size[0], _p(self._ws_head), nws], "head bwd"]
         coef = self._gn_bwd(gst, e.head_gn, m.out[0], final.T, final.C)
         self._gn_apply(Gh, final, coef, final.C, 0)
         # ---- blocks, reversed
@@ -358,8 +362,8 @@ class BackwardPlan:
         stem = m.input_blocks[0][0]
         so = e.stem_out
         assert so.gw
-        self.stem_op = [lib.tq_stem_conv_bwd_weight, [_p(so.grad), None, None, _p(self.g(stem.weight)), B, m.in_channels, so.T,
-                                                      stem.out_channels, stem.kernel_size[0]], "stem wgrad"]
+        self.stem_op = [lib.tq_stem_conv_bwd_weight_ws, [_p(so.grad), None, None, _p(self.g(stem.weight)), B, m.in_channels, so.T,
+                                                         stem.out_channels, stem.kernel_size[0], _p(self._ws_stem), nws], "stem wgrad"]
         self._ready[id(stem.weight)] = self.END  # (run after the sweep, not from self.ops)
         # wide stems (the latent UNet's 16 input channels: 64 x 16 x 5 weights exceed the dedicated kernel's register budget)
         # are differentiated as a generic fused conv over a (B, T, 32) channels-last copy of the pre-scaled input
@@ -702,9 +706,11 @@ class SeqBackwardPlan(BackwardPlan):
         final, out = e.final, m.output_layer
         dfin = self.grad(final)
         if e.out_mode == "head":   # narrow output (decoder): VALU kernel straight from the NCW gradient
-            self.head_op = [lib.tq_head_conv_bwd, [None, None, _p(final.buf), None, None, _p(out.weight), _p(dfin), None,
-                                                   _p(self.g(out.weight)), _p(self.g(out.bias)), B, final.T, final.C,
-                                                   out.out_channels, out.kernel_size[0]], "output layer bwd"]
+            nws = lib.tq_stem_head_bwd_workspace()
+            self._ws_head = torch.empty(nws, dtype=torch.uint8, device=self.dev)
+            self.head_op = [lib.tq_head_conv_bwd_ws, [None, None, _p(final.buf), None, None, _p(out.weight), _p(dfin), None,
+                                                      _p(self.g(out.weight)), _p(self.g(out.bias)), B, final.T, final.C,
+                                                      out.out_channels, out.kernel_size[0], _p(self._ws_head), nws], "output layer bwd"]
             self.dout_btc = None
         else:                      # wide output (encoder): generic conv gradients from a channels-last copy of d out
             self.head_op = None

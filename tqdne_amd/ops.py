@@ -299,22 +299,26 @@ def pair_sum(d_up, accumulate_into=None):
     return dx
 
 
-def stem_conv_bwd_weight(dy, x_nct, wshape, in_scale=None):
+def stem_conv_bwd_weight(dy, x_nct, wshape, in_scale=None, workspace=True):
+    """``workspace``: two-stage sums through a scratch buffer (default) instead of atomics onto the 30 cache lines of dw"""
     lib = _lib.load()
     B, Cin, T = x_nct.shape
     Cout, _, K = wshape
     dw = torch.zeros(Cout, Cin, K, device=dy.device)
-    check(lib.tq_stem_conv_bwd_weight(_p(dy), _p(x_nct), _p(in_scale), _p(dw), B, Cin, T, Cout, K, _stream(dy.device)), "stem wgrad")
+    ws = torch.empty(lib.tq_stem_head_bwd_workspace(), dtype=torch.uint8, device=dy.device) if workspace else None
+    check(lib.tq_stem_conv_bwd_weight_ws(_p(dy), _p(x_nct), _p(in_scale), _p(dw), B, Cin, T, Cout, K, _p(ws), 0 if ws is None else ws.numel(),
+                                         _stream(dy.device)), "stem wgrad")
     return dw
 
 
-def head_conv_bwd(dpred_nct, x, weight, gscale=None, gshift=None, c_out=None, stats=True):
+def head_conv_bwd(dpred_nct, x, weight, gscale=None, gshift=None, c_out=None, stats=True, workspace=True):
     lib = _lib.load()
     B, T, Cin = x.shape
     Cout, _, K = weight.shape
     g = torch.empty_like(x)
     st = torch.empty(B, nslots(T), Cin, 2, device=x.device) if stats else None
     dw, db = torch.zeros_like(weight), torch.zeros(Cout, device=x.device)
-    check(lib.tq_head_conv_bwd(_p(dpred_nct), _p(c_out), _p(x), _p(gscale), _p(gshift), _p(weight.contiguous()), _p(g), _p(st),
-                               _p(dw), _p(db), B, T, Cin, Cout, K, _stream(x.device)), "head bwd")
+    ws = torch.empty(lib.tq_stem_head_bwd_workspace(), dtype=torch.uint8, device=x.device) if workspace else None
+    check(lib.tq_head_conv_bwd_ws(_p(dpred_nct), _p(c_out), _p(x), _p(gscale), _p(gshift), _p(weight.contiguous()), _p(g), _p(st),
+                                  _p(dw), _p(db), B, T, Cin, Cout, K, _p(ws), 0 if ws is None else ws.numel(), _stream(x.device)), "head bwd")
     return g, st, dw, db
