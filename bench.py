@@ -381,6 +381,22 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+_RESULT_OUT = None   # the process's ORIGINAL stdout once claim_stdout() has run (main); None: sys.stdout
+
+
+def claim_stdout():
+    """stdout must carry the ONE JSON line and nothing else, but libraries write there too: RCCL prints a five-line version banner
+    through C stdio when its communicator is created (block-buffered on a pipe: it comes out at exit, i.e. AFTER the result line --
+    seen with TQDNE_BENCH_FORCE_RCCL=1, profiles/r04_t_*), hipcc and torch warn there.  So file descriptor 1 is pointed at stderr for
+    the rest of the process and the result line (or the watchdog's diagnostic line) is written to a duplicate of the original."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _RESULT_OUT
+
+
 class Watchdog:
     """A hung rendezvous or first collective must be VISIBLE in the driver's record (SCALE_rNN.json) instead of a silent timeout of
     the whole run: a timer thread that, unless cancelled in time, prints ONE diagnostic JSON line on stdout (same top-level keys as
@@ -401,8 +417,9 @@ class Watchdog:
                                                          "HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES", "NCCL_DEBUG")},
                     **self.extra)
         try:
-            sys.stdout.write(json.dumps(line) + "\n")
-            sys.stdout.flush()
+            out = _RESULT_OUT or sys.stdout
+            out.write(json.dumps(line) + "\n")
+            out.flush()
             log("WATCHDOG:", line["error"])
         finally:
             os._exit(3)
@@ -445,10 +462,10 @@ def replica_checksum(params) -> "torch.Tensor":
     return torch.stack([(bits * w).sum(), torch.tensor(bits.numel(), device=bits.device, dtype=torch.int64)])
 
 
-def gather_checksums(cs: "torch.Tensor", world: int):
+def gather_checksums(cs: "torch.Tensor", world: int, collective: bool = None):
     """every rank's checksum on every rank -> list of ints (hex strings in the JSON line)"""
     import torch.distributed as dist
-    if world <= 1:
+    if not (world > 1 if collective is None else collective):
         return [int(cs[0].item())]
     out = [torch.zeros_like(cs) for _ in range(world)]
     dist.all_gather(out, cs)
@@ -529,6 +546,7 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))
+    result_out = claim_stdout()   # (after the self-launch: the ranks it starts inherit the real stdout)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -538,7 +556,24 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     first_collective_ranks = 1
-    if world > 1:
+    # TQDNE_BENCH_FORCE_RCCL=1: at N = 1 too, create the RCCL communicator and run every collective of the N > 1 path (broadcast,
+    # bucketed all-reduce from inside the backward sweep, the checksum gathers) over the one rank -- the self-test of that path
+    # that a 1-GPU box allows; the JSON line says so ("rccl_forced_at_world1")
+    force_rccl = world == 1 and os.environ.get("TQDNE_BENCH_FORCE_RCCL", "0") == "1"
+    if force_rccl and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+    multi = world > 1 or force_rccl   # (the collectives of the N > 1 path run)
+    if multi and os.environ.get("TQDNE_BENCH_RESERVE_STREAMS_FIRST", "1") == "1":
+        # The sampler lanes / the backward's weight-gradient stream must make their first submission BEFORE the RCCL communicator
+        # exists: ROCm binds a stream to a hardware queue at its first submission, and with the communicator's streams in first the
+        # backward's two streams end up sharing a queue (measured with the forced one-rank exchange: train half 22.1 -> 28.1 ms,
+        # profiles/r04_u_rccl_ab.txt).  tqdne_amd.engine.reserve_side_streams is what a plan calls when it is first built.
+        from tqdne_amd.engine import reserve_side_streams
+        reserve_side_streams(dev)
+    if multi:
         first_collective_ranks = init_distributed("nccl", rank, world, dev)
 
     import __graft_entry__
@@ -546,7 +581,7 @@ def main():
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):   # (stdout carries the one JSON line only)
             __graft_entry__.build()
-    if world > 1:
+    if multi:
         dist.barrier()
     from tqdne_amd import LightningEDM, paper_1d_unet_config, rng, tiny_1d_unet_config
     from tqdne_amd.trainer import DataParallelTrainer
@@ -596,7 +631,7 @@ def main():
         gpu_parity = dict(denoise=den, loss=lss, sample=smp, **traj)
         del pd
 
-    trainer = DataParallelTrainer(edm, world_size=world, overlap=not args.no_overlap) if do_train else None
+    trainer = DataParallelTrainer(edm, world_size=world, overlap=not args.no_overlap, force_exchange=force_rccl) if do_train else None
     # replicas: every rank's weights right after the trainer's rank-0 broadcast (compared across ranks in the JSON line)
     cs_start = replica_checksum(edm.unet.parameters())
     sigmas = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
@@ -627,7 +662,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -649,7 +684,7 @@ def main():
     dt_rank = dt
     rank_ms = [1e3 * dt_rank / args.steps]
     rccl_ranks = 1
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -662,8 +697,8 @@ def main():
         dist.all_gather(allr, torch.tensor([1e3 * dt_rank / args.steps], device=dev, dtype=torch.float64))
         rank_ms = [float(t.item()) for t in allr]
     # replicas after the timed steps: data parallelism is only correct if every rank applied the same update to the same weights
-    sums_start = gather_checksums(cs_start, world)
-    sums_end = gather_checksums(replica_checksum(edm.unet.parameters()), world)
+    sums_start = gather_checksums(cs_start, world, multi)
+    sums_end = gather_checksums(replica_checksum(edm.unet.parameters()), world, multi)
     replicas = dict(after_broadcast=len(set(sums_start)) == 1, after_timed_steps=len(set(sums_end)) == 1,
                     weights_moved=(sums_start[0] != sums_end[0]) if do_train else None,
                     checksum_after_broadcast=[f"{v & 0xFFFFFFFFFFFFFFFF:016x}" for v in sums_start],
@@ -699,7 +734,7 @@ def main():
     exchange = None
     if do_train and cm is None:
         exchange = dict(rccl_ranks=rccl_ranks, overlap=not args.no_overlap, bucket_bytes=4 * getattr(trainer, "bucket_elems", 0))
-        if world > 1 and not args.no_overlap:
+        if multi and not args.no_overlap:
             def med_train():
                 train_half(); sync()
                 ts = []
@@ -712,12 +747,12 @@ def main():
             trainer.overlap = False
             t_after = med_train()
             trainer.overlap = True
-            tt = torch.tensor([t_after, parts.get("train_ms", 0.0)], device=dev, dtype=torch.float64)
+            tt = torch.tensor([t_after, parts.get("train_ms_synced", 0.0)], device=dev, dtype=torch.float64)   # (both: synced medians)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             exchange.update(train_ms_exchange_after_backward=float(tt[0]), train_ms_exchange_under_backward=float(tt[1]),
-                            hidden_by_overlap_ms=float(tt[0] - tt[1]))
+                            hidden_by_overlap_ms=float(tt[0] - tt[1]), buckets_elems=list(trainer.last_bucket_sizes))
         else:
-            exchange.update(hidden_by_overlap_ms=0.0 if world == 1 else None)
+            exchange.update(hidden_by_overlap_ms=0.0 if not multi else None)
 
     tables = None
     if rank == 0 and not args.no_tables and cm is None:
@@ -738,7 +773,7 @@ def main():
             tables["train_forward"] = class_table(eng._trace, MFMA_BF16_DENSE_PEAK_TFLOPS, HBM_PEAK_GBS)
             tables["train_backward"] = class_table(eng._bwd._trace, MFMA_BF16_DENSE_PEAK_TFLOPS, HBM_PEAK_GBS)
             eng._trace = eng._bwd._trace = None
-    if world > 1:
+    if multi:
         dist.barrier()
 
     if rank == 0:
@@ -827,6 +862,7 @@ def main():
                        "sampler_lanes": 1 if (use_graph or (use_graph is None and os.environ.get("TQDNE_SAMPLER_GRAPH") == "1")) else sampler_lanes(B),
                        "mode": args.mode},
             "parts": parts,
+            "rccl_forced_at_world1": force_rccl,
             "rccl_ranks": rccl_ranks, "rccl_ranks_ok": rccl_ranks == world and first_collective_ranks == world,
             "replicas_equal": replicas["after_broadcast"] and replicas["after_timed_steps"], "replicas": replicas,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
@@ -855,8 +891,8 @@ def main():
                 and not args.no_other_configs):
             log("other BASELINE configurations (cfg0 tiny B=4, cfg3 latent B=16) ...")
             out["other_configs"] = other_configs(dev, args)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=result_out, flush=True)
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rccl_ranks != world or not (replicas["after_broadcast"] and replicas["after_timed_steps"]):

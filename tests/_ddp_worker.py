@@ -31,7 +31,8 @@ def main():
     dev = torch.device("cuda", rank % max(ngpu, 1))
     torch.cuda.set_device(dev)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from tqdne_amd.trainer import init_process_group   # (side streams first, then the communicator)
+        init_process_group("nccl", device=dev, rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
 

@@ -13,9 +13,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(*args, timeout=600):
+def _run(*args, timeout=600, env=None):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       text=True, timeout=timeout, cwd=ROOT)
+                       text=True, timeout=timeout, cwd=ROOT, env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, f"stdout must carry the JSON line only, got {len(lines)} lines"
@@ -64,3 +64,16 @@ def test_bench_partial_modes_are_labelled():
     assert "DEBUG" in d["metric"] and "cpu_baseline" not in d
     d = _run("--config", "tiny", "--batch", "4", "--steps", "1", "--warmup", "1", "--mode", "consistency", "--no-cpu-baseline")
     assert "consistency" in d["metric"] and d["config"]["mode"] == "consistency"
+
+
+@pytest.mark.timeout(600)
+def test_bench_runs_the_rccl_path_over_one_rank_when_forced():
+    """TQDNE_BENCH_FORCE_RCCL=1: communicator, rank-0 broadcast, bucketed all-reduce issued from inside the backward sweep on RCCL's
+    stream, the exchange-after-backward comparison and the checksum gathers all execute on the 1-GPU box (a sum over one rank)."""
+    d = _run("--config", "tiny", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-tables",
+             env={"TQDNE_BENCH_FORCE_RCCL": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["rccl_forced_at_world1"] is True and d["rccl_ranks"] == 1 and d["rccl_ranks_ok"] is True
+    assert d["replicas_equal"] is True and d["replicas"]["weights_moved"] is True
+    ex = d["gradient_exchange"]
+    assert ex["overlap"] is True and len(ex["buckets_elems"]) >= 1 and ex["hidden_by_overlap_ms"] is not None
+    assert d["value"] > 0

@@ -149,6 +149,40 @@ def test_gloo_world2_trainer_matches_full_batch_training_for_any_bucketing():
     assert all(ret[r] for r in range(world))
 
 
+def _forced_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tqdne_amd.trainer import DataParallelTrainer
+
+    g = torch.Generator().manual_seed(3)
+    steps = [{"signal": torch.randn(8, 16, generator=g), "cond": torch.randn(8, 4, generator=g)} for _ in range(3)]
+
+    def run(**kw):
+        m = _StubEDM()
+        tr = DataParallelTrainer(m, world_size=1, fused_optimizer=False, bucket_bytes=4 * 300, **kw)
+        n = 0
+        for b in steps:
+            tr.train_step(b)
+            n += len(tr.last_bucket_sizes)
+        return torch.cat([p.detach().reshape(-1) for p in m.parameters()]), n
+
+    ref, n0 = run()
+    a, n1 = run(force_exchange=True, overlap=True)
+    b, n2 = run(force_exchange=True, overlap=False)
+    ret[rank] = bool(n0 == 0 and n1 > 9 and n2 == n1 and torch.equal(a, ref) and torch.equal(b, ref))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_forced_exchange_over_one_rank_is_the_identity():
+    """TQDNE_BENCH_FORCE_RCCL's trainer switch: with one rank the broadcast / bucketed all-reduce are issued and change nothing."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_forced_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret[0]
+
+
 def test_rank_seeding_gives_distinct_reproducible_streams():
     from tqdne_amd import rng
     seeds = {}
@@ -227,7 +261,7 @@ def _skip_worker(rank, world, port, ret):
         AGREE_EVERY = 4
 
         def __init__(self):   # (only what _range_skip_flag touches)
-            self.world, self.group, self.fused = world, None, True
+            self.world, self.group, self.fused, self.exchange = world, None, True, True
             self.flag = torch.zeros(1, dtype=torch.int32)
             self.auto = True
 

@@ -108,6 +108,13 @@ def reserve_side_streams(dev, n: int = 3):
     if torch.device(dev).type != "cuda" or (str(dev), "reserved") in _SIDE_STREAMS or torch.cuda.is_current_stream_capturing():
         return
     _SIDE_STREAMS[(str(dev), "reserved")] = True
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        import warnings
+        warnings.warn("tqdne_amd: the RCCL process group exists before this device's side streams made their first submission; if its "
+                      "communicator is already created the backward's two streams may share a hardware queue (training step ~25 % "
+                      "slower).  Call tqdne_amd.trainer.init_process_group(...) (or tqdne_amd.engine.reserve_side_streams(device)) "
+                      "before torch.distributed.init_process_group.", RuntimeWarning, stacklevel=2)
     # (a stream is bound to its hardware queue by its first submission, not by its creation: one tiny launch on each)
     main = torch.cuda.current_stream(dev)
     z = torch.zeros(1, device=dev)

@@ -19,6 +19,18 @@ import torch
 import torch.distributed as dist
 
 
+def init_process_group(backend: str = "nccl", device=None, **kw):
+    """``torch.distributed.init_process_group`` with the one ordering rule this package has on ROCm: the sampler lanes and the
+    backward's weight-gradient stream make their first submission BEFORE the RCCL communicator creates its streams.  ROCm binds a
+    HIP stream to a hardware queue at its first submission; with the communicator in first, the backward's two streams share a
+    queue and the training step of the paper UNet runs 22.1 -> 28.1 ms (measured with a forced one-rank exchange,
+    ``profiles/r04_u_rccl_ab.txt``).  Extra keywords go to torch (``rank``, ``world_size``, ``timeout``, ``device_id`` ...)."""
+    if device is not None and torch.device(device).type == "cuda":
+        from .engine import reserve_side_streams
+        reserve_side_streams(torch.device(device))
+    return dist.init_process_group(backend, **kw)
+
+
 def allreduce_mean_(flat, world_size: int, bucket_elems: int = 8 << 20, scale: bool = True):
     """In-place mean of ``flat`` over all ranks: a few large bucketed all-reduces (RCCL over xGMI on GPUs, gloo in the
     CPU tests), launched asynchronously and waited together, then one scale.  62 MB of gradients = 2 buckets of 32 MB."""
@@ -53,8 +65,10 @@ def shard_batch(batch: dict, rank: int, world_size: int) -> dict:
 
 class DataParallelTrainer:
     def __init__(self, module, world_size: int = 1, bucket_bytes: int = 16 << 20, ema_decay=None, fused_optimizer=None,
-                 overlap: bool = True, process_group=None):
-        """``ema_decay``: keep the EMA weights of the reference's EMA callback (tqdne/ema.py; 0.999 in the reference's runs).
+                 overlap: bool = True, process_group=None, force_exchange: bool = False):
+        """``force_exchange``: issue the collectives with ONE rank too (a sum over one rank is the identity: the self-test of the
+        RCCL path on a 1-GPU box -- communicator, RCCL's stream behind the sweep's launches, the waits in front of the optimizer).
+        ``ema_decay``: keep the EMA weights of the reference's EMA callback (tqdne/ema.py; 0.999 in the reference's runs).
         ``fused_optimizer``: one-launch Adam (+ EMA) instead of torch.optim.Adam; default: on GPUs.
         ``overlap``: issue each gradient bucket's all-reduce from inside the backward sweep (default) instead of after it.
         ``bucket_bytes``: 16 MB = 4 buckets over the paper UNet's 62 MB of gradients (xGMI rings are per-link bound: few,
@@ -63,6 +77,7 @@ class DataParallelTrainer:
         self.world = world_size
         self.group = process_group
         self.overlap = overlap
+        self.exchange = world_size > 1 or force_exchange
         cfg = module.configure_optimizers()
         self.optimizer = cfg["optimizer"]
         self.scheduler = cfg["lr_scheduler"]["scheduler"]
@@ -84,7 +99,7 @@ class DataParallelTrainer:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._hooked = "on_bucket" in inspect.signature(module.step_and_backward).parameters
         self.last_bucket_sizes = []   # elements of each bucket exchanged by the last step, in issue order (diagnostics / tests)
-        if world_size > 1:
+        if self.exchange:
             with torch.no_grad():  # replicas start identical (DDP's initial broadcast); in place on the parameter
                 for p in module.parameters():  # itself (not p.data) so that its version counter moves and packed weights follow
                     dist.broadcast(p, src=0, group=self.group)
@@ -102,7 +117,7 @@ class DataParallelTrainer:
         works = []
         self.last_bucket_sizes = []
         hook = None
-        if self.world > 1 and self.overlap and self._hooked:
+        if self.exchange and self.overlap and self._hooked:
             def hook(sl):
                 self.last_bucket_sizes.append(sl.numel())
                 works.append(self._allreduce_async(sl))
@@ -110,7 +125,7 @@ class DataParallelTrainer:
             loss, flat = self.module.step_and_backward(batch, on_bucket=hook, bucket_elems=self.bucket_elems)
         else:
             loss, flat = self.module.step_and_backward(batch)
-        if self.world > 1 and hook is None:
+        if self.exchange and hook is None:
             flats = list(flat) if isinstance(flat, (list, tuple)) else [flat]
             for f in flats:
                 f1 = f.view(-1)
@@ -166,7 +181,7 @@ class DataParallelTrainer:
         flag, auto = self._local_range_flag()
         if flag is None:
             return None
-        if self.world == 1:
+        if not self.exchange:
             return flag if auto else None
         if getattr(self, "_skip_done", False):
             return None
