@@ -333,15 +333,15 @@ def test_paper_config_consistency_sampling_b64_vs_oracle():
     print(f"the same four samples alone vs inside the batch of 64: {e_batch:.2e}")
     assert e_batch < 1e-4, "a sample must not depend on what else is in the batch"
     import tqdne_amd.engine as E
-    old_b = E.SMALL_TILE_B
+    old_b, old_w = E.SMALL_TILE_B, E.SMALL_TILE_WGS
     try:
-        E.SMALL_TILE_B = 0
+        E.SMALL_TILE_B = E.SMALL_TILE_WGS = 0
         net2 = UNetModel(**cfg)
         net2.load_state_dict(sd)
         cm2 = LithningConsistencyModel(net2).to(dev()).eval()
         y1q = cm2.sample_from(start[pick].to(dev()), [], [], cond=cond[pick].to(dev()))
     finally:
-        E.SMALL_TILE_B = old_b
+        E.SMALL_TILE_B, E.SMALL_TILE_WGS = old_b, old_w
     assert torch.equal(y1q, y1[pick]), "same tiles: a sample must not depend on what else is in the batch, bit for bit"
 
 

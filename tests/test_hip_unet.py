@@ -282,11 +282,27 @@ def test_two_lane_sampler_is_bit_identical():
     B = 16
     start = torch.randn(B, 3, 256, generator=g, dtype=torch.float64).to(dev()) * sig[0]
     cond = torch.randn(B, 5, generator=g).to(dev())
-    one = edm.sample_deterministically(start, sig, None, cond, lanes=1)
-    two = edm.sample_deterministically(start, sig, None, cond, lanes=2)
-    four = edm.sample_deterministically(start, sig, None, cond, lanes=4)  # 4 per lane < 8: falls back to one lane
+    import tqdne_amd.engine as E
+    old_w = E.SMALL_TILE_WGS
+    try:
+        E.SMALL_TILE_WGS = 0   # (same tiles in the one-lane plan and in the lanes' plans)
+        one = edm.sample_deterministically(start, sig, None, cond, lanes=1)
+        two = edm.sample_deterministically(start, sig, None, cond, lanes=2)
+        four = edm.sample_deterministically(start, sig, None, cond, lanes=4)  # 4 per lane < 8: falls back to one lane
+    finally:
+        E.SMALL_TILE_WGS = old_w
     assert torch.equal(one, two) and torch.equal(one, four)
     assert torch.isfinite(one).all()
+    # default rule: a plan that has the device to itself takes the small position tile where the default grid is <= SMALL_TILE_WGS
+    # workgroups (here: 16 samples x 2 tiles), the lanes' plans never do -> same convolution arithmetic, GroupNorm sums associated
+    # differently, results equal at rounding level
+    edm2, _ = _edm_pair(4)
+    one_s = edm2.sample_deterministically(start, sig, None, cond, lanes=1)
+    two_s = edm2.sample_deterministically(start, sig, None, cond, lanes=2)
+    assert torch.equal(two_s, two)
+    assert any(getattr(op_desc, "t_tile", 0) == 32 for e in edm2.unet._engine_cache.values() if e.solo for op_desc in e._keep
+               if hasattr(op_desc, "t_tile")) or old_w == 0
+    assert rel_err(one_s.cpu(), one.cpu()) < 1e-5
 
 
 def test_autoencoder_vs_golden():

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import torch as th
 
-from . import _lib, rng
+from . import _lib, engine, rng
 from ._lib import check
 
 
@@ -86,14 +86,14 @@ def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, 
             st.wait_stream(main)
         try:
             for i, st in enumerate(streams):
-                module._lane = i
+                module._lane = i if lanes == 1 else engine.CONCURRENT_LANE0 + i
                 with th.cuda.stream(st):
                     loss = _EDMLossFn.forward(_Ctx, module, cut(sample, i) if lanes > 1 else sample, cut(eps, i) if lanes > 1 else eps,
                                               cut(unit_noise, i) if lanes > 1 else unit_noise, cut(cond, i) if lanes > 1 else cond,
                                               cut(cond_sample, i) if lanes > 1 else cond_sample, *params)
                     bufs = _Ctx.bufs
                     Bl, _, T = _Ctx.shape
-                    eng = module.unet._engine(Bl, T, dev, i)
+                    eng = module.unet._engine(Bl, T, dev, module._lane)
                     scale = th.full((), 1.0 / lanes, device=dev)
                     grads = eng.backward(bufs["dpred"], scale, clone=False, on_bucket=on_bucket if lanes == 1 else None,
                                          bucket_elems=bucket_elems)

@@ -122,7 +122,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
             with torch.cuda.stream(st):
                 sl = slice(i * h, (i + 1) * h)
                 y = self._forward_static(sample[sl].contiguous(), sigma[sl].contiguous(),
-                                         None if cond is None else cond[sl].contiguous(), lane=i, infer=True)
+                                         None if cond is None else cond[sl].contiguous(), lane=engine.CONCURRENT_LANE0 + i, infer=True)
                 out[sl].copy_(y)
         for i in range(1, lanes):
             main.wait_stream(self._side_stream(dev, i))

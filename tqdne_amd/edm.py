@@ -323,14 +323,14 @@ class LightningEDM(LightningModule):
         runs = []
         try:
             for i, st in enumerate(streams):
-                self._lane = i
+                self._lane = engine.CONCURRENT_LANE0 + i
                 with th.cuda.stream(st):
                     runs.append(self._heun_lane(cut(eps, i), sigmas, cut(cond_sample, i), cut(cond, i), use_graph))
             # one sampler step of lane 0, then of lane 1, ...: all queues stay fed well ahead of the GPU
             while not all(r.done for r in runs):
                 for i, (r, st) in enumerate(zip(runs, streams)):
                     if not r.done:
-                        self._lane = i
+                        self._lane = engine.CONCURRENT_LANE0 + i
                         with th.cuda.stream(st):
                             r.advance()
         finally:

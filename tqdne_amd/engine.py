@@ -72,6 +72,13 @@ FUSE_SKIP_CO = 32  # smallest output-channel multiple fused (measured: 128 -> +3
 # the lane-versus-one-lane bit-identity holds.  A sample computed in a small batch differs from the same sample in a large one at
 # rounding level only through the association order of the GroupNorm statistics.  TQDNE_SMALL_TILE=0 turns it off.
 SMALL_TILE_B = int(os.environ.get("TQDNE_SMALL_TILE_B", "4")) if os.environ.get("TQDNE_SMALL_TILE", "1") != "0" else 0
+# ... and, per LAYER of a plan that has the device to itself (UNetEngine.solo: not a lane of a multi-lane sampler), where the default
+# tile's grid B * ceil(T_out / 128) is at most SMALL_TILE_WGS workgroups -- the T = 512 level of a 16-sample plan: 64 workgroups on 256
+# compute units, 36 -> 26 us per 256 -> 256 conv, cfg3's sample 92.5 -> 87.0 ms.  Lanes keep the default tile: four lanes fill the
+# device between them, and there the small tile's 4x weight traffic costs 161 -> 180 ms per B = 64 sample; the mid level (128
+# workgroups) loses 7-18 % alone (profiles/r04_v_small_tile_per_layer.txt).
+SMALL_TILE_WGS = int(os.environ.get("TQDNE_SMALL_TILE_WGS", "64")) if os.environ.get("TQDNE_SMALL_TILE", "1") != "0" else 0
+CONCURRENT_LANE0 = 8   # plan-cache lane ids from here on: sub-batch plans that run concurrently (see UNetModel._engine)
 
 
 class ConvRec:
@@ -276,10 +283,11 @@ class Probe:
 
 
 class UNetEngine:
-    def __init__(self, model, B: int, T: int, device: torch.device):
+    def __init__(self, model, B: int, T: int, device: torch.device, solo: bool = True):
         self.lib = _lib.load()
         self.m = model
         self.B, self.T, self.dev = B, T, device
+        self.solo = solo   # False: one of several plans that run concurrently (sampler / training lanes)
         reserve_side_streams(device)
         self.store = get_store(model, device)
         self._seen_pack = {}
@@ -410,7 +418,7 @@ class UNetEngine:
         srcs_c = [s0.C, (s1.C if s1 else 0)] + ([a.C for a in skip[0]] if skip is not None else [])
         wfmt = _lib.forward_wfmt(site.C_out, srcs_c, stride, upsample, fused_skip=skip is not None) if launch else 0
         # the small tile where it is built (see SMALL_TILE_B): the ResBlock convs of a small-batch plan
-        small = (launch and self.B <= SMALL_TILE_B and stride == 1 and not upsample and site.K == 5 and gn is not None and silu
+        small = (launch and (self.B <= SMALL_TILE_B or (self.solo and self.B * ((T_out + 127) // 128) <= SMALL_TILE_WGS)) and stride == 1 and not upsample and site.K == 5 and gn is not None and silu
                  and qkv_planes is None and wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX6) and not GN_FUSE)
         out = self._act(site.C_out, T_out, stats, slot=32 if small else STAT_SLOT) if launch else None
         d = TqConvDesc()

@@ -202,7 +202,9 @@ class UNetModel(nn.Module):
         key = (B, T, str(device), lane)
         eng = self._engine_cache.get(key)
         if eng is None:
-            eng = engine.UNetEngine(self, B, T, device)
+            # lanes >= engine.CONCURRENT_LANE0 are the sub-batch plans of a multi-lane sampler / training step: they run next to each
+            # other, so grid-filling choices made for a plan that has the device to itself do not apply to them
+            eng = engine.UNetEngine(self, B, T, device, solo=lane < engine.CONCURRENT_LANE0)
             self._engine_cache[key] = eng
         return eng
 
