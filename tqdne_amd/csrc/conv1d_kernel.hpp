@@ -131,7 +131,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
                   (TBW == 2 && (SCH == 0 || (SCH == 2 && WM == 4)) && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 1 && !PW),
                   "slim tile: bf16x3 forward, 2 x 2 waves; small tile (32 positions per workgroup): stride-1 forward, one wave column");
     static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH >= 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, fp16-range schemes");
-    static_assert(SCH != 2 || WN == 1, "scheme 2 tiles are 128 positions wide");
+    static_assert(SCH != 2 || WN == 1 || (WN == 2 && WM == 4 && TBW == 8 && STRIDE == 1 && UPS == 0 && EPI == 0 && !PW),
+                  "scheme 2 tiles are 128 positions wide (experiment: 128 channels x 256 positions, 8 waves)");
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef TQ_STAMP
@@ -1196,6 +1197,15 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
             }
             // (256-channel outputs as two co-resident 4-wave workgroups instead of one 8-wave one: measured 2-8 % slower per layer)
             if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
+#ifdef TQ_EXP_WN2
+            if constexpr (KT == 5 && UPS == 0 && EPI == 0 && ACT >= 2) {
+                // experiment: 128 channels x 256 positions in ONE 8-wave workgroup instead of two co-resident 4-wave ones -- the weights
+                // (C_in x 128 x 5 x 2.2 B per tile: 540 KB for 384 -> 128) are streamed from L2 once per 256 positions instead of 128
+                static const int wn2 = [] { const char* e = getenv("TQDNE_CONV_WN2"); return (e && e[0] == '1') ? 1 : 0; }();
+                if (wn2 && a.C_out % 128 == 0 && !(a.flags & TQ_CONV_POLY2) && a.T_out % 256 == 0)
+                    return launch<KT, STRIDE, UPS, 4, 2, EPI, ACT, FUSE, 2>(a, s);
+            }
+#endif
             if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 2>(a, s);
         }
         return TQ_ERR_SHAPE;
