@@ -809,14 +809,15 @@ def main():
         src_hash = hashlib.sha256(open(os.path.join(ROOT, "tqdne_amd", "csrc", "conv1d_kernel.hpp"), "rb").read()).hexdigest()[:16]
         if pmc and args.config == "paper" and B == 64 and T == 4096:
             try:
-                pj = json.load(open(pmc[-1]))
-                if pj.get("conv1d_mfma_sha16") == src_hash:
+                match = [f for f in pmc if json.load(open(f)).get("conv1d_mfma_sha16") == src_hash]   # (the newest one of THIS build)
+                if match:
+                    pj = json.load(open(match[-1]))
                     roofline["traffic"] = pj.get("hbm_traffic_bytes_per_launch")
-                    roofline["traffic_source"] = os.path.relpath(pmc[-1], ROOT)
+                    roofline["traffic_source"] = os.path.relpath(match[-1], ROOT)
                     roofline["algorithmic_bytes_per_launch"] = pj.get("algorithmic_bytes_per_launch")
                 else:
                     roofline["traffic_source"] = (os.path.relpath(pmc[-1], ROOT) + " is stale (recorded for another build of "
-                                                  "conv1d_mfma.hip): traffic not reported")
+                                                  "the conv kernel template): traffic not reported")
             except Exception:
                 pass
         nfe = 2 * args.sample_steps - 1

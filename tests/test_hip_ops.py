@@ -353,6 +353,24 @@ def test_head(cin, cout, T):
     assert rel_err(y2.cpu(), F.conv1d(x, w, b, padding=2)) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout,T,K", [(16, 1, 77, 5), (32, 2, 129, 3), (48, 2, 129, 3), (128, 3, 61, 1), (128, 4, 200, 5), (64, 3, 60, 5), (64, 3, 1, 5), (64, 6, 190, 5)])
+def test_head_other_shapes(cin, cout, T, K):
+    """the row-per-thread form (C_out <= 4) on ragged lengths (a wave emits 64 - (K - 1) outputs), every tap count and channel count
+    it is dispatched for, and the round-3 kernel for C_out > 4"""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + T + K)
+    B = 3
+    x = torch.randn(B, cin, T, generator=g)
+    a, s = torch.randn(B, cin, generator=g), torch.randn(B, cin, generator=g)
+    w, b = torch.randn(cout, cin, K, generator=g) / 10, torch.randn(cout, generator=g)
+    co, cs = torch.rand(B, generator=g), torch.rand(B, generator=g)
+    skip = torch.randn(B, cout, T, generator=g)
+    d = dev()
+    y = ops.head_conv(cl(x), w.to(d), b.to(d), a.to(d), s.to(d), co.to(d), cs.to(d), skip.to(d))
+    ref = F.conv1d(F.silu(x * a[:, :, None] + s[:, :, None]), w, b, padding=K // 2) * co[:, None, None] + cs[:, None, None] * skip
+    assert rel_err(y.cpu(), ref) < 1e-5
+
+
 def test_linear():
     from tqdne_amd import ops
     g = torch.Generator().manual_seed(1)

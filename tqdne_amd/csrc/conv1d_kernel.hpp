@@ -481,7 +481,28 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
     };
 
     f32x4 acc[2][TBW];
-    if constexpr (!PW) {
+    constexpr bool RES_EARLY = !PW && EPI == 0 && !FUSE && KT == 1;
+    if constexpr (RES_EARLY) {
+        // 1x1 convs (the attention block's x + proj(a): 256 single-round workgroups of load -> 0.4 us of MFMA -> residual load -> store):
+        // the residual (TQ_CONV_RES) is the accumulators' START value, so its load round trip hides behind the main loop instead of
+        // standing between the last MFMA and the stores: 31 -> 28 us per launch (B = 64, T = 512).  Measured neutral for the k = 5
+        // ResBlock convs (their prologue burst grows by what the epilogue saves), which keep the add in the epilogue.  Branch-free -- a
+        // wave-uniform branch here would end in s_waitcnt vmcnt(0) at its join: launches without a residual read one valid address.
+        const bool has_res = (p.flags & TQ_CONV_RES) && !(p.flags & TQ_CONV_POLY2) && (ct * C::MT + wm * 32) < p.C_out;
+        const float* rbase = has_res ? p.res : p.x0;
+#pragma unroll
+        for (int j = 0; j < TBW; ++j) {
+            const int t = t0 + wn * C::WT + j * 16 + (lane & 15);
+            const int tc = t < p.T_out ? t : p.T_out - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int co = ct * C::MT + wm * 32 + i * 16 + 4 * (lane >> 4);
+                const size_t o = has_res ? ((size_t)b * p.T_out + tc) * p.C_out + co : 0;
+                const float4 r = *reinterpret_cast<const float4*>(rbase + o);
+                acc[i][j] = has_res ? f32x4{r.x, r.y, r.z, r.w} : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    } else if constexpr (!PW) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -956,7 +977,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                 const size_t o = poly ? ((size_t)b * 2 * p.T_out + 2 * t + ph) * Cr + co : ((size_t)b * p.T_out + t) * p.C_out + co;
                 float4 v = make_float4(acc[cbk][tb][0] + add[cbk].x, acc[cbk][tb][1] + add[cbk].y,
                                        acc[cbk][tb][2] + add[cbk].z, acc[cbk][tb][3] + add[cbk].w);
-                if (p.flags & TQ_CONV_RES) {
+                if ((!RES_EARLY || poly) && (p.flags & TQ_CONV_RES)) {   // (RES_EARLY: it entered as the accumulators' start value)
                     const float4 r = *reinterpret_cast<const float4*>(p.res + o);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }

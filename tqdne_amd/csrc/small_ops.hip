@@ -290,6 +290,113 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
 }
 }  // namespace
 
+// Round 4, second form (C_out <= 4, C_in in {16, 32, 64, 128}: the EDM / autoencoder heads).  The kernel above reads every weight
+// from LDS once per input element and thread -- 5 ds_read_b128 per element for 20 FMAs, 22 us of LDS pipeline per B = 64 launch
+// (41-46 us measured for 67 MB).  Here a workgroup owns 64 consecutive input rows of one sample:
+//   1. all 256 threads stage the rows with fully coalesced 16-byte loads (a thread owns one 4-channel column: its folded GroupNorm
+//      pair stays in registers), activate them and park them in LDS ([row][C_in + 4]: conflict-free for step 2's reads);
+//   2. wave w takes channels [w C_in / 4, (w + 1) C_in / 4), lane = row: everything per channel -- the KT x C_out weights -- is
+//      wave-uniform, i.e. scalar loads straight from the (C_out, C_in, KT) weight tensor feeding the FMAs' scalar operand (one
+//      ds_read_b128 per 4 KT C_out FMAs instead of one per 4);
+//   3. the four waves' KT x C_out partial sums per row meet in LDS, where the tap shift is an address offset:
+//      output (j, co) = sum over waves and taps of partial[wave][k][co][row j + k]; a workgroup emits 64 - (KT - 1) outputs.
+// (Intermediate forms, B = 64 | 16, us: one wave per row set, rows read straight from global memory with a 256-byte lane stride
+// 39.2 | 22.8; the same with one wave per channel quarter 33.1 | 14.3; the LDS kernel 45.6 | 18.9.)
+namespace {
+template <int KT, int NCO>
+__global__ __launch_bounds__(256) void head_conv_row_kernel(const float* __restrict__ x, const float* __restrict__ gscale,
+                                                            const float* __restrict__ gshift, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ c_out,
+                                                            const float* __restrict__ c_skip, const float* __restrict__ skip_src,
+                                                            float* __restrict__ y, int T, int C_in, int ntiles) {
+    constexpr int PAD = KT / 2, NOUT = 64 - (KT - 1), NP = KT * NCO;
+    extern __shared__ __attribute__((aligned(16))) float shm[];
+    const int RS = C_in + 4;                    // floats per staged row
+    float* tile = shm;                          // [64][RS]
+    float* part = shm;                          // [4][NP][68]: takes the tile's place once every wave is done reading it
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x / ntiles, t0 = (blockIdx.x % ntiles) * NOUT;
+    // the epilogue's skip-connection operand: requested now, used after the last barrier
+    const int to = t0 + lane;
+    const bool emit = wave < NCO && lane < NOUT && to < T;
+    const size_t oo = ((size_t)b * NCO + (wave < NCO ? wave : 0)) * T + (to < T ? to : 0);
+    float skipv = 0.f;
+    if (c_out && emit) skipv = skip_src[oo];
+    // ---- 1. stage
+    {
+        const int ncol = C_in >> 2, rpp = 256 / ncol;   // 4-channel columns, rows per pass
+        const int c4 = threadIdx.x % ncol, r0 = threadIdx.x / ncol;
+        float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f), s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gscale) {
+            a4 = *reinterpret_cast<const float4*>(gscale + (size_t)b * C_in + 4 * c4);
+            s4 = *reinterpret_cast<const float4*>(gshift + (size_t)b * C_in + 4 * c4);
+        }
+        const float* xb = x + (size_t)b * T * C_in + 4 * c4;
+        for (int r = r0; r < 64; r += rpp) {
+            const int t = t0 - PAD + r;
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding of the ACTIVATED input
+            if (t >= 0 && t < T) {
+                u = *reinterpret_cast<const float4*>(xb + (size_t)t * C_in);
+                if (gscale) {
+                    u.x = silu_f(fmaf(a4.x, u.x, s4.x)); u.y = silu_f(fmaf(a4.y, u.y, s4.y));
+                    u.z = silu_f(fmaf(a4.z, u.z, s4.z)); u.w = silu_f(fmaf(a4.w, u.w, s4.w));
+                }
+            }
+            *reinterpret_cast<float4*>(tile + r * RS + 4 * c4) = u;
+        }
+    }
+    __syncthreads();
+    // ---- 2. lane = row, wave = channel quarter
+    const int cq = C_in >> 2;
+    const float* ur = tile + lane * RS + wave * cq;
+    float acc[KT][NCO];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) acc[k][co] = 0.f;
+    const float* wc[NCO];   // per output channel: this wave's (C_in / 4, KT) weight block -- the 4 KT weights of a step are consecutive
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) wc[co] = w + ((size_t)co * C_in + wave * cq) * KT;
+    // ONE 4-channel step per loop trip, not unrolled: with several steps in the body hipcc hoists all their scalar loads to the top
+    // of the trip and parks 240 scalars in VGPR lanes (210 v_readlane + 146 v_writelane per 120 packed FMAs)
+#pragma unroll 1
+    for (int c4 = 0; c4 < (cq >> 2); ++c4) {
+        const float4 v4 = *reinterpret_cast<const float4*>(ur + 4 * c4);
+        const float u[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) {
+            const float* wr = wc[co] + 4 * c4 * KT;   // wave-uniform: scalar loads
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < KT; ++k) acc[k][co] = fmaf(wr[e * KT + k], u[e], acc[k][co]);
+        }
+    }
+    // ---- 3. partial sums -> LDS, tap shift = address offset
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) {
+            float* pr = part + ((wave * NP) + k * NCO + co) * 68;
+            pr[lane] = acc[k][co];
+            if (lane < 4) pr[64 + lane] = 0.f;   // (read by the outputs the workgroup does not emit)
+        }
+    __syncthreads();
+    if (emit) {
+        const int co = wave;
+        float v = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) v += part[((wv * NP) + k * NCO + co) * 68 + lane + k];
+        if (c_out) v = v * c_out[b] + c_skip[b] * skipv;
+        y[oo] = v;
+    }
+}
+}  // namespace
+
 // dynamic LDS of head_conv_kernel for a shape, or 0 when the kernel is not built for it (the one place that knows the limits: the
 // launcher below and the plan builder, through tq_head_conv_lds_bytes, both ask here)
 static size_t head_conv_lds(int C_in, int C_out, int ktaps) {
@@ -309,6 +416,23 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
     if (c_out && (!c_skip || !skip_src)) return TQ_ERR_ARG;
     const size_t sh = head_conv_lds(C_in, C_out, ktaps);
     if (B <= 0 || T <= 0 || sh == 0) return TQ_ERR_SHAPE;
+    // TQDNE_HEAD_FWD=lds: the round-3 kernel for every shape (A/B switch)
+    static const int row_form = [] { const char* e = getenv("TQDNE_HEAD_FWD"); return (e && e[0] == 'l') ? 0 : 1; }();
+    if (row_form && C_out <= 4 && (C_in == 16 || C_in == 32 || C_in == 64 || C_in == 128)) {
+        const int nt = (T + (64 - (ktaps - 1)) - 1) / (64 - (ktaps - 1));
+        const size_t st_ = (size_t)64 * (C_in + 4), sp_ = (size_t)4 * ktaps * C_out * 68;
+        const size_t shr = (st_ > sp_ ? st_ : sp_) * sizeof(float);   // <= 34 KB (the partial sums reuse the staged tile's space)
+#define TQ_HEADR(K, N) hipLaunchKernelGGL((head_conv_row_kernel<K, N>), dim3(B * nt), dim3(256), shr, stream, x, gscale, gshift, w, bias, \
+                                          c_out, c_skip, skip_src, y, T, C_in, nt)
+#define TQ_HEADRK(K) { if (C_out == 1) TQ_HEADR(K, 1); else if (C_out == 2) TQ_HEADR(K, 2); else if (C_out == 3) TQ_HEADR(K, 3); else TQ_HEADR(K, 4); }
+        if (ktaps == 5) TQ_HEADRK(5)
+        else if (ktaps == 3) TQ_HEADRK(3)
+        else TQ_HEADRK(1)
+#undef TQ_HEADRK
+#undef TQ_HEADR
+        TQ_CHECK_LAUNCH();
+        return 0;
+    }
     const int nout = 128 - (ktaps - 1);   // output positions per workgroup (head_conv_kernel's NOUT)
     const int ntiles = (T + nout - 1) / nout;
     const int maxco = C_out <= 4 ? 4 : 16;
