@@ -181,8 +181,10 @@ int tq_conv1d_fwd_skip(const TqConvDesc* desc, const float* x0, const float* x1,
                        const float* skip_x1, const float* skip_bias, float* y, float* stats_partial, hipStream_t stream);
 
 /* Inference form of the AttentionBlock's qkv projection (blocks.py:127-145): 1x1 conv of GN(x) whose K and V output channels are
- * written directly as the pre-split bf16 planes tq_attention_fwd_presplit streams (K pre-scaled by D^-1/4), q as fp32 into
- * qkv (B, T, 3 H D) (its K / V part is left untouched).  kv_planes: tq_attention_workspace_bytes(B, T, H, D) bytes whose rows
+ * written directly as the pre-split planes tq_attention_fwd_presplit streams (K pre-scaled by D^-1/4: bf16 hi / lo; V: fp16 hi / lo,
+ * which that kernel multiplies by ONE fp16 softmax weight -- two products instead of three, 1.4e-4 of the output scale; values
+ * beyond the fp16 range become inf; TQDNE_ATTN_VF16=0 in the environment of both calls: bf16 hi / lo V, three products), q as fp32
+ * into qkv (B, T, 3 H D) (its K / V part is left untouched).  kv_planes: tq_attention_workspace_bytes(B, T, H, D) bytes whose rows
  * t >= T (padding to a multiple of 64) must be zero.  desc: ktaps 1, single source, C_out = 3 H D, flags none or TQ_CONV_GN. */
 int tq_conv1d_fwd_qkv(const TqConvDesc* desc, const float* x, const float* gscale, const float* gshift, const void* packed_w,
                       const float* bias, float* qkv, void* kv_planes, int H, int D, hipStream_t stream);

@@ -276,6 +276,57 @@ def test_attention(H, D, T):
     assert rel_err(ncw(out1), ref) < TOL
 
 
+@pytest.mark.parametrize("H,D,T,peaked", [(4, 64, 512, False), (2, 32, 190, False), (4, 64, 256, True), (1, 64, 64, False)])
+def test_qkv_conv_feeding_the_presplit_attention(H, D, T, peaked):
+    """The inference pair of an AttentionBlock (blocks.py:127-190): tq_conv1d_fwd_qkv writes q as fp32 and K / V as the attention
+    kernel's planes, tq_attention_fwd_presplit consumes them.  Default: V as fp16 hi / lo planes and ONE fp16 softmax weight (two
+    products: ~1e-4 of the output scale); TQDNE_ATTN_VF16=0: bf16 hi / lo V and P (three products: fp32-grade)."""
+    import ctypes as C
+    import os
+    from tqdne_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(H * D + T)
+    B, Cc = 2, H * D
+    d = dev()
+    x = torch.randn(B, T, Cc, generator=g)
+    gs, gh = torch.rand(B, Cc, generator=g) + 0.5, torch.randn(B, Cc, generator=g)
+    w = torch.randn(3 * Cc, Cc, 1, generator=g) / math.sqrt(Cc) * 1.5
+    bias = torch.randn(3 * Cc, generator=g) * 0.1
+    if peaked:   # one key row far outside the others' range: a softmax weight of ~1 next to many tiny ones
+        x[:, 77] *= 6.0
+    wfmt = _lib.forward_wfmt(3 * Cc, [Cc, 0])
+    wp = ops.pack_conv_weight(w.to(d), _lib.PACK_MODE[wfmt])
+    desc = _lib.TqConvDesc()
+    desc.B, desc.T_in, desc.T_out, desc.C_in0, desc.C_in1, desc.C_out = B, T, T, Cc, 0, 3 * Cc
+    desc.ktaps, desc.stride, desc.pad, desc.upsample = 1, 1, 0, 0
+    desc.flags, desc.wfmt = 1, wfmt   # TQ_CONV_GN
+    xd, gsd, ghd, bd = x.to(d), gs.to(d), gh.to(d), bias.to(d)
+    xin = x * gs[:, None, :] + gh[:, None, :]
+    qkv_ref = xin @ w[:, :, 0].T + bias
+    q, k, v = [t.reshape(B, T, H, D).permute(0, 2, 1, 3) for t in qkv_ref.split(Cc, dim=2)]
+    sc = 1 / math.sqrt(math.sqrt(D))
+    att = torch.softmax((q * sc) @ (k * sc).transpose(-1, -2), dim=-1)
+    ref = (att @ v).permute(0, 2, 1, 3).reshape(B, T, Cc)
+    p = lambda t: t.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+    errs = {}
+    for vf16 in ("1", "0"):
+        os.environ["TQDNE_ATTN_VF16"] = vf16
+        try:
+            qkv = torch.zeros(B, T, 3 * Cc, device=d)
+            ws = torch.zeros(lib.tq_attention_workspace_bytes(B, T, H, D), dtype=torch.uint8, device=d)
+            out = torch.empty(B, T, Cc, device=d)
+            assert lib.tq_conv1d_fwd_qkv(C.byref(desc), p(xd), p(gsd), p(ghd), p(wp), p(bd), p(qkv), p(ws), H, D, stream) == 0
+            assert lib.tq_attention_fwd_presplit(p(qkv), p(ws), p(out), B, T, H, D, stream) == 0
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["TQDNE_ATTN_VF16"]
+        assert rel_err(qkv[:, :, :Cc].cpu(), qkv_ref[:, :, :Cc]) < 2e-4   # (q: the conv's own fp16 + fp6 scheme)
+        errs[vf16] = rel_err(out.cpu(), ref)
+    print(f"attention pair H={H} D={D} T={T} peaked={peaked}: fp16 P / V {errs['1']:.2e}, bf16 hi / lo {errs['0']:.2e}")
+    assert errs["1"] < 5e-4 and errs["0"] < 2e-4
+
+
 def test_attention_peaked_softmax():
     """one key dominates one query: exercises the online-softmax rescale path across key tiles"""
     from tqdne_amd import ops

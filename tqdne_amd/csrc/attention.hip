@@ -327,7 +327,11 @@ extern "C" int tq_debug_read_att_timeline(unsigned long long* out, int n) {
 #define ATT_T(i)
 #endif
 
-template <int D>
+// VF16 (round 4; the inference pair tq_conv1d_fwd_qkv -> tq_attention_fwd_presplit): the V planes hold fp16 hi / lo instead of bf16
+// hi / lo and P enters the second product as ONE fp16 value (p <= 2^REF_TH, 11 significant bits: 1.4e-4 of the output scale on
+// random data against 1.3e-5 with the three bf16 products) -- O^T += V_hi^T P^T + V_lo^T P^T: two MFMAs instead of three per
+// (channel block, query block) and one packed conversion per two p instead of two splits per p.
+template <int D, bool VF16 = false>
 __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv,
                                                                 float* __restrict__ out, float* __restrict__ lse, int T, int Tp,
                                                                 int H, float scale) {
@@ -508,6 +512,30 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
             Frag ph[QB], pl[QB];
+            if constexpr (VF16) {
+                typedef _Float16 f16x8a __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    f16x8a pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (_Float16)st[2 * ks2 + (j >> 2)][qb][j & 3];
+                    ph[qb].u = __builtin_bit_cast(uint4, pf);
+                }
+                const int vrow = ks2 * 32 + 4 * g + ((lane >> 2) & 3);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    Frag bh, bl;
+                    const int off = vrow * ROWB + (cb * 16 + 4 * (lane & 3)) * 2;
+                    bh.h[0] = tr_read_f(v_hi + off); bh.h[1] = tr_read_f(v_hi + off + 16 * ROWB);
+                    bl.h[0] = tr_read_f(v_lo + off); bl.h[1] = tr_read_f(v_lo + off + 16 * ROWB);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        o[qb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8a, bh.u), __builtin_bit_cast(f16x8a, ph[qb].u), o[qb][cb], 0, 0, 0);
+                        o[qb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8a, bl.u), __builtin_bit_cast(f16x8a, ph[qb].u), o[qb][cb], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -584,6 +612,14 @@ int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int 
     if (sh > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd2_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int nqt = (T + 64 * ATT_QB - 1) / (64 * ATT_QB);
+    if (presplit && attn_vf16()) {   // (planes written by tq_conv1d_fwd_qkv: V in fp16 hi / lo)
+        if (sh > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd2_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL((attention_fwd2_kernel<D, true>), dim3(B * H * nqt), dim3(256), sh, stream, qkv,
+                           reinterpret_cast<const unsigned char*>(ws), out, lse, T, Tp, H, scale);
+        TQ_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(attention_fwd2_kernel<D>, dim3(B * H * nqt), dim3(256), sh, stream, qkv,
                        reinterpret_cast<const unsigned char*>(ws), out, lse, T, Tp, H, scale);
     TQ_CHECK_LAUNCH();

@@ -4,7 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace tq {
+
+// TQDNE_ATTN_VF16=0: the inference pair tq_conv1d_fwd_qkv -> tq_attention_fwd_presplit keeps V in bf16 hi / lo planes and P as a
+// bf16 hi / lo pair (three products, rounds 2-3) instead of fp16 V planes and ONE fp16 p (two products).  Read at every call (both
+// entry points must agree; plans hold no copy of it).
+inline bool attn_vf16() {
+    const char* e = getenv("TQDNE_ATTN_VF16");
+    return !(e && e[0] == '0');
+}
+
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

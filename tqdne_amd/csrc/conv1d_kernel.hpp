@@ -912,15 +912,28 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                 for (int cbk = 0; cbk < 2; ++cbk) {
                     const float v[4] = {acc[cbk][tb][0] + add[cbk].x, acc[cbk][tb][1] + add[cbk].y,
                                         acc[cbk][tb][2] + add[cbk].z, acc[cbk][tb][3] + add[cbk].w};
-                    bf16x4 hh, ll;
+                    if (sec == 2 && p.kv_vf16) {
+                        // V: fp16 hi / lo (attention_fwd2_kernel<D, true> multiplies both by ONE fp16 p); |v| > 65504 becomes inf and
+                        // surfaces in the output, like out-of-range inputs of the fp16-range convs
+                        f16x4 hh, ll;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        __bf16 a, c;
-                        split_bf16(v[j] * sc, a, c);
-                        hh[j] = a; ll[j] = c;
+                        for (int j = 0; j < 4; ++j) {
+                            hh[j] = (_Float16)v[j];
+                            ll[j] = (_Float16)(v[j] - (float)hh[j]);
+                        }
+                        hi[cbk] = __builtin_bit_cast(uint2, hh);
+                        lo[cbk] = __builtin_bit_cast(uint2, ll);
+                    } else {
+                        bf16x4 hh, ll;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            __bf16 a, c;
+                            split_bf16(v[j] * sc, a, c);
+                            hh[j] = a; ll[j] = c;
+                        }
+                        hi[cbk] = __builtin_bit_cast(uint2, hh);
+                        lo[cbk] = __builtin_bit_cast(uint2, ll);
                     }
-                    hi[cbk] = __builtin_bit_cast(uint2, hh);
-                    lo[cbk] = __builtin_bit_cast(uint2, ll);
                 }
                 const uint2 sh = odd ? hi[0] : hi[1], sl = odd ? lo[0] : lo[1];   // the block this lane gives away
                 uint2 rh, rl;

@@ -104,7 +104,7 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.fx0 = a.fx1 = a.fgs = a.fgh = nullptr; a.y1 = nullptr; a.OC0 = d->C_out; a.bflags = 0;
     a.sx0 = skip_x0; a.sx1 = skip_x1; a.sbias = skip_bias; a.sC0 = d->C_skip0; a.sC1 = d->C_skip1;
     a.wfmt = d->wfmt;
-    a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale;
+    a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale; a.kv_vf16 = (kv_planes && attn_vf16()) ? 1 : 0;
     a.range_flag = d->range_flag;
     a.in_amax = nullptr;
     a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
@@ -189,7 +189,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     } else if (d->wfmt != TQ_WFMT_BF16X3) {
         return TQ_ERR_ARG;
     }
-    a.kv = nullptr; a.kvH = a.kvD = a.kvTp = 0; a.kvscale = 1.f;
+    a.kv = nullptr; a.kvH = a.kvD = a.kvTp = 0; a.kvscale = 1.f; a.kv_vf16 = 0;
     a.range_flag = nullptr;
     a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
     a.gf_gamma = a.gf_beta = nullptr; a.gf_gscale = a.gf_gshift = a.gf_mean_rstd = nullptr;

@@ -40,6 +40,7 @@ struct ConvArgs {
     unsigned char* kv;
     int kvH, kvD, kvTp;
     float kvscale;
+    int kv_vf16;       // V planes as fp16 hi / lo (the attention kernel's one-fp16-p form) instead of bf16 hi / lo
     int* range_flag;  // see TqConvDesc.range_flag
     int t_tile;       // 0: the default tiles (128 / 256 positions per workgroup); 32: the small tile (TqConvDesc.t_tile)
     const uint32_t* in_amax;  // data gradient, TQ_WFMT_F16_MX6: bit pattern of max|dy| over the whole tensor (see TqConvBwdDesc.dy_amax)
