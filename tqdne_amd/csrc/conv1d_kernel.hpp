@@ -86,17 +86,19 @@ namespace {
 //      Staging layout: a thread owns 16 consecutive channels of a row (= exactly one lane fragment of the correction operand).
 // TBW: 16-position blocks per wave along t (8, or 4 for the "slim" 64-channel tile: half the accumulators, so that three or four
 // workgroups share a CU and their load / MFMA / store phases interleave -- see dispatch_tile)
-template <int KT, int STRIDE, int UPS, int WM, int WN, int SCH = 0, int TBW = 8>
+// NCB: 16-channel blocks per wave (2; 4 for the round-4 tile whose waves are 64 channels x 64 positions, see conv1d_mfma_kernel)
+template <int KT, int STRIDE, int UPS, int WM, int WN, int SCH = 0, int TBW = 8, int NCB = 2>
 struct Cfg {
     static constexpr int CH = SCH ? 64 : 32;     // channels per chunk
     static constexpr int ROWB = 2 * CH;          // bytes per row of one LDS plane
     static constexpr int TPR = (SCH == 2) ? 4 : CH / 4;  // staging threads per row (4 channels each; scheme 2: 16 channels each)
-    static constexpr int NW = SCH ? 8 : 4;       // 16-byte weight fragments per lane and (chunk, tap): 2 co blocks x NW/2
+    static constexpr int NWB = SCH ? 4 : 2;      // 16-byte weight fragments per lane, 16-channel block and (chunk, tap)
+    static constexpr int NW = NWB * NCB;         // ... per wave
     static constexpr int NBF = SCH ? 4 : 2;      // 16-byte activation fragments per lane and (tap, t-block)
     static constexpr int NTHR = 64 * WM * WN;
     static constexpr int WT = 16 * TBW;  // output positions per wave
     static constexpr int NT = WT * WN;   // output positions per workgroup
-    static constexpr int MT = 32 * WM;   // output channels per workgroup
+    static constexpr int MT = 16 * NCB * WM;   // output channels per workgroup
     static constexpr int ROWS = (STRIDE == 1) ? (NT + KT - 1) : (2 * NT + 1);
     static constexpr int NIT = (ROWS * TPR + NTHR - 1) / NTHR;
     // staging iterations prefetched into registers across the MFMA phase.  The 4-wave tile of scheme 1 stages twice as many rows
@@ -123,17 +125,22 @@ struct Cfg {
 // is staged ONCE into its own LDS buffers with every load in flight together, then the workgroup runs over all output-channel
 // tiles: no per-chunk barrier / load round trip (a 1x1 chunk has 1/5 of the MFMA work to hide one under) and no re-staging of
 // the same rows by 3 channel-tile workgroups (qkv).
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false, int TBW = 8>
-__global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_kernel(const ConvArgs p) {
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false, int TBW = 8, int NCB = 2>
+__global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) void conv1d_mfma_kernel(const ConvArgs p) {
     static_assert(SCH == 0 || STRIDE == 1, "the fp16-range schemes serve stride-1 launches");
     static_assert(EPI != 1 || SCH == 0 || (SCH == 2 && ACT == 0 && !FUSE && !PW), "data gradients: bf16x3, or fp16 + MX-fp6 on a dy scaled into the fp16 range");
-    static_assert(TBW == 8 || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW) ||
+    // NCB == 4 (round 4): 256 channels x 128 positions as 4 x 2 waves of 64 channels x 64 positions -- every activation fragment read
+    // from LDS feeds twelve MFMAs instead of six (tools/micro/mfma_shape_power.hip: at full load the conv's 4 ds_read_b128 per 6 MFMAs
+    // cost a quarter of the matrix rate; 16 reads + 16 weight loads per 48 MFMAs run 13 % faster than 32 + 8)
+    static_assert(NCB == 2 || (NCB == 4 && TBW == 4 && WM == 4 && WN == 2 && SCH == 2 && KT > 1 && STRIDE == 1 && UPS == 0 && EPI == 0 && !FUSE && !PW),
+                  "64-channel waves: the fp16 + MX-fp6 forward tile of 256 x 128");
+    static_assert(TBW == 8 || (TBW == 4 && NCB == 4) || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW) ||
                   (TBW == 2 && (SCH == 0 || (SCH == 2 && WM == 4)) && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 1 && !PW),
                   "slim tile: bf16x3 forward, 2 x 2 waves; small tile (32 positions per workgroup): stride-1 forward, one wave column");
     static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH >= 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, fp16-range schemes");
-    static_assert(SCH != 2 || WN == 1 || (WN == 2 && WM == 4 && TBW == 8 && STRIDE == 1 && UPS == 0 && EPI == 0 && !PW),
+    static_assert(SCH != 2 || WN == 1 || NCB == 4 || (WN == 2 && WM == 4 && TBW == 8 && STRIDE == 1 && UPS == 0 && EPI == 0 && !PW),
                   "scheme 2 tiles are 128 positions wide (experiment: 128 channels x 256 positions, 8 waves)");
-    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW>;
+    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW, NCB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 #ifdef TQ_STAMP
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
     }
     // per-sample key of the dropout hash (scalar unit; only the dropout prologue / the data gradient's dropout chain read it)
     const uint32_t dkey = (ACT == 3 || EPI == 1) ? drop_key(p.drop_seed, p.drop_site, (uint32_t)b) : 0u;
-    int co_wave = ct * C::MT + wm * 32;
+    int co_wave = ct * C::MT + wm * (16 * NCB);
     const bool wave_active = co_wave < p.C_out;
 
     const int Cin = p.C0 + p.C1;
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
         }
     };
 
-    f32x4 acc[2][TBW];
+    f32x4 acc[NCB][TBW];
     constexpr bool RES_EARLY = !PW && EPI == 0 && !FUSE && KT == 1;
     if constexpr (RES_EARLY) {
         // 1x1 convs (the attention block's x + proj(a): 256 single-round workgroups of load -> 0.4 us of MFMA -> residual load -> store):
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
         }
     } else if constexpr (!PW) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NCB; ++i)
 #pragma unroll
             for (int j = 0; j < TBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -512,8 +519,8 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
 
     const int kq = lane >> 4;
     const int tl_lane = wn * C::WT + (lane & 15);
-    const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * (C::NW / 2)) * 64 + lane;  // (PW: advanced per channel tile)
-    const size_t wstep = (size_t)p.ncob_pad * (C::NW / 2) * 64;  // uint4 per (chunk, tap)
+    const uint4* wbase = p.wpk + ((size_t)(co_wave >> 4) * C::NWB) * 64 + lane;  // (PW: advanced per channel tile)
+    const size_t wstep = (size_t)p.ncob_pad * C::NWB * 64;  // uint4 per (chunk, tap)
 
     // ---- MFMA phase of one chunk.  Written as straight-line code (no branches inside: hipcc's waitcnt insertion falls back to
     // s_waitcnt vmcnt(0) / lgkmcnt(0) at every control-flow join, which serialises each prefetch with its consumer) and pinned
@@ -581,13 +588,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
                               (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
             const f16x8 b0v = __builtin_bit_cast(f16x8, f[0].u), b1v = __builtin_bit_cast(f16x8, f[1].u);
 #pragma unroll
-            for (int cbk = 0; cbk < 2; ++cbk)
+            for (int cbk = 0; cbk < NCB; ++cbk)
                 acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 0].u), b0v, acc[cbk][tb], 0, 0, 0);
 #pragma unroll
-            for (int cbk = 0; cbk < 2; ++cbk)
+            for (int cbk = 0; cbk < NCB; ++cbk)
                 acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 1].u), b1v, acc[cbk][tb], 0, 0, 0);
 #pragma unroll
-            for (int cbk = 0; cbk < 2; ++cbk) {
+            for (int cbk = 0; cbk < NCB; ++cbk) {
                 const Frag& c0 = w[cbk * 4 + 2];
                 const Frag& c1 = w[cbk * 4 + 3];
                 const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
     // Weight fragments live in two register buffers (taps alternate a, b, a, ...); after tap k its buffer is refilled with
     // tap k+2 of this chunk or, wrapping, with the next chunk's tap of the same parity, so every chunk starts with a = tap 0,
     // b = tap 1 already in flight.
-    Frag wa[C::NW], wb[C::NW];
+    Frag wa[C::NW], wb[NCB == 4 ? 1 : C::NW];   // (64-channel waves: ONE buffer, see mma_stream1)
 #ifndef TQ_LDS_DEPTH2
 #define TQ_LDS_DEPTH2 1
 #endif
@@ -641,6 +648,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
     // MFMAs that consume them, across tap boundaries too (a per-tap restart exposed the LDS latency KT times per chunk).
     auto mma_stream = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int s0, auto ntaps_c, auto first_tap_c)
         __attribute__((always_inline)) {
+        if constexpr (NCB == 2) {
         constexpr int NTAPS = decltype(ntaps_c)::value, K0 = decltype(first_tap_c)::value;
         constexpr int DEP = LDS_DEP, NB = LDS_DEP + 1, NS = NTAPS * TBW;
         Frag bf[NB][C::NBF];
@@ -663,11 +671,58 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }
+    };
+
+    // 64-channel waves (NCB == 4): the KT x TBW steps of a chunk with the tap's sixteen weight fragments in ONE register buffer.  A
+    // block's four fragments are replaced by the next (chunk, tap) step's as soon as the tap's last t-block has issued that block's
+    // MFMAs; the wave then waits for them at the next tap's first step (hipcc's counted vmcnt) -- a stall of one L2 round trip per
+    // tap that the SIMD's other wave covers with its own MFMAs (the older wave of a SIMD wins MFMA issue, so the two alternate by
+    // themselves; a second buffer would be 64 more registers).  Activation fragments are read one step ahead.
+    auto mma_block2 = [&](const Frag (&w)[C::NW], const Frag (&f)[C::NBF], int tb, int cbk) __attribute__((always_inline)) {
+        const i32x8 bc = {(int)f[2].u.x, (int)f[2].u.y, (int)f[2].u.z, (int)f[2].u.w,
+                          (int)f[3].u.x, (int)f[3].u.y, (int)f[3].u.z, (int)f[3].u.w};
+        acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 0].u), __builtin_bit_cast(f16x8, f[0].u), acc[cbk][tb], 0, 0, 0);
+        acc[cbk][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[cbk * 4 + 1].u), __builtin_bit_cast(f16x8, f[1].u), acc[cbk][tb], 0, 0, 0);
+        const Frag& c0 = w[cbk * 4 + 2];
+        const Frag& c1 = w[cbk * 4 + 3];
+        const i32x8 ac = {(int)c0.u.x, (int)c0.u.y, (int)c0.u.z, (int)c0.u.w, (int)c1.u.x, (int)c1.u.y, (int)c1.u.z, (int)c1.u.w};
+        acc[cbk][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ac, bc, acc[cbk][tb], 2, 2, 0, (int)c1.u.z, 0, (int)f[3].u.z);
+    };
+    auto mma_stream1 = [&](const unsigned char* hi_plane, const unsigned char* lo_plane, int s0) __attribute__((always_inline)) {
+        if constexpr (NCB == 4 && SCH == 2) {
+            constexpr int NS = KT * TBW;
+            Frag bf[2][C::NBF];
+            int b0 = tap_base(0), b0n = b0;
+            read_b(hi_plane, lo_plane, b0, 0, bf[0]);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int kk = st / TBW, tb = st % TBW;
+                if (tb == 0 && kk + 1 < KT) b0n = tap_base(kk + 1);
+                if (st + 1 < NS) read_b(hi_plane, lo_plane, ((st + 1) / TBW) == kk ? b0 : b0n, (st + 1) % TBW, bf[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tb < TBW - 1) {
+                    mma_step(wa, bf[st & 1], tb);
+                } else {
+                    const int nx = s0 + kk + 1 < last_step ? s0 + kk + 1 : last_step;   // (the final refill re-reads the last fragments)
+                    const uint4* wp = wbase + (size_t)nx * wstep;
+#pragma unroll
+                    for (int cbk = 0; cbk < NCB; ++cbk) {
+                        mma_block2(wa, bf[st & 1], tb, cbk);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) wa[cbk * 4 + q].u = wp[(cbk * 4 + q) * 64];
+                    }
+                    b0 = b0n;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
 
     auto compute = [&](int chunk, int buf) __attribute__((always_inline)) {
         const unsigned char* hi_plane = lds + buf * C::BUF;
-        mma_stream(hi_plane, hi_plane + C::PLANE, chunk * KT, std::integral_constant<int, KT>{}, std::integral_constant<int, 0>{});
+        if constexpr (NCB == 4) mma_stream1(hi_plane, hi_plane + C::PLANE, chunk * KT);
+        else mma_stream(hi_plane, hi_plane + C::PLANE, chunk * KT, std::integral_constant<int, KT>{}, std::integral_constant<int, 0>{});
     };
 
     // skip stage j: one (centre) tap.  Buffer a holds this step's weights and b the next one's (the last main chunk's
@@ -688,9 +743,11 @@ __global__ __launch_bounds__(64 * WM * WN, (TBW == 4 ? 3 : 2)) void conv1d_mfma_
             mma_step(wa, bf[tb % NB], tb);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (NCB == 2) {
 #pragma unroll
-        for (int q = 0; q < C::NW; ++q) wa[q] = wb[q];
-        load_w(nchunks * KT + j + 2, wb);
+            for (int q = 0; q < C::NW; ++q) wa[q] = wb[q];
+            load_w(nchunks * KT + j + 2, wb);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -757,7 +814,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
         }
         // the next channel tile's first weights are requested BEFORE this tile's stores: vmcnt retires in order, behind the
         // stores they would only arrive once the whole output tile has drained
-        if (pass + 1 < npass) wbase += (size_t)(C::MT >> 4) * (C::NW / 2) * 64;
+        if (pass + 1 < npass) wbase += (size_t)(C::MT >> 4) * C::NWB * 64;
         load_w(0, wa);
         load_w(1, wb);
         __builtin_amdgcn_sched_barrier(0);
@@ -766,7 +823,9 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
         stage_load(0);
         if (wave_active) {
             load_w(0, wa);
-            if (KT > 1 || nskip > 0) load_w(1, wb);
+            if constexpr (NCB == 2) {
+                if (KT > 1 || nskip > 0) load_w(1, wb);
+            }
         }
         stage_write(0, 0);
         __syncthreads();
@@ -962,10 +1021,10 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
     // The two 16-channel blocks of a wave are the two 64-byte halves of one 128-byte output line: they are stored back to back
     // (t-block outer, channel block inner).  With the channel block as the outer loop the halves reached L2 microseconds apart
     // and PMC showed 1.46x the output bytes written to HBM.
-    float4 add[2];
-    float s1[2][4], s2[2][4];
+    float4 add[NCB];
+    float s1[NCB][4], s2[NCB][4];
 #pragma unroll
-    for (int cbk = 0; cbk < 2; ++cbk) {
+    for (int cbk = 0; cbk < NCB; ++cbk) {
         const int co = co_real + cbk * 16 + 4 * (lane >> 4);
         add[cbk] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) add[cbk] = *reinterpret_cast<const float4*>(p.bias + co);
@@ -985,7 +1044,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
         const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
         if (t < p.T_out) {
 #pragma unroll
-            for (int cbk = 0; cbk < 2; ++cbk) {
+            for (int cbk = 0; cbk < NCB; ++cbk) {
                 const int co = co_real + cbk * 16 + 4 * (lane >> 4);
                 const size_t o = poly ? ((size_t)b * 2 * p.T_out + 2 * t + ph) * Cr + co : ((size_t)b * p.T_out + t) * p.C_out + co;
                 float4 v = make_float4(acc[cbk][tb][0] + add[cbk].x, acc[cbk][tb][1] + add[cbk].y,
@@ -1005,7 +1064,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
     }
     if (p.flags & TQ_CONV_STATS) {
 #pragma unroll
-        for (int cbk = 0; cbk < 2; ++cbk) {
+        for (int cbk = 0; cbk < NCB; ++cbk) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -1019,23 +1078,23 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             // slim tile: the two waves of a channel half cover the two 64-position halves of ONE 128-position statistics slot; the
             // second one hands its sums over through LDS (the staging buffers are idle) and the first one stores the slot's total
             __syncthreads();
-            float* red = reinterpret_cast<float*>(lds) + (wm * 4 + (lane >> 4)) * 16;   // [wm][kq][cbk][j][2]
+            float* red = reinterpret_cast<float*>(lds) + (wm * 4 + (lane >> 4)) * (8 * NCB);   // [wm][kq][cbk][j][2]
             if (wn == 1 && (lane & 15) == 0) {
 #pragma unroll
-                for (int cbk = 0; cbk < 2; ++cbk)
+                for (int cbk = 0; cbk < NCB; ++cbk)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { red[(cbk * 4 + j) * 2] = s1[cbk][j]; red[(cbk * 4 + j) * 2 + 1] = s2[cbk][j]; }
             }
             __syncthreads();
             if (wn == 0 && (lane & 15) == 0) {
 #pragma unroll
-                for (int cbk = 0; cbk < 2; ++cbk)
+                for (int cbk = 0; cbk < NCB; ++cbk)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { s1[cbk][j] += red[(cbk * 4 + j) * 2]; s2[cbk][j] += red[(cbk * 4 + j) * 2 + 1]; }
             }
         }
 #pragma unroll
-        for (int cbk = 0; cbk < 2; ++cbk) {
+        for (int cbk = 0; cbk < NCB; ++cbk) {
             const int co = co_real + cbk * 16 + 4 * (lane >> 4);
             if ((lane & 15) == 0 && slot < p.nslots && (TBW == 8 || wn == 0)) {
                 float* st = p.stats + (((size_t)b * p.nslots + slot) * Cr + co) * 2;
@@ -1183,10 +1242,10 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
 #endif
 }
 
-template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH = 0, bool PW = false, int TBW = 8>
+template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH = 0, bool PW = false, int TBW = 8, int NCB = 2>
 int launch(const ConvArgs& a, hipStream_t stream) {
-    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW>;
-    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW, TBW>;
+    using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW, NCB>;
+    auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW, TBW, NCB>;
     // scheme 2 keeps the folded GroupNorm coefficients of the workgroup's sample behind the staging buffers (2 x C_in floats)
     constexpr int GTAB_MAX = (SCH == 2 && ACT >= 1) ? 2 * 4 * 1024 : 0;   // room for C_in <= 1024
     constexpr int LDS_BYTES = (PW ? 4 * C::BUF : C::LDS_BYTES) + GTAB_MAX;
@@ -1258,6 +1317,17 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
                     return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2, true>(a, s);
             }
             // (256-channel outputs as two co-resident 4-wave workgroups instead of one 8-wave one: measured 2-8 % slower per layer)
+#ifdef TQ_EXP_NCB4
+            if constexpr (KT > 1 && UPS == 0 && EPI == 0 && !FUSE) {
+                // experiment (-DTQ_EXP_NCB4, TQDNE_CONV_NCB4=1): 4 x 2 waves of 64 channels x 64 positions instead of 8 x 1 of 32 x 128 --
+                // half the LDS reads per MFMA, ONE weight buffer.  Bit-identical convolution, 10-14 % SLOWER (87 -> 99 us, 256 -> 256,
+                // T = 1024): with one buffer a weight wait stands at every tap, and vmcnt retires in order, so the first of them also
+                // waits for the chunk's staging loads issued at the start of the phase (tools/experiments/ncb4_ab.py)
+                static const int ncb4 = [] { const char* e = getenv("TQDNE_CONV_NCB4"); return (e && e[0] == '1') ? 1 : 0; }();
+                if (ncb4 && a.C_out % 256 == 0 && !(a.flags & TQ_CONV_POLY2))
+                    return launch<KT, STRIDE, UPS, 4, 2, EPI, ACT, FUSE, 2, false, 4, 4>(a, s);
+            }
+#endif
             if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
 #ifdef TQ_EXP_WN2
             if constexpr (KT == 5 && UPS == 0 && EPI == 0 && ACT >= 2) {
