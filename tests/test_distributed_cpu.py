@@ -183,6 +183,26 @@ def test_forced_exchange_over_one_rank_is_the_identity():
     assert ret[0]
 
 
+def _ipg_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from tqdne_amd.trainer import init_process_group
+    init_process_group("gloo", device=None, rank=rank, world_size=world)   # (CPU: nothing to reserve, plain torch call)
+    t = torch.ones(1) * (rank + 1)
+    dist.all_reduce(t)
+    ret[rank] = float(t)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_init_process_group_helper_passes_through_on_cpu():
+    """tqdne_amd.trainer.init_process_group = torch's call behind the side-stream reservation a ROCm device needs first"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ipg_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == ret[1] == 3.0
+
+
 def test_rank_seeding_gives_distinct_reproducible_streams():
     from tqdne_amd import rng
     seeds = {}
