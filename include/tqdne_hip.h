@@ -25,7 +25,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define TQ_ABI_VERSION 5
+#define TQ_ABI_VERSION 6
 
 #define TQ_ERR_ARG (-1)   /* null / inconsistent pointer arguments */
 #define TQ_ERR_SHAPE (-2) /* unsupported shape */
@@ -181,13 +181,19 @@ int tq_conv1d_fwd_skip(const TqConvDesc* desc, const float* x0, const float* x1,
                        const float* skip_x1, const float* skip_bias, float* y, float* stats_partial, hipStream_t stream);
 
 /* Inference form of the AttentionBlock's qkv projection (blocks.py:127-145): 1x1 conv of GN(x) whose K and V output channels are
- * written directly as the pre-split planes tq_attention_fwd_presplit streams (K pre-scaled by D^-1/4: bf16 hi / lo; V: fp16 hi / lo,
- * which that kernel multiplies by ONE fp16 softmax weight -- two products instead of three, 1.4e-4 of the output scale; values
- * beyond the fp16 range become inf; TQDNE_ATTN_VF16=0 in the environment of both calls: bf16 hi / lo V, three products), q as fp32
- * into qkv (B, T, 3 H D) (its K / V part is left untouched).  kv_planes: tq_attention_workspace_bytes(B, T, H, D) bytes whose rows
- * t >= T (padding to a multiple of 64) must be zero.  desc: ktaps 1, single source, C_out = 3 H D, flags none or TQ_CONV_GN. */
+ * written directly as the pre-split planes tq_attention_fwd_presplit streams (K pre-scaled by D^-1/4: bf16 hi / lo; V in
+ * `v_format`, which both calls of the pair must be given alike), q as fp32 into qkv (B, T, 3 H D) (its K / V part is left
+ * untouched).  kv_planes: tq_attention_workspace_bytes(B, T, H, D) bytes whose rows t >= T (padding to a multiple of 64) must be
+ * zero.  desc: ktaps 1, single source, C_out = 3 H D, flags none or TQ_CONV_GN.
+ * v_format (ABI 6; was the environment variable TQDNE_ATTN_VF16 read inside the library):
+ *   TQ_KV_V_F16: V as fp16 hi / lo planes, which the attention kernel multiplies by ONE fp16 softmax weight -- two products instead
+ *     of three, 1.4e-4 of the output scale.  fp16 RANGE: with desc->range_flag set the epilogue raises it when |v| reaches half of
+ *     the fp16 range (or is not finite), exactly like the fp16-range conv schemes; the caller repeats with TQ_KV_V_BF16;
+ *   TQ_KV_V_BF16: bf16 hi / lo V, three products, fp32 range. */
+#define TQ_KV_V_BF16 0
+#define TQ_KV_V_F16 1
 int tq_conv1d_fwd_qkv(const TqConvDesc* desc, const float* x, const float* gscale, const float* gshift, const void* packed_w,
-                      const float* bias, float* qkv, void* kv_planes, int H, int D, hipStream_t stream);
+                      const float* bias, float* qkv, void* kv_planes, int H, int D, int v_format, hipStream_t stream);
 
 /* Data gradient of tq_conv1d_fwd (stride 1): g = (W^T * dy) chained through the forward prologue (dropout, SiLU,
  * folded GN scale); packed_w_t from tq_pack_conv_weight(mode 1).  x0/x1/gscale/gshift are the FORWARD conv's inputs.
@@ -321,7 +327,8 @@ int tq_attention_fwd(const float* qkv, float* out, float* lse /* (B,H,T) log-sum
 /* backward of the above (recomputes P from qkv and lse): dqkv (B, T, 3*H*D) from dout (B, T, H*D);
  * delta (B,H,T) is scratch.  Two passes: queries-stationary for dq, keys-stationary for dk/dv (no atomics). */
 /* attention core on q from qkv and K / V planes already written by tq_conv1d_fwd_qkv (no log-sum-exp output: inference) */
-int tq_attention_fwd_presplit(const float* qkv, const void* kv_planes, float* out, int B, int T, int H, int D, hipStream_t stream);
+int tq_attention_fwd_presplit(const float* qkv, const void* kv_planes, float* out, int B, int T, int H, int D, int v_format,
+                              hipStream_t stream);
 int tq_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv, int B,
                      int T, int H, int D, hipStream_t stream);
 /* the same with a scratch buffer of 2 * tq_attention_workspace_bytes(): second-generation kernels for D = 32 / 64 (one prep pass

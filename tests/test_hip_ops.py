@@ -310,21 +310,32 @@ def test_qkv_conv_feeding_the_presplit_attention(H, D, T, peaked):
     p = lambda t: t.data_ptr()
     stream = torch.cuda.current_stream().cuda_stream
     errs = {}
+    flag = torch.zeros(1, dtype=torch.int32, device=d)
+    desc.range_flag = flag.data_ptr()
     for vf16 in ("1", "0"):
-        os.environ["TQDNE_ATTN_VF16"] = vf16
-        try:
-            qkv = torch.zeros(B, T, 3 * Cc, device=d)
-            ws = torch.zeros(lib.tq_attention_workspace_bytes(B, T, H, D), dtype=torch.uint8, device=d)
-            out = torch.empty(B, T, Cc, device=d)
-            assert lib.tq_conv1d_fwd_qkv(C.byref(desc), p(xd), p(gsd), p(ghd), p(wp), p(bd), p(qkv), p(ws), H, D, stream) == 0
-            assert lib.tq_attention_fwd_presplit(p(qkv), p(ws), p(out), B, T, H, D, stream) == 0
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["TQDNE_ATTN_VF16"]
+        vfmt = _lib.TQ_KV_V_F16 if vf16 == "1" else _lib.TQ_KV_V_BF16
+        qkv = torch.zeros(B, T, 3 * Cc, device=d)
+        ws = torch.zeros(lib.tq_attention_workspace_bytes(B, T, H, D), dtype=torch.uint8, device=d)
+        out = torch.empty(B, T, Cc, device=d)
+        assert lib.tq_conv1d_fwd_qkv(C.byref(desc), p(xd), p(gsd), p(ghd), p(wp), p(bd), p(qkv), p(ws), H, D, vfmt, stream) == 0
+        assert lib.tq_attention_fwd_presplit(p(qkv), p(ws), p(out), B, T, H, D, vfmt, stream) == 0
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0   # (V well inside the fp16 range: the guard stays down)
         assert rel_err(qkv[:, :, :Cc].cpu(), qkv_ref[:, :, :Cc]) < 2e-4   # (q: the conv's own fp16 + fp6 scheme)
         errs[vf16] = rel_err(out.cpu(), ref)
     print(f"attention pair H={H} D={D} T={T} peaked={peaked}: fp16 P / V {errs['1']:.2e}, bf16 hi / lo {errs['0']:.2e}")
     assert errs["1"] < 5e-4 and errs["0"] < 2e-4
+    # the V planes' range guard (ABI 6): a bias that lifts one V channel to 4e4 raises the flag in the fp16 format only
+    if not peaked:
+        big = bias.clone()
+        big[2 * Cc + 3] = 4.0e4
+        bigd = big.to(d)
+        for vfmt, want in ((_lib.TQ_KV_V_BF16, 0), (_lib.TQ_KV_V_F16, 1)):
+            flag.zero_()
+            assert lib.tq_conv1d_fwd_qkv(C.byref(desc), p(xd), p(gsd), p(ghd), p(wp), p(bigd), p(qkv), p(ws), H, D, vfmt, stream) == 0
+            torch.cuda.synchronize()
+            assert int(flag.item()) == want, (vfmt, int(flag.item()))
+        assert lib.tq_conv1d_fwd_qkv(C.byref(desc), p(xd), p(gsd), p(ghd), p(wp), p(bd), p(qkv), p(ws), H, D, 7, stream) == -1  # TQ_ERR_ARG
 
 
 def test_attention_peaked_softmax():

@@ -548,12 +548,12 @@ def test_inference_forward_matches_backward_capable_forward(which):
     finally:
         del os.environ["TQDNE_POLYPHASE_UPSAMPLE"]
     a = eng.forward(x, t, cond).clone()
-    # (TQDNE_ATTN_VF16=0: the inference pair keeps V as bf16 hi / lo planes and P as a bf16 hi / lo pair, as the default plan does)
-    os.environ["TQDNE_ATTN_VF16"] = "0"
-    try:
-        b = eng.forward(x, t, cond, infer=True).clone()
-    finally:
-        del os.environ["TQDNE_ATTN_VF16"]
+    # (TQ_KV_V_BF16: the inference pair keeps V as bf16 hi / lo planes and P as a bf16 hi / lo pair, as the training forward does)
+    from tqdne_amd import _lib
+    assert eng.kv_v_format == _lib.TQ_KV_V_F16
+    eng.set_kv_v_format(_lib.TQ_KV_V_BF16)
+    b = eng.forward(x, t, cond, infer=True).clone()
+    eng.set_kv_v_format(_lib.TQ_KV_V_F16)
     assert torch.equal(a, b)
     # default inference form of the attention core: V as fp16 hi / lo planes, P as ONE fp16 value -- two products instead of
     # three; 1.4e-4 of the attention output's scale on random data, less at the UNet's output
@@ -568,11 +568,9 @@ def test_inference_forward_matches_backward_capable_forward(which):
     # un-upsampled length is a multiple of 128): same sums in a different order -> fp32-rounding-level differences only
     eng2 = net._engine(B, T, dev())
     a2 = eng2.forward(x, t, cond).clone()
-    os.environ["TQDNE_ATTN_VF16"] = "0"
-    try:
-        b2 = eng2.forward(x, t, cond, infer=True).clone()
-    finally:
-        del os.environ["TQDNE_ATTN_VF16"]
+    eng2.set_kv_v_format(_lib.TQ_KV_V_BF16)
+    b2 = eng2.forward(x, t, cond, infer=True).clone()
+    eng2.set_kv_v_format(_lib.TQ_KV_V_F16)
     assert torch.equal(a2, a)
     npoly = sum(op[2].endswith("+polyphase") for op in eng2.ops_infer)
     assert npoly == (3 if which == "paper" else 0)
@@ -650,3 +648,33 @@ def test_sampler_does_not_retain_start_state():
         assert used[-1] - used[1] < 100_000, used
     finally:
         gc.enable()
+
+
+def test_conv_scheme_bf16x3_moves_the_data_gradients_too(monkeypatch):
+    """TQDNE_CONV_SCHEME=bf16x3 is the documented fp32-range switch: forward convs AND data gradients must then run the three-product
+    scheme (round-4 advisor finding: the data gradients kept fp16-packed weights).  The default leaves f16+mx6 data gradients on."""
+    from tqdne_amd import LightningEDM, _lib, tiny_1d_unet_config
+    cfg = dict(tiny_1d_unet_config(), model_channels=128, dropout=0.0)   # (128 | C_in so that the mx6 data gradient is eligible)
+    g = torch.Generator().manual_seed(5)
+    B, T = 2, 512
+    sig, cond = 0.5 * torch.randn(B, 3, T, generator=g), torch.randn(B, 5, generator=g)
+    eps, noise = torch.randn(B, generator=g), torch.randn(B, 3, T, generator=g)
+    grads = {}
+    for scheme in ("f16mx6", "bf16x3"):
+        monkeypatch.setenv("TQDNE_CONV_SCHEME", scheme)
+        torch.manual_seed(0)
+        edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
+        edm.unet.load_state_dict(perturbed_state(edm.unet, 3))
+        edm = edm.to(dev()).train()
+        loss = edm.step_with_noise(sig.to(dev()), eps.to(dev()), noise.to(dev()), cond=cond.to(dev()) if cfg["cond_features"] else None)
+        loss.backward()
+        eng = edm.unet._engine(B, T, dev())
+        wf = [d.wfmt for d in eng._bwd.dgrad_descs]
+        assert wf, "no data-gradient descriptors recorded"
+        if scheme == "bf16x3":
+            assert all(w == _lib.TQ_WFMT_BF16X3 for w in wf), wf
+            assert all(d.wfmt == _lib.TQ_WFMT_BF16X3 for d, _s, _p in eng._wfmt_sites)
+        else:
+            assert any(w == _lib.TQ_WFMT_F16_MX6 for w in wf), wf
+        grads[scheme] = torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]).cpu()
+    assert rel_err(grads["f16mx6"], grads["bf16x3"]) < TOL

@@ -155,3 +155,27 @@ def test_hardware_queue_default_is_set_before_the_device_is_touched():
     import os
     import tqdne_amd  # noqa: F401
     assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 8
+
+
+def test_plan_cache_is_bounded_and_evicts_least_recently_used_shape_groups():
+    """tqdne_amd/_cache.py: the plans of a model are cached per (B, T, device, lane); the cache keeps the most recently used
+    (B, T, device) GROUPS (all lanes of a shape together) and tells its owner which keys went (round-4 verdict: the cache was unbounded)."""
+    from tqdne_amd._cache import PlanCache, plan_cache, PLAN_SHAPES
+    gone = []
+    c = PlanCache(3, group=lambda k: k[:3], on_evict=gone.extend)
+    for lane in range(4):
+        c[(16, 4096, "cuda:0", 64 + lane)] = f"lane{lane}"
+    c[(64, 4096, "cuda:0", 0)] = "train"
+    c[(8, 4096, "cuda:0", 0)] = "ragged"
+    assert len(c) == 6 and len(c.groups()) == 3 and not gone
+    assert c.get((16, 4096, "cuda:0", 65)) == "lane1"        # touches the lane group: now the most recently used
+    c[(4, 4096, "cuda:0", 0)] = "new"                        # evicts the B = 64 group (least recently used), not the lanes
+    assert gone == [(64, 4096, "cuda:0", 0)]
+    assert c.get((64, 4096, "cuda:0", 0)) is None and (16, 4096, "cuda:0", 66) in c
+    c[(2, 4096, "cuda:0", 0)] = "newer"                      # ... then the ragged one
+    assert gone[-1] == (8, 4096, "cuda:0", 0) and len(c.groups()) == 3 and c.evictions == 2
+    assert sorted(v for v in c.values() if v.startswith("lane")) == ["lane0", "lane1", "lane2", "lane3"]
+    assert plan_cache().cap == PLAN_SHAPES >= 2
+    # the model classes use it
+    from tqdne_amd import UNetModel, tiny_1d_unet_config
+    assert isinstance(UNetModel(**tiny_1d_unet_config())._engine_cache, PlanCache)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-workgroup phase timeline of the attention forward kernel (needs the -DTQ_STAMP build: tqdne_amd/lib/stamp.so)."""
 import os, sys, ctypes as C
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["TQDNE_HIP_LIB"] = os.path.join(root, "tqdne_amd", "lib", "stamp.so")
 sys.path.insert(0, root)
 import numpy as np, torch

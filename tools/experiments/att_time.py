@@ -2,7 +2,7 @@
 """Kernel-only time of the attention forward on pre-split K / V planes (the inference path: `tq_attention_fwd_presplit`), B = 64,
 T = 512, 4 heads x 64, plus its error against fp64.  usage: att_time.py [B] [T] [H] [D] [reps]   (TQDNE_HIP_LIB selects the build)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tqdne_amd import _lib, ops
 from tqdne_amd.ops import _p, _stream, check
@@ -19,7 +19,7 @@ st = _stream(dev)
 
 
 def run():
-    check(lib.tq_attention_fwd_presplit(_p(qkv), _p(ws), _p(out), B, T, H, D, st), "attention presplit")
+    check(lib.tq_attention_fwd_presplit(_p(qkv), _p(ws), _p(out), B, T, H, D, 0, st), "attention presplit")
 
 
 for _ in range(10):

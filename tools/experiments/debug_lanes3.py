@@ -2,7 +2,7 @@
 every lane is compared with a reference run made alone.  Reports the first differing activation (in plan order)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from tqdne_amd import LightningEDM, paper_1d_unet_config
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Which launch of the plan corrupts a concurrently running head conv?  Head (plan 0, stream A) against each op of plan 1 (stream B)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from tqdne_amd import LightningEDM, paper_1d_unet_config, _lib
 from tqdne_amd.engine import _p

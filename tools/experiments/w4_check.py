@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """conv1d_w4.hip (one wave per SIMD) against conv1d_mfma.hip (two waves per SIMD) on the same launches: outputs and GroupNorm
 partial sums must be BIT-IDENTICAL (same operand formats, same accumulation order), then per-layer timing of both, interleaved.
-Developer tool, run on the GPU box: python tools/w4_check.py [B]"""
+Developer tool, run on the GPU box: python tools/experiments/w4_check.py [B]"""
 import ctypes as C
 import os
 import subprocess
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -2,9 +2,9 @@
 """In-kernel clock of the one-wave-per-SIMD conv kernel (conv1d_w4.hip), VERDICT r3 item 5: after >= 2 s of back-to-back launches on
 random data, every workgroup's d s_memtime / d s_memrealtime x 100 MHz of the LAST launch, median over workgroups.
 Needs a library built with TQDNE_BUILD_EXPERIMENTS=1 and -DTQ_W4_STAMP (and, for the MFMA / weight / LDS-read stream alone,
--DTQ_W4_ABL_NOCONV), given in TQDNE_HIP_LIB.  usage: TQDNE_CONV_W4=1 TQDNE_HIP_LIB=... python tools/w4_clock.py C0 C1 Cout T [B] [seconds]"""
+-DTQ_W4_ABL_NOCONV), given in TQDNE_HIP_LIB.  usage: TQDNE_CONV_W4=1 TQDNE_HIP_LIB=... python tools/experiments/w4_clock.py C0 C1 Cout T [B] [seconds]"""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from tqdne_amd import _lib, ops

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Timing of one conv launch with the library given in TQDNE_HIP_LIB (developer tool for conv1d_w4.hip ablation builds).
-usage: python tools/w4_time.py C0 C1 Cout T [B]"""
+usage: python tools/experiments/w4_time.py C0 C1 Cout T [B]"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tqdne_amd import _lib, ops
 C0, C1, Co, T = map(int, sys.argv[1:5]); B = int(sys.argv[5]) if len(sys.argv) > 5 else 64

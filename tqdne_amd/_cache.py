@@ -1,0 +1,90 @@
+"""Bounded caches of execution plans and per-shape scratch buffers.
+
+Every plan owns static activation buffers (a few GB for the paper UNet at B = 64), so a cache keyed by the call's shape must not grow
+with every shape a run ever sees (a loader's ragged last batch, evaluation over several batch sizes).  ``PlanCache`` keeps the
+``cap`` most recently used GROUPS of keys (a group = the plans of one (batch, length, device): the lanes of a multi-stream sampler /
+training step live and die together) and drops the least recently used group when a new one arrives."""
+
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+PLAN_SHAPES = max(2, int(os.environ.get("TQDNE_PLAN_CACHE_SHAPES", "6")))   # (batch, length, device) groups kept per model
+SCRATCH_ENTRIES = max(16, int(os.environ.get("TQDNE_SCRATCH_CACHE_ENTRIES", "64")))
+
+
+class PlanCache:
+    """dict-like (``get`` / ``[]=`` / ``values`` / ``items`` / ``in`` / ``len``), least-recently-used eviction by group.
+
+    ``group(key)``: the eviction unit of a key (default: the key itself).  ``on_evict(keys)``: called after a group was dropped
+    (before its buffers can be handed to anybody else) -- the owners synchronise the device there: launches of an evicted plan may
+    still be in flight on a side stream, and the caching allocator only orders re-use against the stream a block was allocated on."""
+
+    def __init__(self, cap: int, group=None, on_evict=None):
+        self.cap, self._group, self._on_evict = cap, (group or (lambda k: k)), on_evict
+        self._d: "OrderedDict[object, dict]" = OrderedDict()   # group -> {key: value}, least recently used first
+        self.evictions = 0
+
+    def get(self, key, default=None):
+        g = self._group(key)
+        grp = self._d.get(g)
+        if grp is None or key not in grp:
+            return default
+        self._d.move_to_end(g)
+        return grp[key]
+
+    def __setitem__(self, key, value):
+        g = self._group(key)
+        grp = self._d.get(g)
+        if grp is None:
+            dropped = []
+            while len(self._d) >= self.cap:
+                _, old = self._d.popitem(last=False)
+                dropped += list(old.keys())
+                self.evictions += 1
+                old.clear()
+            if dropped and self._on_evict is not None:
+                self._on_evict(dropped)
+            grp = self._d[g] = {}
+        grp[key] = value
+        self._d.move_to_end(g)
+
+    def __contains__(self, key):
+        grp = self._d.get(self._group(key))
+        return grp is not None and key in grp
+
+    def __len__(self):
+        return sum(len(g) for g in self._d.values())
+
+    def groups(self):
+        return list(self._d.keys())
+
+    def keys(self):
+        return [k for g in self._d.values() for k in g]
+
+    def values(self):
+        return [v for g in self._d.values() for v in g.values()]
+
+    def items(self):
+        return [kv for g in self._d.values() for kv in g.items()]
+
+    def clear(self):
+        self._d.clear()
+
+
+def _sync_on_evict(_keys):
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def plan_cache() -> PlanCache:
+    """cache of execution plans keyed (B, T, device[, lane]): grouped by the first three entries"""
+    return PlanCache(PLAN_SHAPES, group=lambda k: k[:3], on_evict=_sync_on_evict)
+
+
+def scratch_cache() -> PlanCache:
+    """cache of per-shape scratch buffers of the EDM / consistency wrappers (scalars, noised copies, sampler state): small next to the
+    plans, bounded per entry"""
+    return PlanCache(SCRATCH_ENTRIES, on_evict=_sync_on_evict)

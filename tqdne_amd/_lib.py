@@ -19,12 +19,29 @@ SZ = C.c_size_t
 TQ_CONV_GN, TQ_CONV_SILU, TQ_CONV_EMB, TQ_CONV_RES, TQ_CONV_STATS, TQ_CONV_DROPOUT = 1, 2, 4, 8, 16, 32
 TQ_CONV_POLY2 = 64
 TQ_WFMT_BF16X3, TQ_WFMT_F16_MX8, TQ_WFMT_F16_MX6 = 0, 1, 2
+TQ_KV_V_BF16, TQ_KV_V_F16 = 0, 1     # v_format of tq_conv1d_fwd_qkv / tq_attention_fwd_presplit
 PACK_MODE = {TQ_WFMT_BF16X3: 0, TQ_WFMT_F16_MX8: 2, TQ_WFMT_F16_MX6: 3}   # tq_pack_conv_weight mode of a forward weight format
 PACK_MODE_T = {TQ_WFMT_BF16X3: 1, TQ_WFMT_F16_MX6: 5}                      # ... of a data-gradient (transposed) weight format
 
 
 DEFAULT_SCHEME = "f16mx6"
-ABI_VERSION = 5   # include/tqdne_hip.h TQ_ABI_VERSION
+ABI_VERSION = 6   # include/tqdne_hip.h TQ_ABI_VERSION
+
+
+def requested_scheme() -> str:
+    """TQDNE_CONV_SCHEME resolved and validated: the scheme the forward convs AND (engine_bwd._dgrad) the data gradients may use."""
+    v = os.environ.get("TQDNE_CONV_SCHEME", DEFAULT_SCHEME).lower()
+    if v not in ("bf16x3", "f16mx8", "f16mx6"):
+        raise ValueError(f"TQDNE_CONV_SCHEME={v!r}: expected bf16x3, f16mx8 or f16mx6")
+    return v
+
+
+def attn_v_format() -> int:
+    """V-plane format of the inference attention pair: fp16 hi / lo + ONE fp16 softmax weight (two products, fp16 range, guarded by
+    the plan's range flag) unless TQDNE_ATTN_VF16=0 or the fp32-range scheme is requested (TQDNE_CONV_SCHEME=bf16x3)."""
+    if os.environ.get("TQDNE_ATTN_VF16", "1") == "0" or requested_scheme() == "bf16x3":
+        return TQ_KV_V_BF16
+    return TQ_KV_V_F16
 
 
 def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False) -> int:
@@ -32,9 +49,7 @@ def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, f
     is built for the shape (stride 1 incl. the nearest-upsampling convs, 128 | C_out, 64 | every source's channels incl. a fused skip
     conv's), bf16x3 elsewhere.  TQDNE_CONV_SCHEME: f16mx6 (default: e2m3 corrections with per-lane block scales), f16mx8 (round 1's
     e4m3 corrections with uniform scales), bf16x3 (the fp32-range three-product scheme everywhere)."""
-    v = os.environ.get("TQDNE_CONV_SCHEME", DEFAULT_SCHEME).lower()
-    if v not in ("bf16x3", "f16mx8", "f16mx6"):
-        raise ValueError(f"TQDNE_CONV_SCHEME={v!r}: expected bf16x3, f16mx8 or f16mx6")
+    v = requested_scheme()
     ok = stride == 1 and C_out % 128 == 0 and all(c % 64 == 0 for c in sources if c)
     if fused_skip:
         ok = ok and os.environ.get("TQDNE_FUSED_SKIP_MX8", "1") != "0"
@@ -108,8 +123,8 @@ _PROTOS = {
     "tq_embed_fwd": (I, [VP] * 14 + [I, I, I, VP]),
     "tq_linear_fwd": (I, [VP] * 4 + [I, I, I, VP]),
     "tq_attention_fwd": (I, [VP, VP, VP, VP, I, I, I, I, VP]),
-    "tq_attention_fwd_presplit": (I, [VP, VP, VP, I, I, I, I, VP]),
-    "tq_conv1d_fwd_qkv": (I, [C.POINTER(TqConvDesc)] + [VP] * 7 + [I, I, VP]),
+    "tq_attention_fwd_presplit": (I, [VP, VP, VP, I, I, I, I, I, VP]),
+    "tq_conv1d_fwd_qkv": (I, [C.POINTER(TqConvDesc)] + [VP] * 7 + [I, I, I, VP]),
     "tq_attention_workspace_bytes": (SZ, [I, I, I, I]),
     "tq_attention_bwd": (I, [VP] * 6 + [I, I, I, I, VP]),
     "tq_attention_bwd_ws": (I, [VP] * 7 + [I, I, I, I, VP]),

@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch as th
 from torch import nn
 
+from ._cache import plan_cache
 from . import engine, rng
 from .lightning_compat import LightningModule
 from .unet import AttentionParams, DownsampleParams, ResBlockParams, UpsampleParams, _conv
@@ -53,7 +54,7 @@ class Encoder(nn.Module):
         self.down_blocks = nn.Sequential(*blocks)
         self.output_layer = _conv(dims)(ch, out_channels, k, padding="same")
         self.time_scale = ds  # T_out = T_in / ds
-        self._engine_cache = {}
+        self._engine_cache = plan_cache()
 
     blocks_attr = "down_blocks"
 
@@ -69,7 +70,7 @@ class Encoder(nn.Module):
         return y
 
     def _apply(self, fn, *a, **k):
-        self._engine_cache = {}
+        self._engine_cache = plan_cache()
         self.__dict__.pop("_packed_stores", None)
         return super()._apply(fn, *a, **k)
 
@@ -99,7 +100,7 @@ class Decoder(nn.Module):
                     blocks.append(AttentionParams(ch, num_heads, dims))
         self.up_blocks = nn.Sequential(*blocks)
         self.output_layer = _conv(dims)(ch, out_channels, k, padding="same")
-        self._engine_cache = {}
+        self._engine_cache = plan_cache()
 
     blocks_attr = "up_blocks"
 
@@ -115,7 +116,7 @@ class Decoder(nn.Module):
         return y
 
     def _apply(self, fn, *a, **k):
-        self._engine_cache = {}
+        self._engine_cache = plan_cache()
         self.__dict__.pop("_packed_stores", None)
         return super()._apply(fn, *a, **k)
 

@@ -12,6 +12,7 @@ import torch
 
 from . import _lib, engine, rng
 from ._lib import check
+from ._cache import scratch_cache
 from .edm import sampler_lanes
 from .lightning_compat import LightningModule
 
@@ -74,7 +75,7 @@ class LithningConsistencyModel(LightningModule):  # (sic) the reference's class 
         self.sigma_min, self.sigma_max, self.rho, self.sigma_data = sigma_min, sigma_max, rho, sigma_data
         self.initial_timesteps, self.final_timesteps = initial_timesteps, final_timesteps
         self.lognormal_mean, self.lognormal_std, self.lr = lognormal_mean, lognormal_std, lr
-        self._scal = {}
+        self._scal = scratch_cache()
 
     def _forward_static(self, sample, sigma, cond, lane=0, train=False, dropout_seed=0, infer=False):
         lib = _lib.load()

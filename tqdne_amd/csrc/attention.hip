@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd2_kernel(const float* __r
 }
 
 template <int D>
-int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int T, int H, hipStream_t stream, bool presplit = false) {
+int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int T, int H, hipStream_t stream, bool presplit = false,
+                 bool v_fp16 = false) {
     const int Tp = (T + 63) / 64 * 64;
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
     if (!presplit) {
@@ -612,7 +613,7 @@ int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int 
     if (sh > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd2_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int nqt = (T + 64 * ATT_QB - 1) / (64 * ATT_QB);
-    if (presplit && attn_vf16()) {   // (planes written by tq_conv1d_fwd_qkv: V in fp16 hi / lo)
+    if (presplit && v_fp16) {   // (planes written by tq_conv1d_fwd_qkv: V in fp16 hi / lo)
         if (sh > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd2_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((attention_fwd2_kernel<D, true>), dim3(B * H * nqt), dim3(256), sh, stream, qkv,
@@ -648,11 +649,13 @@ extern "C" int tq_attention_fwd(const float* qkv, float* out, float* lse, void* 
 }
 
 extern "C" int tq_attention_fwd_presplit(const float* qkv, const void* kv_planes, float* out, int B, int T, int H, int D,
-                                         hipStream_t stream) {
+                                         int v_format, hipStream_t stream) {
     if (!qkv || !kv_planes || !out) return TQ_ERR_ARG;
+    if (v_format != TQ_KV_V_BF16 && v_format != TQ_KV_V_F16) return TQ_ERR_ARG;
     if (B <= 0 || T <= 0 || H <= 0) return TQ_ERR_SHAPE;
-    if (D == 64) return launch_attn2<64>(qkv, out, nullptr, const_cast<void*>(kv_planes), B, T, H, stream, true);
-    if (D == 32) return launch_attn2<32>(qkv, out, nullptr, const_cast<void*>(kv_planes), B, T, H, stream, true);
+    const bool vf = v_format == TQ_KV_V_F16;
+    if (D == 64) return launch_attn2<64>(qkv, out, nullptr, const_cast<void*>(kv_planes), B, T, H, stream, true, vf);
+    if (D == 32) return launch_attn2<32>(qkv, out, nullptr, const_cast<void*>(kv_planes), B, T, H, stream, true, vf);
     return TQ_ERR_SHAPE;
 }
 

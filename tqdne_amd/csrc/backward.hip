@@ -241,7 +241,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
                 }
                 if (p.flags & TQ_CONV_DROPOUT) {
                     const uint32_t e0 = (uint32_t)pos * (uint32_t)Cin + (uint32_t)(cb + 4 * m);
-                    const uint32_t dkey = drop_key(p.drop_seed, p.drop_site, (uint32_t)b);   // (b is uniform: scalar unit)
+                    const DropKey dkey = drop_key(p.drop_seed, p.drop_site, (uint32_t)b);   // (b is uniform: scalar unit)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         v[j] = (drop_hash(dkey, e0 + j) >= p.drop_thresh) ? v[j] * p.drop_scale : 0.f;

@@ -8,15 +8,6 @@
 
 namespace tq {
 
-// TQDNE_ATTN_VF16=0: the inference pair tq_conv1d_fwd_qkv -> tq_attention_fwd_presplit keeps V in bf16 hi / lo planes and P as a
-// bf16 hi / lo pair (three products, rounds 2-3) instead of fp16 V planes and ONE fp16 p (two products).  Read at every call (both
-// entry points must agree; plans hold no copy of it).
-inline bool attn_vf16() {
-    const char* e = getenv("TQDNE_ATTN_VF16");
-    return !(e && e[0] == '0');
-}
-
-
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -104,13 +95,27 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32" integer
     x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t drop_key(uint64_t seed, uint32_t site, uint32_t b) {
+// Round 5: the key has TWO words.  With one word every mask of every (sample, site, step) was an XOR-translated window of ONE fixed
+// 2^32-entry sequence (mix32(e ^ key)); the second word enters between the finaliser's two multiplies, so different keys select
+// different functions of e, not translates of one -- for one more 32-bit add per element (the key words are scalar operands).
+struct DropKey { uint32_t a, b; };
+__device__ __forceinline__ DropKey drop_key(uint64_t seed, uint32_t site, uint32_t b) {
     uint32_t k = mix32((uint32_t)seed ^ 0x9E3779B9u);
     k = mix32(k ^ (uint32_t)(seed >> 32));
     k = mix32(k + 0x85EBCA6Bu * (site + 1u));
-    return mix32(k + 0xC2B2AE35u * (b + 1u));
+    DropKey r;
+    r.a = mix32(k + 0xC2B2AE35u * (b + 1u));
+    r.b = mix32((k ^ 0x27D4EB2Fu) + 0x165667B1u * (b + 1u));
+    return r;
 }
-__device__ __forceinline__ uint32_t drop_hash(uint32_t key, uint32_t e) { return mix32(e ^ key); }
+__device__ __forceinline__ uint32_t drop_hash(DropKey key, uint32_t e) {
+    uint32_t x = e ^ key.a;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x += key.b;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
 
 }  // namespace tq
 

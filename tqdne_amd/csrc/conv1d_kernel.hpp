@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) voi
         }
     }
     // per-sample key of the dropout hash (scalar unit; only the dropout prologue / the data gradient's dropout chain read it)
-    const uint32_t dkey = (ACT == 3 || EPI == 1) ? drop_key(p.drop_seed, p.drop_site, (uint32_t)b) : 0u;
+    const DropKey dkey = (ACT == 3 || EPI == 1) ? drop_key(p.drop_seed, p.drop_site, (uint32_t)b) : DropKey{0u, 0u};
     int co_wave = ct * C::MT + wm * (16 * NCB);
     const bool wave_active = co_wave < p.C_out;
 
@@ -963,6 +963,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             const float sc = sec == 1 ? p.kvscale : 1.0f;
             const int dch = d0 + (odd ? 16 + 4 * (g - 1) : 4 * g);
             unsigned char* base0 = p.kv + (((size_t)b * p.kvH + h) * 4 + (sec == 1 ? 0 : 2)) * plane + (size_t)dch * 2;
+            float vmax = 0.f;   // range guard of the fp16 V planes: max |v| this lane converts
 #pragma unroll
             for (int tb = 0; tb < TBW; ++tb) {
                 const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
@@ -979,6 +980,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                         for (int j = 0; j < 4; ++j) {
                             hh[j] = (_Float16)v[j];
                             ll[j] = (_Float16)(v[j] - (float)hh[j]);
+                            vmax = fmaxf(vmax, fabsf(v[j]));
                         }
                         hi[cbk] = __builtin_bit_cast(uint2, hh);
                         lo[cbk] = __builtin_bit_cast(uint2, ll);
@@ -1006,6 +1008,8 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                     *reinterpret_cast<uint4*>(dst + plane) = ol;
                 }
             }
+            // (TqConvDesc.range_flag: V within a factor two of the fp16 range, or not finite -> the caller repeats on bf16 planes)
+            if (p.range_flag && !(vmax < 32752.f)) *p.range_flag = 1;
         }
     } else if constexpr (EPI == 0) {
     // TQ_CONV_POLY2: the upper half of the (virtual) output channels is phase 1 of an upsampling conv: real channel co - C,

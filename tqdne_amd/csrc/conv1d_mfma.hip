@@ -20,17 +20,18 @@ extern "C" int tq_conv_tile_co(int C_out) {
 static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale, const float* gshift,
                            const void* wpk, const float* bias, const float* emb, const float* res, const float* skip_x0,
                            const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream,
-                           unsigned char* kv_planes = nullptr, int kvH = 0, int kvD = 0, int kvTp = 0, float kvscale = 1.f);
+                           unsigned char* kv_planes = nullptr, int kvH = 0, int kvD = 0, int kvTp = 0, float kvscale = 1.f, int kv_vf16 = 0);
 
 extern "C" int tq_conv1d_fwd_qkv(const TqConvDesc* d, const float* x, const float* gscale, const float* gshift, const void* wpk,
-                                 const float* bias, float* qkv, void* kv_planes, int H, int D, hipStream_t stream) {
+                                 const float* bias, float* qkv, void* kv_planes, int H, int D, int v_format, hipStream_t stream) {
     if (!d || !kv_planes || H <= 0 || (D != 32 && D != 64)) return TQ_ERR_ARG;
+    if (v_format != TQ_KV_V_BF16 && v_format != TQ_KV_V_F16) return TQ_ERR_ARG;
     if (d->ktaps != 1 || d->stride != 1 || d->upsample || d->C_in1 || d->C_out != 3 * H * D || (d->C_skip0 | d->C_skip1)) return TQ_ERR_SHAPE;
     if (d->flags & (TQ_CONV_EMB | TQ_CONV_RES | TQ_CONV_STATS | TQ_CONV_DROPOUT | TQ_CONV_SILU)) return TQ_ERR_ARG;
     const int Tp = (d->T_out + 63) / 64 * 64;
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
     return conv1d_fwd_impl(d, x, nullptr, gscale, gshift, wpk, bias, nullptr, nullptr, nullptr, nullptr, nullptr, qkv, nullptr, stream,
-                           reinterpret_cast<unsigned char*>(kv_planes), H, D, Tp, scale);
+                           reinterpret_cast<unsigned char*>(kv_planes), H, D, Tp, scale, v_format == TQ_KV_V_F16 ? 1 : 0);
 }
 
 extern "C" int tq_conv1d_fwd(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale,
@@ -54,7 +55,7 @@ extern "C" int tq_conv1d_fwd_skip(const TqConvDesc* d, const float* x0, const fl
 static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale, const float* gshift,
                            const void* wpk, const float* bias, const float* emb, const float* res, const float* skip_x0,
                            const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream,
-                           unsigned char* kv_planes, int kvH, int kvD, int kvTp, float kvscale) {
+                           unsigned char* kv_planes, int kvH, int kvD, int kvTp, float kvscale, int kv_vf16) {
     if (!d || !x0 || !wpk || !y) return TQ_ERR_ARG;
     if (d->C_in0 <= 0 || d->C_in0 % 32 || d->C_in1 < 0 || d->C_in1 % 32 || d->C_out <= 0 || d->C_out % 32) return TQ_ERR_SHAPE;
     if (d->C_in1 > 0 && !x1) return TQ_ERR_ARG;
@@ -104,7 +105,7 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.fx0 = a.fx1 = a.fgs = a.fgh = nullptr; a.y1 = nullptr; a.OC0 = d->C_out; a.bflags = 0;
     a.sx0 = skip_x0; a.sx1 = skip_x1; a.sbias = skip_bias; a.sC0 = d->C_skip0; a.sC1 = d->C_skip1;
     a.wfmt = d->wfmt;
-    a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale; a.kv_vf16 = (kv_planes && attn_vf16()) ? 1 : 0;
+    a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale; a.kv_vf16 = (kv_planes && kv_vf16) ? 1 : 0;
     a.range_flag = d->range_flag;
     a.in_amax = nullptr;
     a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;

@@ -525,6 +525,7 @@ int conv1d_w4_launch(const ConvArgs& a, int ktaps, hipStream_t stream) {
     static const int enabled = [] { const char* e = getenv("TQDNE_CONV_W4"); return (e && e[0] == '1') ? 1 : 0; }();
     if (!enabled) return TQ_ERR_SHAPE;
     if (a.wfmt != TQ_WFMT_F16_MX6 || a.kv || a.gf_counters || (a.flags & TQ_CONV_DROPOUT) || ktaps != 5) return TQ_ERR_SHAPE;
+    if (a.t_tile) return TQ_ERR_SHAPE;   // (a small-tile plan sized its statistics for 32-position slots: not this kernel's 128)
     if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64 || a.C0 + a.C1 > 1024 || a.C_out % 128) return TQ_ERR_SHAPE;
     if ((a.flags & TQ_CONV_POLY2) || a.T_in != a.T_out) return TQ_ERR_SHAPE;
     const bool gn = a.flags & TQ_CONV_GN, silu = a.flags & TQ_CONV_SILU;

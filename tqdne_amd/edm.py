@@ -21,6 +21,7 @@ from typing import Optional
 import torch as th
 
 from . import _lib, engine
+from ._cache import scratch_cache
 from ._lib import check
 from .lightning_compat import LightningModule
 from .unet import UNetModel
@@ -114,7 +115,7 @@ class LightningEDM(LightningModule):
             for param in self.autoencoder.parameters():
                 param.requires_grad = False
         self.save_hyperparameters(ignore=("autoencoder"))
-        self._scal = {}
+        self._scal = scratch_cache()
         self._lane = 0  # which set of static buffers / execution plan the calls below use (two-lane sampling)
 
     # ------------------------------------------------------------------ preconditioned network
@@ -421,7 +422,7 @@ class LightningEDM(LightningModule):
         eng = self.unet._engine(B, eps.shape[2], dev, self._lane)
         nsig = int(sigmas.numel())
         key = (nsig, None if cond is None else tuple(cond.shape), None if cond_sample is None else tuple(cond_sample.shape),
-               eng.plan_epoch, self.num_sampling_steps)
+               eng.uid, eng.plan_epoch, self.num_sampling_steps)
         cache = bufs.setdefault("loop_graphs", {})   # one captured loop per key (a sweep over step counts re-uses them)
         g = cache.get(key)
         if g is None:
@@ -472,7 +473,7 @@ class LightningEDM(LightningModule):
         runs ahead of the GPU."""
         g = bufs.get("graph")
         eng = self.unet._engine(x32.shape[0], x32.shape[2], x32.device, self._lane)
-        key = (None if cond is None else cond.data_ptr(), None if cond_sample is None else cond_sample.data_ptr(), eng.plan_epoch)
+        key = (None if cond is None else cond.data_ptr(), None if cond_sample is None else cond_sample.data_ptr(), eng.uid, eng.plan_epoch)
         if g is None or bufs.get("graph_cond") != key:
             slot = th.ones(1, device=x32.device)  # (a valid sigma for the warm-up: sigma = 0 gives c_noise = -inf, NaN activations)
             self._denoise_static(x32, slot, 0, cond, cond_sample=cond_sample, infer=True)  # warm-up outside capture (plan build, packing)

@@ -282,6 +282,9 @@ class Probe:
         return sum(ms) / len(ms), self.flops, self.name, len(ms)
 
 
+_PLAN_UID = __import__("itertools").count(1)
+
+
 class UNetEngine:
     def __init__(self, model, B: int, T: int, device: torch.device, solo: bool = True):
         self.lib = _lib.load()
@@ -301,7 +304,11 @@ class UNetEngine:
         # fp32 range everywhere (after the range guard fired, or on request: model._conv_scheme / TQDNE_CONV_SCHEME)
         self.scheme = "auto"
         self.plan_epoch = 0
+        self.uid = next(_PLAN_UID)          # never reused: captured HIP graphs are keyed by it (a plan evicted from the bounded cache
+                                            # and rebuilt for the same shape owns NEW buffers)
         self._wfmt_sites = []               # (descriptor, [conv sites packed for it], preferred wfmt)
+        self.kv_v_format = _lib.attn_v_format()   # V planes of the inference attention pair (TQ_KV_V_*): a property of the plan
+        self._vfmt_ops = []                 # indices into ops_infer of the launches that carry it as their last argument
         # set by the conv epilogues (TqConvDesc.range_flag); ONE flag per model and device, shared by every plan of the model (any
         # batch, length, lane): the optimizer launch of the trainer is predicated on it (tq_adam_ema_step_guarded)
         self.range_flag = shared_range_flag(model, device)
@@ -314,7 +321,7 @@ class UNetEngine:
         self.acts: List[Act] = []
         self.gn_bufs: List[torch.Tensor] = []   # every GroupNorm's folded coefficients (see poison_gn)
         self.gn_fused = 0                         # GroupNorms folded inside their producer's launch
-        self.poison_gn = os.environ.get("TQDNE_POISON_GN") == "1"
+        self.poison_gn = False               # tests set it on the plan object (tests/test_concurrency.py); no environment switch
         self._probe = None
         self.tape = []
         self.last_rec = None
@@ -390,11 +397,10 @@ class UNetEngine:
                 d.gn_fuse = C.pointer(f)
             self.gn_fused += 1
             return gscale, gshift, mean_rstd
-        for _ in range(2 if os.environ.get("TQDNE_DUP_GN") == "1" else 1):   # (measurement switch: what do these launches cost?)
-            self._emit((self.lib.tq_gn_finalize, (
-                _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
-                _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd), s0.slot, s1.slot if s1 else 0), "gn_finalize", 0),
-                nbytes=4 * self.B * (2 * nslots(s0.T) * C_ + 2 * C_))
+        self._emit((self.lib.tq_gn_finalize, (
+            _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
+            _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd), s0.slot, s1.slot if s1 else 0), "gn_finalize", 0),
+            nbytes=4 * self.B * (2 * nslots(s0.T) * C_ + 2 * C_))
         return gscale, gshift, mean_rstd
 
     def _conv(self, srcs: Sequence[Act], site: ConvSite, *, gn=None, silu=False, emb_ptr=None, res: Optional[Act] = None,
@@ -480,9 +486,12 @@ class UNetEngine:
                 infer_op = self._polyphase_op(site, d, s0, s1, out, flops)
             if qkv_planes is not None:  # (ws, H, D): K / V straight into the attention kernel's pre-split planes
                 ws, H_, D_ = qkv_planes
+                # V planes in the plan's format (fp16 hi / lo unless the plan is on the fp32-range scheme): under the range guard
+                d.range_flag = self.range_flag.data_ptr()
                 infer_op = (self.lib.tq_conv1d_fwd_qkv, (
                     C.byref(d), _p(s0.buf), _p(gn[0]) if gn else None, _p(gn[1]) if gn else None, _p(site.packed), _p(site.bias),
-                    _p(out.buf), _p(ws), H_, D_), "conv:" + site.name + "+split", flops)
+                    _p(out.buf), _p(ws), H_, D_, self.kv_v_format), "conv:" + site.name + "+split", flops)
+                self._vfmt_ops.append(len(self.ops_infer))
             self._emit(op, infer_op, nbytes=nbytes)
             if stats and qkv_planes is None:   # (its inference form, the two-phase up-sampling conv, is a launch of its own shape)
                 poly = getattr(self, "_poly_desc", None)
@@ -643,8 +652,9 @@ class UNetEngine:
         op = (self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), _p(lse), _p(ws), self.B, x.T, ab.num_heads, D), "attention", flops)
         infer_op = None
         if split is not None:
-            infer_op = (self.lib.tq_attention_fwd_presplit, (_p(qkv.buf), _p(ws), _p(att.buf), self.B, x.T, ab.num_heads, D),
-                        "attention", flops)
+            infer_op = (self.lib.tq_attention_fwd_presplit, (_p(qkv.buf), _p(ws), _p(att.buf), self.B, x.T, ab.num_heads, D,
+                                                             self.kv_v_format), "attention", flops)
+            self._vfmt_ops.append(len(self.ops_infer))
         self._emit(op, infer_op, nbytes=4 * self.B * x.T * 4 * ab.channels)
         out = self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
         self.tape.append(("attn", dict(ab=ab, x=x, g=g, qkv=qkv, att=att, lse=lse, out=out, rec_qkv=rec_qkv,
@@ -670,7 +680,7 @@ class UNetEngine:
         return self._probe
 
     def _poison(self):
-        """test mode (``poison_gn`` / TQDNE_POISON_GN=1): NaN into every GroupNorm coefficient buffer before a forward, so that a
+        """test mode (``plan.poison_gn = True``): NaN into every GroupNorm coefficient buffer before a forward, so that a
         fold that is skipped, raced or mis-addressed is a loud NaN in the output instead of the previous call's coefficients"""
         if self.poison_gn and not torch.cuda.is_current_stream_capturing():
             for t in self.gn_bufs:
@@ -690,8 +700,19 @@ class UNetEngine:
         if getattr(self, "emb_desc", None) is not None:
             self.emb_desc.wfmt = _lib.TQ_WFMT_BF16X3
             self.emb_pack_mode = 0
+        # the inference attention pair leaves the fp16 V planes with the convs (its v_format is the last integer of both calls)
+        self.set_kv_v_format(_lib.TQ_KV_V_BF16)
         self.scheme = "bf16x3"            # (the pack mode is part of every store entry's version tag: the next forward re-packs)
         self.plan_epoch += 1     # captured HIP graphs of this plan are stale
+
+    def set_kv_v_format(self, fmt: int):
+        """V planes of the inference attention pair (``_lib.TQ_KV_V_*``; the last integer argument of both launches of the pair)."""
+        if fmt != self.kv_v_format:
+            self.kv_v_format = fmt
+            for i in self._vfmt_ops:
+                fn, args, *rest = self.ops_infer[i]
+                self.ops_infer[i] = (fn, tuple(args[:-1]) + (fmt,), *rest)
+            self.plan_epoch += 1     # captured HIP graphs of this plan are stale
 
     def _range_fallback(self):
         import warnings

@@ -21,6 +21,7 @@ from typing import Dict, List
 
 import torch
 
+from . import _lib
 from ._lib import (PACK_MODE_T, TQ_AMAX_WORDS, TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_BWD_GN, TQ_BWD_SILU, TQ_BWD_STATS, TQ_WFMT_BF16X3, TQ_WFMT_F16_MX6, STAT_SLOT,
                    TqConvBwdDesc, check)
 
@@ -157,6 +158,7 @@ class BackwardPlan:
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.dev)
         self.amax = self.flat[off_amax:off_amax + N_AMAX * TQ_AMAX_WORDS].view(torch.int32)   # bit patterns of max|dy|, written by atomic max
         self._amax_slot = {}       # data_ptr of a gradient tensor -> index of its slot
+        self.dgrad_descs = []      # every data-gradient descriptor of the plan (introspection: tests assert their scheme)
         self._mx6_dgrads = []      # (descriptor, site) of the data gradients planned in the fp16 + MX-fp6 scheme
         self.gview = {id(p): self.flat[offs[id(p)]:offs[id(p)] + p.numel()].view_as(p) for p in swept + emb_w + emb_b + tail}
         self.demb_all = self.flat[self.off_demb:self.off_demb + self.B * e.emb_total].view(self.B, e.emb_total)
@@ -265,7 +267,10 @@ class BackwardPlan:
         # scheme: fp16 + MX-fp6 on the scaled dy where the kernel is built for the shape and a max|dy| slot exists (filled by the
         # column-sum pass that every conv with a bias has ahead of its data gradient)
         amax = self.amax_ptr((amax_of if amax_of is not None else dy).data_ptr(), create=False)
-        mx6 = (DGRAD_SCHEME == "f16mx6" and amax is not None and site.C_out % 64 == 0 and site.C_in % 128 == 0
+        # (and only where the forward scheme requested for the model is the same one: TQDNE_CONV_SCHEME=bf16x3 / f16mx8 means
+        # fp32-range three-product data gradients too)
+        mx6 = (DGRAD_SCHEME == "f16mx6" and _lib.requested_scheme() == "f16mx6"
+               and amax is not None and site.C_out % 64 == 0 and site.C_in % 128 == 0
                and getattr(self.e, "scheme", "auto") == "auto" and getattr(self.m, "_conv_scheme", "auto") == "auto")
         want = 5 if mx6 else 1
         if site.packed_t is None:
@@ -279,6 +284,7 @@ class BackwardPlan:
         d = TqConvBwdDesc()
         d.wfmt = TQ_WFMT_F16_MX6 if mx6 else TQ_WFMT_BF16X3
         d.dy_amax = amax if mx6 else None
+        self.dgrad_descs.append(d)
         if mx6:
             self._mx6_dgrads.append((d, site))
         d.B, d.T, d.C_dy = self.B, T, site.C_out

@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from . import engine
+from ._cache import plan_cache
 
 GN_GROUPS = 32
 
@@ -193,7 +194,7 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(BlockSeq(*layers))
 
         self.out = nn.Sequential(_gn(ch), nn.SiLU(), _zero(_conv(dims)(input_ch, out_channels, k, padding="same")))
-        self._engine_cache = {}
+        self._engine_cache = plan_cache()   # bounded: the least recently used (B, T, device) group of plans goes when a 7th shape arrives
         self._conv_scheme = "auto"   # "bf16x3" once the range guard of the fp16-range scheme has fired (engine.py)
 
     # ------------------------------------------------------------------ execution
@@ -225,6 +226,6 @@ class UNetModel(nn.Module):
         return y
 
     def _apply(self, fn, *a, **k):  # parameters moved (.to / .cuda): compiled plans hold stale pointers
-        self._engine_cache = {}
+        self._engine_cache = plan_cache()
         self.__dict__.pop("_packed_stores", None)
         return super()._apply(fn, *a, **k)
