@@ -252,8 +252,9 @@ def parity_block(gpu, cpu_path, args):
 
 
 def other_configs(dev, args):
-    """BASELINE.json configs[0] and configs[3] next to the headline (configs[1]): parity-test cases, reported with the same step
-    definition (1 train step + one 18-step sample) so that the small / latent paths have a number in the driver's record.
+    """BASELINE.json configs[0], [3], [4] and the reference's real data shape next to the headline (configs[1]): parity-test cases,
+    reported with the same step definition (1 train step + one 18-step sample; cfg4: one consistency sample) so that the small / latent /
+    consistency paths have a number in the driver's record.
       cfg0  tiny UNet (32 base channels, no attention, unconditioned), B = 4, 3 x 4096 -- with its own CPU-oracle baseline at B = 4
       cfg3  latent EDM: frozen autoencoder 3 x 16384 <-> 16 x 4096 + paper-shape latent UNet, B = 16 (sample = 18 steps + decode)"""
     from tqdne_amd import LightningAutoencoder, LightningEDM, paper_1d_unet_config, rng, tiny_1d_unet_config
@@ -351,6 +352,66 @@ def other_configs(dev, args):
         del edm, ae, tr
     except Exception as e:
         res.append(dict(config="cfg3", error=repr(e)))
+    torch.cuda.empty_cache()
+    # ---- cfg4: consistency-model sampling on the paper UNet (consistency_model.py:81-106), B = 64: one network evaluation per sample
+    # (sigmas = []) and the reference's default call (sigmas = [1.0]: two evaluations + one uniform-noise refinement)
+    try:
+        from tqdne_amd import UNetModel
+        from tqdne_amd.consistency_model import LithningConsistencyModel
+        torch.manual_seed(args.seed)
+        net = UNetModel(**paper_1d_unet_config())
+        net.load_state_dict(perturbed_state(net, 17))
+        cm = LithningConsistencyModel(net).to(dev).eval()
+        B, T = 64, 4096
+        g = torch.Generator().manual_seed(4323)
+        eps4, cond4 = torch.randn(B, 3, T, generator=g).to(dev), torch.randn(B, 5, generator=g).to(dev)
+        u4 = torch.rand(B, 3, T, generator=g).to(dev)
+        ms1 = med(lambda: cm.sample_from(eps4, [], [], None, cond4), 7)
+        ms2 = med(lambda: cm.sample_from(eps4, [1.0], [u4], None, cond4), 7)
+        res.append(dict(config="cfg4: consistency-model sampling (consistency_model.py:81-106) on the paper UNet, B=64, 3x4096: step = ONE "
+                               "1-step sample of the batch (1 network evaluation); parts: the reference's default sigmas=[1.0] call (2 evaluations)",
+                        value=B / (ms1 * 1e-3), unit="waveforms/s", ms_per_step=ms1,
+                        parts=dict(one_step_sample_ms=ms1, two_step_sample_ms=ms2, two_step_waveforms_per_s=B / (ms2 * 1e-3))))
+        del cm, net
+    except Exception as e:
+        res.append(dict(config="cfg4", error=repr(e)))
+    torch.cuda.empty_cache()
+    # ---- the reference's real data shape (experiments/config.py:62-67, train_1d_edm.py): 3 x 4064 waveforms -> MovingAverageEnvelope ->
+    # 6 x 4064 signals, paper UNet with 6 channels in / out, B = 64; the representation and its inverse run on the GPU here
+    try:
+        from tqdne_amd.representation import MovingAverageEnvelope
+        torch.manual_seed(args.seed)
+        edm = LightningEDM(paper_1d_unet_config(in_channels=6, out_channels=6), {"learning_rate": 1e-4, "max_steps": 100000, "eta_min": 0.0},
+                           num_sampling_steps=args.sample_steps)
+        edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
+        edm = edm.to(dev)
+        B, T = 64, 4064
+        g = torch.Generator().manual_seed(4324)
+        wave = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev)
+        cond6 = torch.randn(B, 5, generator=g).to(dev)
+        rep = MovingAverageEnvelope()
+        tr = DataParallelTrainer(edm, world_size=1)
+
+        def train6():
+            edm.train()
+            tr.train_step({"signal": rep.get_representation(wave), "cond": cond6})
+
+        def step6():
+            train6()
+            edm.eval()
+            return rep.invert_representation(edm.sample((B, 6, T), cond=cond6))
+
+        def repr6():
+            return rep.invert_representation(rep.get_representation(wave))
+
+        ms, ms_train, ms_rep = med(step6, 3), med(train6, 3), med(repr6, 5)
+        res.append(dict(config="reference data shape: 3x4064 waveforms through MovingAverageEnvelope (GPU) -> 6x4064, paper UNet 6 -> 6 channels, "
+                               f"B=64: 1 train step (representation + fwd/bwd + Adam) + {args.sample_steps}-step Heun sample + inverse representation",
+                        value=B / (ms * 1e-3), unit="waveforms/s (3x4064)", ms_per_step=ms,
+                        parts=dict(train_ms=ms_train, sample_ms=ms - ms_train, representation_fwd_inv_ms=ms_rep)))
+        del edm, tr
+    except Exception as e:
+        res.append(dict(config="6x4064", error=repr(e)))
     torch.cuda.empty_cache()
     return res
 
@@ -863,6 +924,10 @@ def main():
                        "sampler_lanes": 1 if (use_graph or (use_graph is None and os.environ.get("TQDNE_SAMPLER_GRAPH") == "1")) else sampler_lanes(B),
                        "mode": args.mode},
             "parts": parts,
+            "parts_definition": "train_ms / sample_ms (since round 4): mean of 5 calls back to back between two synchronisations (the half's "
+                                "throughput time inside the timed steps); *_ms_synced: median of 5 calls each followed by a synchronisation "
+                                "(the definition train_ms / sample_ms had in rounds 1-3: ~2 ms more per training step); other_configs' parts "
+                                "are synced medians",
             "rccl_forced_at_world1": force_rccl,
             "rccl_ranks": rccl_ranks, "rccl_ranks_ok": rccl_ranks == world and first_collective_ranks == world,
             "replicas_equal": replicas["after_broadcast"] and replicas["after_timed_steps"], "replicas": replicas,

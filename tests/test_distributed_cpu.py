@@ -82,7 +82,8 @@ class _StubEDM(torch.nn.Module):
         for p in ps:
             self._offs[id(p)] = total
             total += p.numel()
-        self.flat = torch.zeros(total)
+        self.n_grad = total
+        self.flat = torch.zeros(total + 2)   # (+ the two tail words of BackwardPlan's layout, engine_bwd.TAIL_WORDS)
         self.release_order = None  # permutation of the bucket issue order (None: as completed)
 
     def configure_optimizers(self):
@@ -91,7 +92,8 @@ class _StubEDM(torch.nn.Module):
                                                          eta_min=self.optimizer_params["eta_min"])
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sch, "interval": "step"}}
 
-    def step_and_backward(self, batch, on_bucket=None, bucket_elems=1 << 20):
+    def step_and_backward(self, batch, on_bucket=None, bucket_elems=1 << 20, tail_fill=None):
+        self.flat.zero_()
         loss = ((self.net(batch["signal"]) - batch["cond"]) ** 2).mean()
         grads = torch.autograd.grad(loss, list(self.parameters()))
         for p, g in zip(self.parameters(), grads):
@@ -99,11 +101,14 @@ class _StubEDM(torch.nn.Module):
             self.flat[o:o + p.numel()].copy_(g.reshape(-1))
             p.grad = self.flat[o:o + p.numel()].view_as(p)
         if on_bucket is not None:
-            n = self.flat.numel()
+            n = self.n_grad
             cuts = [(i, min(i + bucket_elems, n)) for i in range(0, n, bucket_elems)]
             for lo, hi in cuts:
+                if hi == n and tail_fill is not None:   # (as BackwardPlan.run: the last bucket takes the caller's tail words along)
+                    tail_fill(self.flat[n:n + 2])
+                    hi = n + 2
                 on_bucket(self.flat[lo:hi])
-        return loss.detach(), self.flat
+        return loss.detach(), self.flat[:self.n_grad]
 
 
 def _trainer_worker(rank, world, port, ret):
@@ -268,6 +273,68 @@ def test_bench_watchdog_reports_a_hung_rendezvous():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["value"] is None and d["stage"] == "init_process_group" and "did not complete" in d["error"] and d["n_gpus"] == 2
+
+
+def _tail_worker(rank, world, port, ret):
+    """the range-guard pair folded into the tail of the last gradient bucket (round 5): same predicate on every rank at every step as
+    with its own collective, ONE collective fewer per step, and the gradients next to it are untouched"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tqdne_amd.trainer import DataParallelTrainer, shard_batch
+
+    class T(DataParallelTrainer):
+        AGREE_EVERY = 4
+        flag, auto = None, True
+
+        def _local_range_flag(self):
+            return self.flag, self.auto
+
+    g = torch.Generator().manual_seed(3)
+    steps = [{"signal": torch.randn(8, 16, generator=g), "cond": torch.randn(8, 4, generator=g)} for _ in range(10)]
+
+    def run(tailed):
+        m = _StubEDM()
+        tr = T(m, world_size=world, fused_optimizer=False, bucket_bytes=4 * 300)
+        tr.flag = torch.zeros(1, dtype=torch.int32)
+        tr._tailed = tailed
+        calls, log = [], []
+        orig = tr._allreduce_async
+        tr._allreduce_async = lambda t: (calls.append(t.numel()), orig(t))[1]
+        for step, b in enumerate(steps, 1):
+            if step == 2 and rank == 1:
+                tr.flag.fill_(1)
+            if step == 3 and rank == 1:
+                tr.flag.zero_(); tr.auto = False
+            if step == 5 and rank == 0:
+                tr.auto = False
+            n0 = len(calls)
+            tr.train_step(shard_batch(b, rank, world))
+            f = tr.last_skip
+            log.append((len(calls) - n0, None if f is None else (float(f[0]) != 0.0, float(f[1]))))
+        return torch.cat([p.detach().reshape(-1) for p in m.parameters()]), log
+
+    wa, la = run(True)
+    wb, lb = run(False)
+    ret[rank] = dict(weights_equal=bool(torch.equal(wa, wb)), tailed=la, separate=lb)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_range_flag_pair_rides_in_the_last_gradient_bucket():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_tail_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0]["tailed"] == ret[1]["tailed"] and ret[0]["separate"] == ret[1]["separate"]
+    r = ret[0]
+    assert r["weights_equal"]                                            # the gradients next to the tail words are untouched
+    assert [x[1] for x in r["tailed"]] == [x[1] for x in r["separate"]]  # the same predicate at every step
+    nb = r["tailed"][0][0]
+    assert nb >= 3 and r["separate"][0][0] == nb + 1                     # one collective fewer per step while the pair is exchanged
+    assert r["tailed"][1][1] == (True, 0.0) and r["tailed"][7][1] == (False, 2.0) and r["tailed"][8][1] is None
+    assert r["tailed"][9][0] == nb and r["separate"][9][0] == nb         # after the agreement: gradients only, either way
 
 
 # ---------------------------------------------------------------------------------------------------------------- range-guard flag, N > 1

@@ -56,7 +56,7 @@ class _EDMLossFn(th.autograd.Function):
 
 
 def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, lanes=None, on_bucket=None,
-                       bucket_elems: int = 4 << 20):
+                       bucket_elems: int = 4 << 20, tail_fill=None):
     """Fused training step without the autograd round trip: runs the HIP forward and backward back to back and leaves the
     gradients in the backward plan's flat buffer; ``p.grad`` of every UNet parameter is (re)bound to its view of that buffer.
     Returns (loss, flat_gradient_buffer).  Used by DataParallelTrainer (one all-reduce over the flat buffer, no per-parameter
@@ -68,7 +68,9 @@ def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, 
 
     ``on_bucket(flat_slice)``: gradient-exchange hook of the data-parallel trainer, called from inside the backward sweep as
     soon as a bucket of the flat buffer is final (BackwardPlan.run); with several lanes the buckets are only final after
-    the lanes' buffers have been summed, so the hook is then called for every bucket at the end."""
+    the lanes' buffers have been summed, so the hook is then called for every bucket at the end.
+
+    ``tail_fill``: see BackwardPlan.run (extra words of the caller at the end of the last bucket)."""
     params = list(module.unet.parameters())
     B = sample.shape[0]
     if lanes is None:
@@ -96,7 +98,7 @@ def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, 
                     eng = module.unet._engine(Bl, T, dev, module._lane)
                     scale = th.full((), 1.0 / lanes, device=dev)
                     grads = eng.backward(bufs["dpred"], scale, clone=False, on_bucket=on_bucket if lanes == 1 else None,
-                                         bucket_elems=bucket_elems)
+                                         bucket_elems=bucket_elems, tail_fill=tail_fill if lanes == 1 else None)
                     losses.append(loss)
                     flats.append(eng._bwd.flat)
                     if i == 0:
@@ -108,7 +110,11 @@ def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, 
         for f in flats[1:]:
             flats[0].add_(f)
         if on_bucket is not None and lanes > 1:
+            from .engine_bwd import TAIL_WORDS
             for lo, hi, _ in eng0_bwd.plan_buckets(bucket_elems):
+                if tail_fill is not None and hi == eng0_bwd.n_grad:
+                    tail_fill(flats[0][hi:hi + TAIL_WORDS])
+                    hi += TAIL_WORDS
                 on_bucket(flats[0][lo:hi])
         for p, g in zip(params, grads0):
             if g is not None and (p.grad is None or p.grad.data_ptr() != g.data_ptr()):

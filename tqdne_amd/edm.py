@@ -199,9 +199,10 @@ class LightningEDM(LightningModule):
         return edm_loss(self, sample.contiguous(), eps.contiguous().float(), unit_noise.contiguous(), cond,
                         None if cond_sample is None else cond_sample.contiguous())
 
-    def step_and_backward(self, batch, on_bucket=None, bucket_elems: int = 4 << 20):
+    def step_and_backward(self, batch, on_bucket=None, bucket_elems: int = 4 << 20, tail_fill=None):
         """``step`` + backward in one call, gradients left in ``p.grad`` (views of one flat buffer, returned as well).
-        ``on_bucket``: gradient-exchange hook, called as buckets of the flat buffer become final (BackwardPlan.run)."""
+        ``on_bucket``: gradient-exchange hook, called as buckets of the flat buffer become final (BackwardPlan.run);
+        ``tail_fill``: extra words of the caller that ride at the end of the last bucket (BackwardPlan.run)."""
         from .autograd import edm_loss_and_grads
         if self.unet.dims == 2:
             raise NotImplementedError("DataParallelTrainer drives the 1-D HIP path; train dims=2 models with step() + torch.autograd")
@@ -217,7 +218,7 @@ class LightningEDM(LightningModule):
         unit_noise = th.randn_like(sample)
         return edm_loss_and_grads(self, sample.contiguous(), eps, unit_noise, cond,
                                   None if cond_sample is None else cond_sample.contiguous(), on_bucket=on_bucket,
-                                  bucket_elems=bucket_elems)
+                                  bucket_elems=bucket_elems, tail_fill=tail_fill)
 
     def training_step(self, batch, batch_idx):
         loss = self.step(batch, batch_idx)

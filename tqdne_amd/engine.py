@@ -958,12 +958,12 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, dpred: torch.Tensor, gloss: torch.Tensor, c_out=None, in_scale=None, clone: bool = True, on_bucket=None,
-                 bucket_elems: int = 4 << 20):
+                 bucket_elems: int = 4 << 20, tail_fill=None):
         """Gradients of every UNet parameter for d loss / d pred = gloss * dpred, for the last train-mode forward.
         Returns a list aligned with ``model.parameters()`` (None for frozen parameters).  ``on_bucket``: see BackwardPlan.run."""
         if self._bwd is None:
             self._bwd = BackwardPlan(self)
-        return self._bwd.run(dpred, gloss, clone=clone, on_bucket=on_bucket, bucket_elems=bucket_elems)
+        return self._bwd.run(dpred, gloss, clone=clone, on_bucket=on_bucket, bucket_elems=bucket_elems, tail_fill=tail_fill)
 
 
 class SeqEngine(UNetEngine):

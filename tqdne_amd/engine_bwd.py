@@ -26,6 +26,9 @@ from ._lib import (PACK_MODE_T, TQ_AMAX_WORDS, TQ_BWD_ACCUM, TQ_BWD_DROPOUT, TQ_
                    TqConvBwdDesc, check)
 
 
+TAIL_WORDS = 2   # floats reserved behind the parameter gradients in a backward plan's flat buffer (see BackwardPlan.run, tail_fill)
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -149,6 +152,7 @@ class BackwardPlan:
             offs[id(p)] = total
             total += p.numel()
         self.n_grad = total
+        total += TAIL_WORDS      # flat[n_grad : n_grad + TAIL_WORDS]: rides at the end of the LAST gradient bucket (``tail_fill`` of run())
         total = (total + 63) // 64 * 64
         self.off_demb = total
         total += self.B * e.emb_total
@@ -482,11 +486,24 @@ class BackwardPlan:
         x.gw = True
 
     # ------------------------------------------------------------------ run
-    def run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True, on_bucket=None, bucket_elems: int = 4 << 20):
+    def run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True, on_bucket=None, bucket_elems: int = 4 << 20,
+            tail_fill=None):
         """``on_bucket(flat_slice)``: called from inside the sweep, right after the launch that finalises the last gradient of
         each bucket of >= ``bucket_elems`` floats has been enqueued (buckets = contiguous slices of the flat buffer in the
         order the sweep completes them; every rank cuts them identically).  The data-parallel trainer starts the slice's
-        all-reduce there, so the exchange runs under the rest of the backward."""
+        all-reduce there, so the exchange runs under the rest of the backward.
+        ``tail_fill(words)``: the ``TAIL_WORDS`` floats that follow the gradients in the flat buffer are handed to this callback right
+        before the LAST bucket leaves, and that bucket then includes them: a few extra words of the caller (the trainer's range-guard
+        flags) ride in the gradients' last collective instead of in one of their own."""
+        if tail_fill is not None and on_bucket is not None:
+            user_bucket, n_grad, flat = on_bucket, self.n_grad, self.flat
+
+            def on_bucket(sl):   # (the bucket that ends the gradients takes the tail words along)
+                end = sl.storage_offset() + sl.numel()
+                if end == n_grad:
+                    tail_fill(flat[n_grad:n_grad + TAIL_WORDS])
+                    sl = flat[sl.storage_offset():n_grad + TAIL_WORDS]
+                user_bucket(sl)
         e, m, lib = self.e, self.m, self.lib
         last = e._last
         if last.get("infer", False):

@@ -97,15 +97,32 @@ class DataParallelTrainer:
         elif ema_decay is not None:
             self._ema = {n: p.detach().clone() for n, p in module.named_parameters() if p.requires_grad}
         self.bucket_elems = max(1, bucket_bytes // 4)
-        self._hooked = "on_bucket" in inspect.signature(module.step_and_backward).parameters
+        sig = inspect.signature(module.step_and_backward).parameters
+        self._hooked = "on_bucket" in sig
+        self._tailed = "tail_fill" in sig   # the module lets a few words of ours ride at the end of the last gradient bucket
         self.last_bucket_sizes = []   # elements of each bucket exchanged by the last step, in issue order (diagnostics / tests)
         if self.exchange:
-            with torch.no_grad():  # replicas start identical (DDP's initial broadcast); in place on the parameter
-                for p in module.parameters():  # itself (not p.data) so that its version counter moves and packed weights follow
-                    dist.broadcast(p, src=0, group=self.group)
-                torch._C._increment_version(list(module.parameters()))
+            self._broadcast_parameters()
 
     # ------------------------------------------------------------------ exchange
+    def _broadcast_parameters(self):
+        """Replicas start identical (DDP's initial broadcast): rank 0's parameters go out as ONE flat buffer per dtype
+        (round 4 issued one collective per tensor: 311 for the paper UNet) and are copied back in place on the parameters themselves
+        (not p.data), so that their version counters move and the packed weights follow."""
+        with torch.no_grad():
+            by_dtype = {}
+            for p in self.module.parameters():
+                by_dtype.setdefault(p.dtype, []).append(p)
+            for ps in by_dtype.values():
+                flat = torch.cat([p.detach().reshape(-1) for p in ps])
+                dist.broadcast(flat, src=0, group=self.group)
+                o = 0
+                views = []
+                for p in ps:
+                    views.append(flat[o:o + p.numel()].view_as(p))
+                    o += p.numel()
+                torch._foreach_copy_(ps, views)
+
     def _allreduce_async(self, t: torch.Tensor):
         """start the sum all-reduce of ``t`` (in place); returns a handle with ``wait()``.  NCCL/RCCL: the collective is
         enqueued on the process group's own stream behind everything the current stream holds so far."""
@@ -121,7 +138,17 @@ class DataParallelTrainer:
             def hook(sl):
                 self.last_bucket_sizes.append(sl.numel())
                 works.append(self._allreduce_async(sl))
-        if self._hooked:
+        tail = None
+        if hook is not None and self._tailed and self._skip_exchange_live():
+            # the range-guard pair of this step rides at the end of the last gradient bucket (no collective of its own)
+            tail = []
+
+            def tail_fill(words):
+                self._skip_fill(words)
+                tail.append(words)
+        if tail is not None:
+            loss, flat = self.module.step_and_backward(batch, on_bucket=hook, bucket_elems=self.bucket_elems, tail_fill=tail_fill)
+        elif self._hooked:
             loss, flat = self.module.step_and_backward(batch, on_bucket=hook, bucket_elems=self.bucket_elems)
         else:
             loss, flat = self.module.step_and_backward(batch)
@@ -132,9 +159,14 @@ class DataParallelTrainer:
                 for i in range(0, f1.numel(), self.bucket_elems):
                     self.last_bucket_sizes.append(min(self.bucket_elems, f1.numel() - i))
                     works.append(self._allreduce_async(f1[i:i + self.bucket_elems]))
-        skip = self._range_skip_flag()
+        reduced = tail[0] if tail else None
+        if reduced is None:
+            skip = self._range_skip_flag()
         for w in works:   # (NCCL: makes the current stream wait for the exchange; the host does not block)
             w.wait()
+        if reduced is not None:
+            skip = self._range_skip_flag(reduced)   # (after the waits: every AGREE_EVERY steps the host reads the reduced pair)
+        self.last_skip = skip
         if self.fused:
             # the 1 / world_size of the gradient mean rides in the optimizer launch
             self.optimizer.step(grad_scale=1.0 / self.world, skip_flag=skip)
@@ -162,7 +194,7 @@ class DataParallelTrainer:
         from .engine import shared_range_flag
         return shared_range_flag(unet, dev), getattr(unet, "_conv_scheme", "auto") == "auto"
 
-    def _range_skip_flag(self):
+    def _range_skip_flag(self, reduced=None):
         """Device predicate of the optimizer launch (fused optimizer only): the range-guard flag of the fp16-range forward scheme.
         The host learns of a raised flag one or more steps late (engine._range_poll does not synchronise), so the step whose
         forward raised it -- activations within a factor two of the fp16 range, possibly inf / NaN gradients -- is dropped ON
@@ -177,7 +209,11 @@ class DataParallelTrainer:
 
         The exchange ends by agreement: the second word of the exchanged pair counts the ranks that are off the fp16-range scheme;
         every ``AGREE_EVERY`` steps all ranks read it (the same step on every rank, so they stop together) and, once it equals the
-        world size, no rank issues the collective any more."""
+        world size, no rank issues the collective any more.
+
+        ``reduced`` (round 5): the pair already summed over the ranks -- it rode at the end of the step's last gradient bucket
+        (``tail_fill`` of BackwardPlan.run), so the step has no collective of its own for it; None: the pair is exchanged here (modules
+        without the bucket hook, ``overlap=False``)."""
         flag, auto = self._local_range_flag()
         if flag is None:
             return None
@@ -185,22 +221,33 @@ class DataParallelTrainer:
             return flag if auto else None
         if getattr(self, "_skip_done", False):
             return None
-        # (summed as floats through the same exchange path as the gradients; the kernel tests word 0 for "non-zero", and a sum of
-        # 0 / 1 flags has a non-zero bit pattern exactly when some rank raised its flag)
-        if getattr(self, "_skip", None) is None:
-            self._skip = torch.zeros(2, dtype=torch.float32, device=flag.device)
-            self._skip_steps = 0
-        if auto:
-            self._skip[0:1].copy_(flag)
-            self._skip[1:2].zero_()
-        else:
-            self._skip[0:1].zero_()
-            self._skip[1:2].fill_(1.0)
-        self._allreduce_async(self._skip).wait()
-        self._skip_steps += 1
-        if self._skip_steps % self.AGREE_EVERY == 0 and float(self._skip[1].item()) >= self.world:
+        if reduced is None:
+            # (summed as floats through the same exchange path as the gradients; the kernel tests word 0 for "non-zero", and a sum
+            # of 0 / 1 flags has a non-zero bit pattern exactly when some rank raised its flag)
+            if getattr(self, "_skip", None) is None:
+                self._skip = torch.zeros(2, dtype=torch.float32, device=flag.device)
+            self._skip_fill(self._skip)
+            self._allreduce_async(self._skip).wait()
+            reduced = self._skip
+        self._skip_steps = getattr(self, "_skip_steps", 0) + 1
+        if self._skip_steps % self.AGREE_EVERY == 0 and float(reduced[1].item()) >= self.world:
             self._skip_done = True
-        return self._skip
+        return reduced
+
+    def _skip_exchange_live(self) -> bool:
+        """does this step exchange the range-guard pair? (fused optimizer on a 1-D UNet, exchange on, no agreement reached yet)"""
+        flag, _ = self._local_range_flag()
+        return flag is not None and self.exchange and not getattr(self, "_skip_done", False)
+
+    def _skip_fill(self, words):
+        """this rank's pair into ``words`` (2 floats): [its range-guard flag while it is on the fp16-range scheme, 1 once it left it]"""
+        flag, auto = self._local_range_flag()
+        if auto:
+            words[0:1].copy_(flag)
+            words[1:2].zero_()
+        else:
+            words[0:1].zero_()
+            words[1:2].fill_(1.0)
 
     def ema_state(self):
         """name -> EMA weights, as the reference's EMA callback stores them in a checkpoint (tqdne/ema.py:50-51)."""
