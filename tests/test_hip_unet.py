@@ -654,7 +654,7 @@ def test_conv_scheme_bf16x3_moves_the_data_gradients_too(monkeypatch):
     """TQDNE_CONV_SCHEME=bf16x3 is the documented fp32-range switch: forward convs AND data gradients must then run the three-product
     scheme (round-4 advisor finding: the data gradients kept fp16-packed weights).  The default leaves f16+mx6 data gradients on."""
     from tqdne_amd import LightningEDM, _lib, tiny_1d_unet_config
-    cfg = dict(tiny_1d_unet_config(), model_channels=128, dropout=0.0)   # (128 | C_in so that the mx6 data gradient is eligible)
+    cfg = dict(tiny_1d_unet_config(), model_channels=128, num_heads=8, dropout=0.0)   # (128 | C_in: the mx6 data gradient is eligible; head dim 64)
     g = torch.Generator().manual_seed(5)
     B, T = 2, 512
     sig, cond = 0.5 * torch.randn(B, 3, T, generator=g), torch.randn(B, 5, generator=g)

@@ -61,13 +61,20 @@ constexpr int TQ_WGRAD_PLAIN_ORDER = 1 << 30;  // (internal flag bit of WgArgs.f
 // cycles were conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.)
 constexpr int WG_DY_STRIDE1 = 288;  // bytes per dy image row, 32-channel chunks (128 co * 2 B + 32 pad: 72 banks = 8 mod 64)
 constexpr int WG_DY_STRIDE2 = 272;  // 64-channel chunks (k = 1 only): the plain image -- 288-byte rows would cost the third resident workgroup
-template <int NCI> __device__ __forceinline__ int wg_dy_swz(int row) { return NCI == 1 ? ((row >> 3) & 1) << 7 : 0; }   // slot ^ 16
+template <int NCI> __device__ __forceinline__ int wg_dy_swz(int row) { return (NCI == 1 || NCI == 4) ? ((row >> 3) & 1) << 7 : 0; }   // slot ^ 16
 __device__ __forceinline__ int wg_x_swz(int row) { return ((row >> 3) & 1) << 5; }    // byte offset XOR: slot ^ 4 (64-byte rows)
 // 128-byte xhat rows (W8): a 32-lane read touches rows {r .. r+3} and {r+8 .. r+11}, 4 slots of 8 bytes each; rows of equal parity
 // share their 32 banks, so the slot is XOR-ed with 4 * bit 1 and 8 * bit 3 of the row: r, r+2, r+8, r+10 land in four disjoint
 // slot groups
 __device__ __forceinline__ int wg_x_swz128(int row) { return (((row >> 1) & 1) << 5) | (((row >> 3) & 1) << 6); }
+// 256-byte xhat rows (NCI = 4, round 5): every row spans all 64 banks, so the eight rows of a 32-lane read (r .. r+3, r+8 .. r+11; 32
+// bytes each) go to eight different 32-byte slots: slot ^= (row & 3) | 4 * bit 3 of the row
+__device__ __forceinline__ int wg_x_swz256(int row) { return ((row & 3) << 5) | (((row >> 3) & 1) << 7); }
 
+// NCI = 4 (round 5, k = 1 only): a 128-channel input chunk per workgroup -- the 1x1 convs (ResBlock skip convs, attention qkv / proj) have
+// a fifth of a k = 5 conv's MFMA work per staged dy tile, so their launches are bound by re-reading and re-splitting dy once per input
+// chunk (C_in / 64 times with NCI = 2): 64 accumulator registers, both LDS images conflict-free (288-byte dy rows, swizzled 256-byte
+// xhat rows), 70 KB of LDS = two workgroups per CU as before.
 // NCI: input-channel chunk of a workgroup in units of 32.  The dy tile (128 co) is staged, split and read once per workgroup and
 // unit whatever the chunk width, so the 64-channel chunk (NCI = 2) halves the number of times dy is re-read from L2 / HBM and
 // re-split (measured traffic-bound with 32: every conv's dy was read C_in / 32 times); 160 accumulator registers at k = 5.
@@ -86,7 +93,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
     constexpr int XC4 = 8 * NCX;             // float4 columns of the xhat tile
     constexpr int XIT = (XR * XC4 + NT - 1) / NT;
     constexpr int DYIT = 2048 / NT;          // float4 of the 64 x 128 dy tile per thread
-    constexpr int WG_DY_STRIDE = (NCI == 1) ? WG_DY_STRIDE1 : WG_DY_STRIDE2;
+    static_assert(NCI != 4 || (KT == 1 && STRIDE == 1 && !UPS), "128-channel chunks: the 1x1 convs");
+    constexpr int WG_DY_STRIDE = (NCI == 1 || NCI == 4) ? WG_DY_STRIDE1 : WG_DY_STRIDE2;
     constexpr int DY_PLANE = WG_TT * WG_DY_STRIDE;
     constexpr int X_PLANE = XR * WG_X_STRIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
             bf16x4 h, l;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { __bf16 hh, ll; split_bf16(v[j], hh, ll); h[j] = hh; l[j] = ll; }
-            const int off = i * WG_X_STRIDE + (W8 ? ((m * 8) ^ wg_x_swz128(i)) : (NCI == 1 ? ((m * 8) ^ wg_x_swz(i)) : m * 8));
+            const int off = i * WG_X_STRIDE + (W8 ? ((m * 8) ^ wg_x_swz128(i)) : (NCI == 1 ? ((m * 8) ^ wg_x_swz(i)) : (NCI == 4 ? ((m * 8) ^ wg_x_swz256(i)) : m * 8)));
             *reinterpret_cast<bf16x4*>(x_hi + off) = h;
             *reinterpret_cast<bf16x4*>(x_lo + off) = l;
         }
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
     // xhat image offset of (row, 16-channel block nb, this lane's 8-byte slot)
     auto x_off = [&](int xrow, int nb) -> int __attribute__((always_inline)) {
         const int colx = ((wci * 2 + nb) * 16 + 4 * pp) * 2;
-        return xrow * WG_X_STRIDE + (W8 ? (colx ^ wg_x_swz128(xrow)) : (NCI == 1 ? (colx ^ wg_x_swz(xrow)) : colx));
+        return xrow * WG_X_STRIDE + (W8 ? (colx ^ wg_x_swz128(xrow)) : (NCI == 1 ? (colx ^ wg_x_swz(xrow)) : (NCI == 4 ? (colx ^ wg_x_swz256(xrow)) : colx)));
     };
     auto a_frags = [&](int r0, Frag (&ah)[2], Frag (&al)[2]) __attribute__((always_inline)) {
 #pragma unroll
@@ -476,6 +484,8 @@ int wgrad_nci(const TqConvDesc* d) {
     // fifth of a k = 5 one, so the dy staging dominates); k = 5 loses 35-50 % (160 accumulator registers: 17 spills and no room
     // for the staging prefetch), k = 3 loses 16-34 %, the attention projections are neutral -> 64 only for k = 1
     if (d->ktaps != 1 && forced != 2) return 1;
+    // round 5: 128-channel chunks for the 1x1 convs whose sources are made of whole ones (dy is then staged C_in / 128 times)
+    if (d->ktaps == 1 && d->stride == 1 && !d->upsample && forced != 2 && d->C_in0 % 128 == 0 && d->C_in1 % 128 == 0) return 4;
     return (d->C_in0 % 64 == 0 && d->C_in1 % 64 == 0) ? 2 : 1;
 }
 
@@ -495,7 +505,7 @@ template <int KT, int STRIDE, int UPS>
 size_t wgrad_lds(int nci, bool w8) {
     constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
     const int ncx = w8 ? 2 : nci;
-    return 2 * WG_TT * (nci == 1 ? WG_DY_STRIDE1 : WG_DY_STRIDE2) + 2 * XR * 64 * ncx + 128 * sizeof(float);   // (+ the fused column sums)
+    return 2 * WG_TT * ((nci == 1 || nci == 4) ? WG_DY_STRIDE1 : WG_DY_STRIDE2) + 2 * XR * 64 * ncx + 128 * sizeof(float);   // (+ the fused column sums)
 }
 
 template <int KT, int STRIDE, int UPS, int NCI, bool W8>
@@ -517,6 +527,9 @@ int wgrad_slots_of() {
 template <int KT, int STRIDE, int UPS>
 int wgrad_slots_k(int nci, bool w8) {
     if (w8) return wgrad_slots_of<KT, STRIDE, UPS, 1, true>();
+    if constexpr (KT == 1 && STRIDE == 1 && UPS == 0) {
+        if (nci == 4) return wgrad_slots_of<KT, STRIDE, UPS, 4, false>();
+    }
     return nci == 2 ? wgrad_slots_of<KT, STRIDE, UPS, 2, false>() : wgrad_slots_of<KT, STRIDE, UPS, 1, false>();
 }
 
@@ -556,6 +569,17 @@ int launch_wgrad(const WgArgs& a, int nci, bool w8, hipStream_t stream) {
         }();
         (void)raised;
         hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 1, true>), dim3(grid), dim3(512), sh, stream, a);
+    } else if (nci == 4) {
+        if constexpr (KT == 1 && STRIDE == 1 && UPS == 0) {
+            static const bool raised4 = [] {   // (70 KB of LDS images: above the 64 KB default of a dynamic allocation)
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1, 1, 0, 4, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+            }();
+            (void)raised4;
+            hipLaunchKernelGGL((wgrad_kernel<1, 1, 0, 4, false>), dim3(grid), dim3(256), sh, stream, a);
+        } else {
+            return TQ_ERR_SHAPE;
+        }
     } else if (nci == 2) {
         hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 2, false>), dim3(grid), dim3(256), sh, stream, a);
     } else {

@@ -709,8 +709,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) voi
 #pragma unroll
                     for (int cbk = 0; cbk < NCB; ++cbk) {
                         mma_block2(wa, bf[st & 1], tb, cbk);
+#ifndef TQ_ABL_NCB4_NOREFILL   // (ablation, wrong numerics: the tap's weights are never replaced = a weight prefetch that costs nothing)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) wa[cbk * 4 + q].u = wp[(cbk * 4 + q) * 64];
+#endif
                     }
                     b0 = b0n;
                 }
