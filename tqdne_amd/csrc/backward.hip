@@ -14,6 +14,20 @@ namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// -DTQ_WG_ABL_HIHI (timing ablation, wrong numerics, never in the shipped library): the weight gradient's products with the two
+// first-order terms dropped (ONE bf16 MFMA per product instead of three) = the bound of any cheaper contraction scheme for it;
+// -DTQ_WG_ABL_HALF: two of the three (the MFMA cycles an fp16 + MX-fp6 port would execute: 1.5 units, here as 2)
+__device__ __forceinline__ f32x4 wg_mma(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 c) {
+#if defined(TQ_WG_ABL_HIHI)
+    return mfma_bf16(ah, bh, c);
+#elif defined(TQ_WG_ABL_HALF)
+    c = mfma_bf16(ah, bl, c);
+    return mfma_bf16(ah, bh, c);
+#else
+    return mfma_x3(ah, al, bh, bl, c);
+#endif
+}
+
 // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of (row q, cols 4p..4p+3); lane i receives
 // column i of rows 0..3.  Two reads (rows +0, +4) give the 8 consecutive k of one MFMA operand fragment.
 __device__ __forceinline__ uint2 lds_tr_read(const unsigned char* p) {
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
                     tap_frag(w.l, ol, k, bl);
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb)
-                        acc[mb][nb][k] = mfma_x3(ah[mb].v, al[mb].v, bh.v, bl.v, acc[mb][nb][k]);
+                        acc[mb][nb][k] = wg_mma(ah[mb].v, al[mb].v, bh.v, bl.v, acc[mb][nb][k]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
                     bl.h[1] = lds_tr_read(x_lo + off4);
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb)
-                        acc[mb][nb][k] = mfma_x3(ah[mb].v, al[mb].v, bh.v, bl.v, acc[mb][nb][k]);
+                        acc[mb][nb][k] = wg_mma(ah[mb].v, al[mb].v, bh.v, bl.v, acc[mb][nb][k]);
                 }
             }
         }
