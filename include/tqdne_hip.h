@@ -336,6 +336,12 @@ int tq_attention_bwd(const float* qkv, const float* out, const float* dout, cons
  * workspace == NULL fall through to tq_attention_bwd.  Replaces the autograd backward of blocks.py:156-190. */
 int tq_attention_bwd_ws(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
                         void* workspace, int B, int T, int H, int D, hipStream_t stream);
+/* ABI 6.  The same with the K / V planes the training forward already wrote: `kv_planes` is the `workspace` argument of the
+ * tq_attention_fwd call whose backward this is (D = 32 / 64; it must still hold that call's planes: give every attention block of a
+ * training plan a workspace of its own).  The prep pass then forms Q, dO and delta only.  `workspace`: as tq_attention_bwd_ws
+ * (its first half stays unused).  Gradients bit-identical to tq_attention_bwd_ws. */
+int tq_attention_bwd_ws_kv(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+                           void* workspace, const void* kv_planes, int B, int T, int H, int D, hipStream_t stream);
 
 /* ---- EDM / sampler elementwise ------------------------------------------------------------------------------ */
 /* per-sample scalars from sigma: c_in, c_out, c_skip, c_noise, loss weight  (edm.py:24-37); sigma_stride 0 = shared */

@@ -678,3 +678,41 @@ def test_conv_scheme_bf16x3_moves_the_data_gradients_too(monkeypatch):
             assert any(w == _lib.TQ_WFMT_F16_MX6 for w in wf), wf
         grads[scheme] = torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]).cpu()
     assert rel_err(grads["f16mx6"], grads["bf16x3"]) < TOL
+
+
+def test_attention_backward_reuses_the_training_forwards_kv_planes_bit_identically():
+    """Round 5: once a backward plan exists, every attention block's training forward keeps its K / V planes in a workspace of its own
+    and the backward's prep pass forms Q, dO and delta only (tq_attention_bwd_ws_kv).  The first sweep of a plan still re-derives the
+    planes (its forward ran before the plan existed): same inputs, same gradients to the bit on both routes."""
+    from tqdne_amd import LightningEDM
+    sd, d = load_golden("micro_unet.npz")
+    cfg = dict(cfg_of(d), dropout=0.0)
+    edm = LightningEDM(cfg, {"learning_rate": 1e-3, "max_steps": 10, "eta_min": 0.0})
+    edm.unet.load_state_dict(sd)
+    edm = edm.to(dev()).train()
+    g = torch.Generator().manual_seed(21)
+    B, T = 3, 256
+    sig, cond = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev()), torch.randn(B, 5, generator=g).to(dev())
+    eps, noise = torch.randn(B, generator=g).to(dev()), torch.randn(B, 3, T, generator=g).to(dev())
+    runs = []
+    for _ in range(3):
+        for p in edm.unet.parameters():
+            p.grad = None
+        loss = edm.step_with_noise(sig, eps, noise, cond=cond)
+        loss.backward()
+        eng = edm.unet._engine(B, T, dev())
+        runs.append((eng._last["block_kv"], float(loss), torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]).clone()))
+    assert [r[0] for r in runs] == [False, True, True]
+    assert any(t[0] == "attn" and "kv_ws" in t[1] for t in eng.tape)
+    assert runs[0][1] == runs[1][1] == runs[2][1]
+    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[1][2], runs[2][2])
+    # an inference forward in between uses the shared workspace and leaves the kept planes alone
+    edm.eval()
+    with torch.no_grad():
+        edm(sig, torch.full((B,), 0.7, device=dev()), None, cond)
+    edm.train()
+    for p in edm.unet.parameters():
+        p.grad = None
+    loss = edm.step_with_noise(sig, eps, noise, cond=cond)
+    loss.backward()
+    assert torch.equal(runs[0][2], torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]))

@@ -128,6 +128,7 @@ _PROTOS = {
     "tq_attention_workspace_bytes": (SZ, [I, I, I, I]),
     "tq_attention_bwd": (I, [VP] * 6 + [I, I, I, I, VP]),
     "tq_attention_bwd_ws": (I, [VP] * 7 + [I, I, I, I, VP]),
+    "tq_attention_bwd_ws_kv": (I, [VP] * 8 + [I, I, I, I, VP]),
     "tq_edm_scalars": (I, [VP, I, F, VP, VP, VP, VP, VP, I, VP]),
     "tq_cm_scalars": (I, [VP, I, F, F, VP, VP, I, VP]),
     "tq_edm_noise_inject": (I, [VP, VP, VP, F, F, VP, VP, I, I, VP]),

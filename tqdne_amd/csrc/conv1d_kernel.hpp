@@ -575,7 +575,26 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) voi
     };
     // the MFMAs of one (tap, t-block) step for both 16-channel blocks of the wave
     auto mma_step = [&](const Frag (&w)[C::NW], const Frag (&f)[C::NBF], int tb) __attribute__((always_inline)) {
+#ifdef TQ_ABL_NOMMA   // (timing ablation, wrong numerics: no matrix instruction; the operands stay live through an empty asm so that the weight loads
+                      // and LDS fragment reads that feed them are still issued and waited for)
+#pragma unroll
+        for (int q = 0; q < C::NW; ++q) asm volatile("" :: "v"(w[q].u.x), "v"(w[q].u.w));
+#pragma unroll
+        for (int q = 0; q < C::NBF; ++q) asm volatile("" :: "v"(f[q].u.x), "v"(f[q].u.w));
+        return;
+#endif
         if constexpr (SCH == 0) {
+#if defined(TQ_ABL_SCH0_UNITS)   // (timing ablation, wrong numerics: the forward bf16x3 launches with 1 or 2 of their 3 products -- what a
+                                 // cheaper contraction scheme for the 64-channel layers could save at most)
+            if constexpr (EPI == 0) {
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk) {
+                    if (TQ_ABL_SCH0_UNITS >= 2) acc[cbk][tb] = mfma_bf16(w[cbk * 2].v, f[1].v, acc[cbk][tb]);
+                    acc[cbk][tb] = mfma_bf16(w[cbk * 2].v, f[0].v, acc[cbk][tb]);
+                }
+                return;
+            }
+#endif
 #pragma unroll
             for (int cbk = 0; cbk < 2; ++cbk)
                 acc[cbk][tb] = mfma_x3(w[cbk * 2].v, w[cbk * 2 + 1].v, f[0].v, f[1].v, acc[cbk][tb]);

@@ -309,6 +309,8 @@ class UNetEngine:
         self._wfmt_sites = []               # (descriptor, [conv sites packed for it], preferred wfmt)
         self.kv_v_format = _lib.attn_v_format()   # V planes of the inference attention pair (TQ_KV_V_*): a property of the plan
         self._vfmt_ops = []                 # indices into ops_infer of the launches that carry it as their last argument
+        self._attn_train_ops = []           # (index into ops, index into tape, workspace bytes) of every tq_attention_fwd launch
+        self._block_kv = False              # training forwards keep each attention block's K / V planes for its backward
         # set by the conv epilogues (TqConvDesc.range_flag); ONE flag per model and device, shared by every plan of the model (any
         # batch, length, lane): the optimizer launch of the trainer is predicated on it (tq_adam_ema_step_guarded)
         self.range_flag = shared_range_flag(model, device)
@@ -650,6 +652,8 @@ class UNetEngine:
         lse = self._empty(self.B, ab.num_heads, x.T)
         flops = 4 * ab.channels * x.T * x.T * self.B
         op = (self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), _p(lse), _p(ws), self.B, x.T, ab.num_heads, D), "attention", flops)
+        if split is not None:   # (see enable_block_kv: once a backward plan exists this launch gets a workspace of its own)
+            self._attn_train_ops.append((len(self.ops), len(self.tape), ws.numel()))
         infer_op = None
         if split is not None:
             infer_op = (self.lib.tq_attention_fwd_presplit, (_p(qkv.buf), _p(ws), _p(att.buf), self.B, x.T, ab.num_heads, D,
@@ -704,6 +708,22 @@ class UNetEngine:
         self.set_kv_v_format(_lib.TQ_KV_V_BF16)
         self.scheme = "bf16x3"            # (the pack mode is part of every store entry's version tag: the next forward re-packs)
         self.plan_epoch += 1     # captured HIP graphs of this plan are stale
+
+    def enable_block_kv(self):
+        """Called once a backward plan exists: every attention block's TRAINING forward gets a K / V workspace of its own (the shared one
+        is overwritten by the next block), so that the backward re-uses those planes instead of re-deriving them from qkv
+        (tq_attention_bwd_ws_kv).  Forwards already run keep nothing: ``_last["block_kv"]`` says which kind the last one was."""
+        if self._block_kv:
+            return
+        for i, ti, nbytes in self._attn_train_ops:
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)   # (padding rows t >= T stay zero)
+            self._keep.append(ws)
+            fn, args, *rest = self.ops[i]
+            self.ops[i] = (fn, args[:3] + (ws.data_ptr(),) + args[4:], *rest)
+            if self.ops_infer[i] is not self.ops[i] and self.ops_infer[i][0] is fn:   # (D = 128: one op serves both lists)
+                self.ops_infer[i] = self.ops[i]
+            self.tape[ti][1]["kv_ws"] = ws
+        self._block_kv = True
 
     def set_kv_v_format(self, fmt: int):
         """V planes of the inference attention pair (``_lib.TQ_KV_V_*``; the last integer argument of both launches of the pair)."""
@@ -942,7 +962,7 @@ class UNetEngine:
                     check(rc, what)
         self._fwd_count = getattr(self, "_fwd_count", 0) + 1
         self._last = dict(x=x, in_scale=in_scale, c_out=c_out, timesteps=timesteps, cond=cond, train=train,
-                          dropout_p=p, dropout_seed=dropout_seed, infer=infer and not train)
+                          dropout_p=p, dropout_seed=dropout_seed, infer=infer and not train, block_kv=self._block_kv)
         head = m.out[2]
         e0 = ev() if ev else None
         check(lib.tq_head_conv_fwd(_p(self.final.buf), _p(self.head_gn[0]), _p(self.head_gn[1]), _p(head.weight),
@@ -1022,7 +1042,7 @@ class SeqEngine(UNetEngine):
                 d.dropout_p, d.dropout_seed = p, dropout_seed
             else:
                 d.flags &= ~TQ_CONV_DROPOUT
-        self._last = dict(x=x, train=train, dropout_p=p, dropout_seed=dropout_seed)
+        self._last = dict(x=x, train=train, dropout_p=p, dropout_seed=dropout_seed, block_kv=self._block_kv)
         stem = m.input_layer
         check(lib.tq_stem_conv_fwd(_p(x), None, _p(stem.weight), _p(stem.bias), _p(self.stem_out.buf), _p(self.stem_out.stats), B,
                                    m.in_channels, T, stem.out_channels, stem.kernel_size[0], stream), "input layer")

@@ -70,6 +70,7 @@ class BackwardPlan:
         self._trace = None                   # list: HIP-event pairs around every launch of the next sweeps (measurement only)
         self._layout_gradients()
         self._build()
+        eng.enable_block_kv()   # (from the next forward on; this plan's first sweep still re-derives the planes)
 
     # ------------------------------------------------------------------ memory
     def _empty(self, *shape):
@@ -455,8 +456,21 @@ class BackwardPlan:
         Tp = (T + 63) // 64 * 64
         # (D = 128 falls through to the first-generation kernels, which never touch it: no buffer, NULL)
         ws = self.scratch("attn_bwd_ws", 4 * ab.num_heads * Tp * t["D"]) if t["D"] in (32, 64) else None
-        self.ops.append([self.lib.tq_attention_bwd_ws, [_p(qkv.buf), _p(att.buf), _p(datt), _p(t["lse"]), _p(delta), _p(dqkv), _p(ws),
-                                                        B, T, ab.num_heads, t["D"]], "attention bwd"])
+        if ws is not None:
+            # the K / V planes of the training forward are re-used where that forward kept them (engine.enable_block_kv: every forward
+            # after this plan was built); ``t["kv_ws"]`` is filled in by then
+            e, lib = self.e, self.lib
+
+            def attn_bwd(qkv_p, att_p, datt_p, lse_p, delta_p, dqkv_p, ws_p, B_, T_, H_, D_, stream, _t=t):
+                kv = _t.get("kv_ws") if e._last.get("block_kv") else None
+                if kv is not None:
+                    return lib.tq_attention_bwd_ws_kv(qkv_p, att_p, datt_p, lse_p, delta_p, dqkv_p, ws_p, kv.data_ptr(), B_, T_, H_, D_, stream)
+                return lib.tq_attention_bwd_ws(qkv_p, att_p, datt_p, lse_p, delta_p, dqkv_p, ws_p, B_, T_, H_, D_, stream)
+            fn = attn_bwd
+        else:
+            fn = self.lib.tq_attention_bwd_ws
+        self.ops.append([fn, [_p(qkv.buf), _p(att.buf), _p(datt), _p(t["lse"]), _p(delta), _p(dqkv), _p(ws),
+                              B, T, ab.num_heads, t["D"]], "attention bwd"])
         self._wrote(dqkv)
         self._wgrad(t["rec_qkv"], dqkv)
         G = self.scratch("G", T, Cc)
