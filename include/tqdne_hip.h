@@ -41,7 +41,8 @@ typedef struct ihipStream_t* hipStream_t;
  * (Upsample.forward, blocks.py:56-66) written as one k = 3 conv over the un-upsampled input -- even outputs see the taps
  * (w0+w1, w2+w3, w4), odd outputs (w0, w1+w2, w3+w4), 3/5 of the multiply-adds.  C_out = 2*C: output channel block [p*C, (p+1)*C)
  * is phase p and is stored to row 2t+p of a (B, 2*T_out, C) tensor; bias / emb / res are indexed by the real channel / row;
- * statistics: 2*ceil(T_out/128) slots of C channels (slot = 2*tile + p; T_out must be a multiple of 128 with TQ_CONV_STATS). */
+ * statistics: 2*ceil(T_out/128) slots of C channels (slot = 2*tile + p; with TQ_CONV_STATS T_out must be a multiple of 128 or leave
+ * more than 64 rows in its last tile, so that this equals the ceil(2*T_out/128) slots of the (B, 2*T_out, C) tensor). */
 #define TQ_CONV_POLY2 64
 
 /* TqConvDesc.wfmt: how the fp32 product x * w is contracted on the matrix cores (= format of the packed weights).

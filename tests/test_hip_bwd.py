@@ -256,6 +256,40 @@ def test_attention_backward(H, D, T):
             assert rel_err(got[:, sl], qkv.grad[:, sl]) < TOL, (name, ws)
 
 
+@pytest.mark.parametrize("H,D,T", [(4, 64, 512), (2, 32, 62), (2, 64, 127)])
+def test_attention_backward_on_the_forwards_kv_planes_is_bit_identical(H, D, T):
+    """tq_attention_bwd_ws_kv (round 5): the backward takes the K / V planes the training forward wrote into its workspace instead of
+    re-deriving them from qkv -- same planes, same kernels behind the prep pass: dqkv and delta to the bit."""
+    from tqdne_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7 * H + D + T)
+    B = 2
+    d = dev()
+    qkv = (torch.randn(B, T, 3 * H * D, generator=g) * 1.2).to(d)
+    dout = torch.randn(B, T, H * D, generator=g).to(d)
+    out, lse = torch.empty(B, T, H * D, device=d), torch.empty(B, H, T, device=d)
+    nws = lib.tq_attention_workspace_bytes(B, T, H, D)
+    kv = torch.zeros(nws, dtype=torch.uint8, device=d)   # (padding rows t >= T must be zero)
+    p = lambda t: t.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tq_attention_fwd(p(qkv), p(out), p(lse), p(kv), B, T, H, D, st) == 0
+    res = []
+    for use_kv in (False, True):
+        dqkv, delta = torch.full_like(qkv, float("nan")), torch.empty(B, H, T, device=d)
+        ws = torch.full((2 * nws,), 0xFF, dtype=torch.uint8, device=d)   # (garbage: what the kv route does not write it must not read)
+        if use_kv:
+            rc = lib.tq_attention_bwd_ws_kv(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), p(ws), p(kv), B, T, H, D, st)
+        else:
+            rc = lib.tq_attention_bwd_ws(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), p(ws), B, T, H, D, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res.append((dqkv, delta))
+    assert torch.isfinite(res[1][0]).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert lib.tq_attention_bwd_ws_kv(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), p(ws), None, B, T, H, D, st) == -1   # TQ_ERR_ARG
+    assert lib.tq_attention_bwd_ws_kv(p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), p(ws), p(kv), B, T, H, 128, st) == -2  # TQ_ERR_SHAPE
+
+
 # ---------------------------------------------------------------------------------------------------------------- round 4
 @pytest.mark.parametrize("cin,cout,k,T,scale", [(128, 256, 5, 200, 1e-6), (256, 256, 5, 333, 3e-5), (256, 128, 3, 127, 1.0),
                                                 (512, 256, 1, 100, 1e-9), (384, 256, 5, 130, 2e3), (128, 768, 1, 256, 1e-6)])

@@ -187,7 +187,8 @@ def test_conv_downsample(C, T):
     assert rel_err(st.cpu(), ref_stats(ref)) < TOL
 
 
-@pytest.mark.parametrize("C0,C1,Co,T", [(256, 0, 256, 256), (128, 0, 128, 384), (64, 64, 64, 128), (32, 0, 32, 128), (256, 0, 128, 512)])
+@pytest.mark.parametrize("C0,C1,Co,T", [(256, 0, 256, 256), (128, 0, 128, 384), (64, 64, 64, 128), (32, 0, 32, 128), (256, 0, 128, 512),
+                                        (256, 0, 256, 508), (128, 0, 128, 1016), (64, 0, 64, 252)])   # (ragged: the 4064-sample signals)
 def test_conv_upsample_polyphase(C0, C1, Co, T):
     """TQ_CONV_POLY2: nearest x2 upsampling + conv k = 5 (Upsample.forward, blocks.py:56-66) as one two-phase k = 3 conv over the
     un-upsampled rows, through the C ABI: output, and the GroupNorm partial statistics summed over their slots."""
@@ -208,7 +209,7 @@ def test_conv_upsample_polyphase(C0, C1, Co, T):
     for wfmt in {_lib.forward_wfmt(2 * Co, [C0, C1]), _lib.TQ_WFMT_BF16X3}:
         wp = ops.pack_conv_weight(w2.to(d), _lib.PACK_MODE[wfmt])
         y = torch.full((B, 2 * T, Co), float("nan"), device=d)
-        st = torch.full((B, 2 * T // 128, Co, 2), float("nan"), device=d)
+        st = torch.full((B, (2 * T + 127) // 128, Co, 2), float("nan"), device=d)
         desc = _lib.TqConvDesc()
         desc.B, desc.T_in, desc.T_out, desc.C_in0, desc.C_in1, desc.C_out = B, T, T, C0, C1, 2 * Co
         desc.ktaps, desc.stride, desc.pad, desc.upsample = 3, 1, 1, 0
@@ -222,7 +223,7 @@ def test_conv_upsample_polyphase(C0, C1, Co, T):
         tot = st.cpu().double().sum(1)
         assert rel_err(tot[..., 0].float(), ref.double().sum(-1).float()) < TOL
         assert rel_err(tot[..., 1].float(), (ref.double() ** 2).sum(-1).float()) < TOL
-    desc.T_in = desc.T_out = T - 64  # statistics slots need whole 128-row tiles
+    desc.T_in = desc.T_out = T // 128 * 128 + 64  # a last tile of <= 64 rows: one statistics slot more than the tensor has
     assert lib.tq_conv1d_fwd(C_.byref(desc), p(x0), p(x1), None, None, p(wp), p(bd), None, None, p(y), p(st),
                              torch.cuda.current_stream().cuda_stream) == -2  # TQ_ERR_SHAPE
 

@@ -653,8 +653,8 @@ def test_sampler_does_not_retain_start_state():
 def test_conv_scheme_bf16x3_moves_the_data_gradients_too(monkeypatch):
     """TQDNE_CONV_SCHEME=bf16x3 is the documented fp32-range switch: forward convs AND data gradients must then run the three-product
     scheme (round-4 advisor finding: the data gradients kept fp16-packed weights).  The default leaves f16+mx6 data gradients on."""
-    from tqdne_amd import LightningEDM, _lib, tiny_1d_unet_config
-    cfg = dict(tiny_1d_unet_config(), model_channels=128, num_heads=8, dropout=0.0)   # (128 | C_in: the mx6 data gradient is eligible; head dim 64)
+    from tqdne_amd import LightningEDM, _lib, paper_1d_unet_config
+    cfg = dict(paper_1d_unet_config(), dropout=0.0)   # (has 128 | C_in layers: the mx6 data gradient is eligible)
     g = torch.Generator().manual_seed(5)
     B, T = 2, 512
     sig, cond = 0.5 * torch.randn(B, 3, T, generator=g), torch.randn(B, 5, generator=g)
@@ -680,10 +680,10 @@ def test_conv_scheme_bf16x3_moves_the_data_gradients_too(monkeypatch):
     assert rel_err(grads["f16mx6"], grads["bf16x3"]) < TOL
 
 
-def test_attention_backward_reuses_the_training_forwards_kv_planes_bit_identically():
+def test_attention_backward_reuses_the_training_forwards_kv_planes():
     """Round 5: once a backward plan exists, every attention block's training forward keeps its K / V planes in a workspace of its own
     and the backward's prep pass forms Q, dO and delta only (tq_attention_bwd_ws_kv).  The first sweep of a plan still re-derives the
-    planes (its forward ran before the plan existed): same inputs, same gradients to the bit on both routes."""
+    planes (its forward ran before the plan existed): same inputs, same gradients on both routes."""
     from tqdne_amd import LightningEDM
     sd, d = load_golden("micro_unet.npz")
     cfg = dict(cfg_of(d), dropout=0.0)
@@ -704,8 +704,12 @@ def test_attention_backward_reuses_the_training_forwards_kv_planes_bit_identical
         runs.append((eng._last["block_kv"], float(loss), torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]).clone()))
     assert [r[0] for r in runs] == [False, True, True]
     assert any(t[0] == "attn" and "kv_ws" in t[1] for t in eng.tape)
-    assert runs[0][1] == runs[1][1] == runs[2][1]
-    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[1][2], runs[2][2])
+    # (column sums and GroupNorm-backward sums use atomics: two sweeps agree to rounding, not to the bit -- the two routes must agree as
+    # closely as two sweeps of the same route do)
+    same_route = rel_err(runs[2][2].cpu(), runs[1][2].cpu())
+    two_routes = rel_err(runs[1][2].cpu(), runs[0][2].cpu())
+    print(f"attention backward: planes re-derived vs re-used {two_routes:.2e}; re-used twice {same_route:.2e}")
+    assert abs(runs[0][1] - runs[1][1]) < 1e-6 * abs(runs[0][1]) and two_routes < 2e-6 and same_route < 2e-6
     # an inference forward in between uses the shared workspace and leaves the kept planes alone
     edm.eval()
     with torch.no_grad():
@@ -715,4 +719,4 @@ def test_attention_backward_reuses_the_training_forwards_kv_planes_bit_identical
         p.grad = None
     loss = edm.step_with_noise(sig, eps, noise, cond=cond)
     loss.backward()
-    assert torch.equal(runs[0][2], torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]))
+    assert rel_err(torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]).cpu(), runs[0][2].cpu()) < 2e-6

@@ -482,7 +482,8 @@ class UNetEngine:
                 _p(site.packed), _p(site.bias), emb_ptr, _p(res.buf) if res else None, _p(out.buf), _p(out.stats)),
                 "conv:" + site.name, flops)
             infer_op = None
-            if (upsample and site.K == 5 and T_in % STAT_SLOT == 0 and site.C_out % 32 == 0 and gn is None and res is None
+            # (two-phase form: its 2 * ceil(T_in / 128) statistics slots must be the tensor's ceil(2 T_in / 128))
+            if (upsample and site.K == 5 and (T_in % STAT_SLOT == 0 or T_in % STAT_SLOT > STAT_SLOT // 2) and site.C_out % 32 == 0 and gn is None and res is None
                     and emb_ptr is None and os.environ.get("TQDNE_POLYPHASE_UPSAMPLE", "1") != "0"):
                 self._poly_desc = None
                 infer_op = self._polyphase_op(site, d, s0, s1, out, flops)
