@@ -565,7 +565,7 @@ def test_inference_forward_matches_backward_capable_forward(which):
     with pytest.raises(RuntimeError):
         eng.backward(torch.zeros_like(a), torch.ones((), device=dev()))
     # default plan: the upsampling convs additionally run as two-phase k = 3 convs at inference (TQ_CONV_POLY2, where the
-    # un-upsampled length is a multiple of 128): same sums in a different order -> fp32-rounding-level differences only
+    # un-upsampled length is a multiple of 128 or leaves more than half a slot): same sums in a different order -> fp32-rounding-level differences only
     eng2 = net._engine(B, T, dev())
     a2 = eng2.forward(x, t, cond).clone()
     eng2.set_kv_v_format(_lib.TQ_KV_V_BF16)
@@ -573,7 +573,8 @@ def test_inference_forward_matches_backward_capable_forward(which):
     eng2.set_kv_v_format(_lib.TQ_KV_V_F16)
     assert torch.equal(a2, a)
     npoly = sum(op[2].endswith("+polyphase") for op in eng2.ops_infer)
-    assert npoly == (3 if which == "paper" else 0)
+    # (micro at T = 248: the up-sampling conv over 124 rows qualifies since round 5 -- a last tile of more than 64 rows --, the one over 62 does not)
+    assert npoly == (3 if which == "paper" else 1)
     assert rel_err(b2.cpu(), a.cpu()) < 4e-5
 
 
