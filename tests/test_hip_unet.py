@@ -721,3 +721,55 @@ def test_attention_backward_reuses_the_training_forwards_kv_planes():
     loss = edm.step_with_noise(sig, eps, noise, cond=cond)
     loss.backward()
     assert rel_err(torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]).cpu(), runs[0][2].cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("which,B,T", [("micro", 3, 256), ("paper", 2, 1024)])
+def test_use_checkpoint_recomputes_block_activations_same_gradients_less_memory(which, B, T):
+    """``use_checkpoint=True`` (reference unet.py:202,129; blocks.py:137; nn.py:137-215: block-internal activations are recomputed in the
+    backward instead of kept): here the activations inside a ResBlock (conv1's output and its statistics) and inside an AttentionBlock
+    (qkv, the attention output, the log-sum-exp, the K / V planes) live in buffers shared by all blocks of a shape, and the backward plan
+    re-issues the block's forward launches first.  Same loss, same gradients (to the rounding of the atomics-summed column sums), fewer
+    bytes held by the plans; and the forward's result does not depend on the flag."""
+    from tqdne_amd import LightningEDM, paper_1d_unet_config
+    if which == "micro":
+        sd, d = load_golden("micro_unet.npz")
+        cfg = dict(cfg_of(d), dropout=0.1)
+    else:
+        cfg = dict(paper_1d_unet_config(), dropout=0.1)
+        torch.manual_seed(0)
+        sd = perturbed_state(LightningEDM(cfg, {"learning_rate": 1e-3, "max_steps": 10, "eta_min": 0.0}).unet, 9)
+    g = torch.Generator().manual_seed(31)
+    sig, cond = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev()), torch.randn(B, 5, generator=g).to(dev())
+    eps, noise = torch.randn(B, generator=g).to(dev()), torch.randn(B, 3, T, generator=g).to(dev())
+    from tqdne_amd import rng
+    res = {}
+    for ck in (False, True):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        base = torch.cuda.memory_allocated()
+        edm = LightningEDM(dict(cfg, use_checkpoint=ck), {"learning_rate": 1e-3, "max_steps": 10, "eta_min": 0.0})
+        edm.unet.load_state_dict(sd)
+        edm = edm.to(dev()).train()
+        steps = []
+        for _ in range(2):   # (the second step runs on the kept / recomputed K / V planes)
+            rng.seed_rank(77, 0)   # same dropout masks in every run
+            for p in edm.unet.parameters():
+                p.grad = None
+            loss = edm.step_with_noise(sig, eps, noise, cond=cond)
+            loss.backward()
+            steps.append((float(loss), torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]).clone()))
+        torch.cuda.synchronize()
+        eng = edm.unet._engine(B, T, dev())
+        assert eng.ckpt == ck
+        nrec = sum(op[2].startswith("recompute:") for op in eng._bwd.ops)
+        n_res = sum(t[0] == "res" for t in eng.tape)
+        n_att = sum(t[0] == "attn" for t in eng.tape)
+        assert nrec == (2 * n_res + 2 * n_att if ck else 0)
+        res[ck] = dict(steps=steps, mem=torch.cuda.memory_allocated() - base)
+        del edm, eng
+    for s in (0, 1):
+        assert abs(res[True]["steps"][s][0] - res[False]["steps"][s][0]) < 1e-6 * abs(res[False]["steps"][s][0])
+        e = rel_err(res[True]["steps"][s][1].cpu(), res[False]["steps"][s][1].cpu())
+        assert e < 2e-6, (s, e)
+    print(f"use_checkpoint ({which}, B={B}, T={T}): plan memory {res[False]['mem'] / 2**20:.1f} -> {res[True]['mem'] / 2**20:.1f} MiB")
+    assert res[True]["mem"] < 0.95 * res[False]["mem"]

@@ -147,6 +147,15 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) voi
     const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
 #endif
 
+#ifdef TQ_EXP_STAGGER
+    // experiment (round 5): the workgroups of one launch run in lock-step -- every CU in its load burst, then in its MFMA loop, then in
+    // its store burst (DESIGN_LOG.md).  Start them apart: workgroup i sleeps (hash(i) % 8) * p.exp_stagger * 64 cycles first, so that the
+    // bursts of one round spread over the round (first-round workgroups only matter: later ones start when a CU frees up).
+    if (p.exp_stagger > 0) {
+        const unsigned k = (blockIdx.x * 2654435761u) >> 29;
+        for (unsigned i = 0; i < k * (unsigned)p.exp_stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1353,7 +1362,11 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
                     return launch<KT, STRIDE, UPS, 4, 2, EPI, ACT, FUSE, 2, false, 4, 4>(a, s);
             }
 #endif
-            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
+            // TQDNE_CONV_TILE256=0 (A/B switch, round 5): 256-channel outputs as two co-resident 4-wave workgroups (128 channels each) instead
+            // of one 8-wave one.  Per layer 2-8 % slower (round 2: co-resident workgroups of ONE launch run in lock-step, and every input
+            // tile is staged twice); re-measured under the 4-lane sampler, where co-resident workgroups of different lanes are out of phase
+            static const int tile256 = [] { const char* e = getenv("TQDNE_CONV_TILE256"); return (e && e[0] == '0') ? 0 : 1; }();
+            if (tile256 && a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
 #ifdef TQ_EXP_WN2
             if constexpr (KT == 5 && UPS == 0 && EPI == 0 && ACT >= 2) {
                 // experiment: 128 channels x 256 positions in ONE 8-wave workgroup instead of two co-resident 4-wave ones -- the weights

@@ -17,6 +17,11 @@ extern "C" int tq_conv_tile_co(int C_out) {
     return 32;
 }
 
+static int conv_exp_stagger() {   // (TQDNE_CONV_STAGGER: see -DTQ_EXP_STAGGER in conv1d_kernel.hpp; 0 in default builds' kernels: unread)
+    static const int v = [] { const char* e = getenv("TQDNE_CONV_STAGGER"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1, const float* gscale, const float* gshift,
                            const void* wpk, const float* bias, const float* emb, const float* res, const float* skip_x0,
                            const float* skip_x1, const float* skip_bias, float* y, float* stats, hipStream_t stream,
@@ -110,7 +115,7 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.kv = kv_planes; a.kvH = kvH; a.kvD = kvD; a.kvTp = kvTp; a.kvscale = kvscale; a.kv_vf16 = (kv_planes && kv_vf16) ? 1 : 0;
     a.range_flag = d->range_flag;
     a.in_amax = nullptr;
-    a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
+    a.gf_counters = nullptr; a.exp_stagger = conv_exp_stagger(); a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
     a.gf_gamma = a.gf_beta = nullptr; a.gf_gscale = a.gf_gshift = a.gf_mean_rstd = nullptr;
 #ifndef TQ_BUILD_EXPERIMENTS
     if (d->gn_fuse) return TQ_ERR_ARG;   // reserved: the in-launch GroupNorm fold is an experiment (TQDNE_BUILD_EXPERIMENTS=1 builds it)
@@ -194,7 +199,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     }
     a.kv = nullptr; a.kvH = a.kvD = a.kvTp = 0; a.kvscale = 1.f; a.kv_vf16 = 0;
     a.range_flag = nullptr;
-    a.gf_counters = nullptr; a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
+    a.gf_counters = nullptr; a.exp_stagger = conv_exp_stagger(); a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
     a.gf_gamma = a.gf_beta = nullptr; a.gf_gscale = a.gf_gshift = a.gf_mean_rstd = nullptr;
     return conv_launch_dgrad(a, d->ktaps, stream);
 }

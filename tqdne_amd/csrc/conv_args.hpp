@@ -53,6 +53,7 @@ struct ConvArgs {
     float* gf_gscale;
     float* gf_gshift;
     float* gf_mean_rstd;
+    int exp_stagger;   // experiment builds (-DTQ_EXP_STAGGER): s_sleep units by which the workgroups of a launch start apart; else 0, unread
 };
 
 

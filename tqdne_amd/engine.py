@@ -309,6 +309,8 @@ class UNetEngine:
         self._wfmt_sites = []               # (descriptor, [conv sites packed for it], preferred wfmt)
         self.kv_v_format = _lib.attn_v_format()   # V planes of the inference attention pair (TQ_KV_V_*): a property of the plan
         self._vfmt_ops = []                 # indices into ops_infer of the launches that carry it as their last argument
+        self.ckpt = bool(getattr(model, "use_checkpoint", False))   # block-internal activations shared + recomputed in the backward
+        self._ckpt_pool = {}
         self._attn_train_ops = []           # (index into ops, index into tape, workspace bytes) of every tq_attention_fwd launch
         self._block_kv = False              # training forwards keep each attention block's K / V planes for its backward
         # set by the conv epilogues (TqConvDesc.range_flag); ONE flag per model and device, shared by every plan of the model (any
@@ -342,6 +344,20 @@ class UNetEngine:
 
     def _act(self, C_: int, T_: int, stats: bool = True, slot: int = STAT_SLOT) -> Act:
         a = Act(self._empty(self.B, T_, C_), self._empty(self.B, (T_ + slot - 1) // slot, C_, 2) if stats else None, C_, T_, slot)
+        self.acts.append(a)
+        return a
+
+    def _ckpt_act(self, tag: str, C_: int, T_: int, stats: bool = True, slot: int = STAT_SLOT) -> Act:
+        """``use_checkpoint`` plans (reference nn.py:137-215: a block's intermediate activations are not kept for the backward but
+        recomputed there): an activation INSIDE a ResBlock / AttentionBlock lives in a buffer shared by every block of the plan with
+        that shape; the backward plan re-issues the block's forward launches in front of the block's backward.  Each block still gets
+        an Act of its own (gradient bookkeeping), the tensors are shared."""
+        key = (tag, C_, T_, stats, slot)
+        first = self._ckpt_pool.get(key)
+        if first is None:
+            first = self._ckpt_pool[key] = self._act(C_, T_, stats, slot)
+            return first
+        a = Act(first.buf, first.stats, C_, T_, slot)
         self.acts.append(a)
         return a
 
@@ -407,7 +423,7 @@ class UNetEngine:
 
     def _conv(self, srcs: Sequence[Act], site: ConvSite, *, gn=None, silu=False, emb_ptr=None, res: Optional[Act] = None,
               stats=True, stride=1, upsample=False, dropout_site: Optional[int] = None, launch: bool = True,
-              skip: Optional[Tuple[Sequence[Act], ConvSite]] = None, qkv_planes=None) -> Optional[Act]:
+              skip: Optional[Tuple[Sequence[Act], ConvSite]] = None, qkv_planes=None, ckpt_tag: Optional[str] = None) -> Optional[Act]:
         """launch=False only records the conv (descriptor for its gradients): its product is formed by another launch.
         skip=(srcs, 1x1 site): fuse that convolution of the un-activated srcs into this launch (site.packed holds both)."""
         s0 = srcs[0]
@@ -428,7 +444,10 @@ class UNetEngine:
         # the small tile where it is built (see SMALL_TILE_B): the ResBlock convs of a small-batch plan
         small = (launch and (self.B <= SMALL_TILE_B or (self.solo and self.B * ((T_out + 127) // 128) <= SMALL_TILE_WGS)) and stride == 1 and not upsample and site.K == 5 and gn is not None and silu
                  and qkv_planes is None and wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX6) and not GN_FUSE)
-        out = self._act(site.C_out, T_out, stats, slot=32 if small else STAT_SLOT) if launch else None
+        if launch and ckpt_tag is not None and self.ckpt:
+            out = self._ckpt_act(ckpt_tag, site.C_out, T_out, stats, slot=32 if small else STAT_SLOT)
+        else:
+            out = self._act(site.C_out, T_out, stats, slot=32 if small else STAT_SLOT) if launch else None
         d = TqConvDesc()
         d.t_tile = 32 if small else 0
         d.B, d.T_in, d.T_out = self.B, T_in, T_out
@@ -613,9 +632,13 @@ class UNetEngine:
         srcs = list(x) if isinstance(x, tuple) else [x]
         emb_ptr = self.emb_all.data_ptr() + 4 * self.emb_offsets[id(rb)] if hasattr(rb, "emb_layers") else None
         g1 = self._gn(srcs, rb.in_layers[0])
-        h1 = self._conv(srcs, self._site(name + ".in_layers.2", rb.in_layers[2]), gn=g1, silu=True, emb_ptr=emb_ptr)
+        i_conv1 = len(self.ops)
+        h1 = self._conv(srcs, self._site(name + ".in_layers.2", rb.in_layers[2]), gn=g1, silu=True, emb_ptr=emb_ptr, ckpt_tag="h1")
         rec1 = self.last_rec
+        i_gn2 = len(self.ops)
         g2 = self._gn([h1], rb.out_layers[0])
+        # use_checkpoint: h1 and its statistics live in a shared buffer; the backward re-issues [conv1, GroupNorm 2's fold] first
+        recompute = list(range(i_conv1, len(self.ops))) if self.ckpt else None
         rec_sk = None
         conv2 = rb.out_layers[3]
         self._site_counter += 1
@@ -635,7 +658,7 @@ class UNetEngine:
             out = self._conv([h1], self._site(name + ".out_layers.3", conv2), gn=g2, silu=True, res=res,
                              dropout_site=self._site_counter)
         self.tape.append(("res", dict(rb=rb, srcs=srcs, g1=g1, g2=g2, h1=h1, out=out, rec1=rec1, rec2=self.last_rec,
-                                      rec_sk=rec_sk)))
+                                      rec_sk=rec_sk, recompute=recompute)))
         return out
 
     def _attention(self, x: Act, ab, name: str) -> Act:
@@ -647,13 +670,19 @@ class UNetEngine:
         # inference forwards: the qkv projection writes K / V as the attention kernel's bf16 hi / lo planes itself (no fp32 K / V,
         # no split pass: -134 MB and one launch per block); forwards a backward may follow keep fp32 qkv for tq_attention_bwd
         split = (ws, ab.num_heads, D) if D in (32, 64) else None
-        qkv = self._conv([x], self._site(name + ".qkv", ab.qkv), gn=g, silu=False, stats=False, qkv_planes=split)
+        i_qkv = len(self.ops)
+        qkv = self._conv([x], self._site(name + ".qkv", ab.qkv), gn=g, silu=False, stats=False, qkv_planes=split, ckpt_tag="qkv")
         rec_qkv = self.last_rec
-        att = self._act(ab.channels, x.T, False)
-        lse = self._empty(self.B, ab.num_heads, x.T)
+        att = self._ckpt_act("att", ab.channels, x.T, False) if self.ckpt else self._act(ab.channels, x.T, False)
+        if self.ckpt:
+            lse = self._ckpt_pool.get(("lse", ab.num_heads, x.T))
+            if lse is None:
+                lse = self._ckpt_pool[("lse", ab.num_heads, x.T)] = self._empty(self.B, ab.num_heads, x.T)
+        else:
+            lse = self._empty(self.B, ab.num_heads, x.T)
         flops = 4 * ab.channels * x.T * x.T * self.B
         op = (self.lib.tq_attention_fwd, (_p(qkv.buf), _p(att.buf), _p(lse), _p(ws), self.B, x.T, ab.num_heads, D), "attention", flops)
-        if split is not None:   # (see enable_block_kv: once a backward plan exists this launch gets a workspace of its own)
+        if split is not None and not self.ckpt:   # (see enable_block_kv: once a backward plan exists this launch gets a workspace of its own)
             self._attn_train_ops.append((len(self.ops), len(self.tape), ws.numel()))
         infer_op = None
         if split is not None:
@@ -661,9 +690,15 @@ class UNetEngine:
                                                              self.kv_v_format), "attention", flops)
             self._vfmt_ops.append(len(self.ops_infer))
         self._emit(op, infer_op, nbytes=4 * self.B * x.T * 4 * ab.channels)
+        # use_checkpoint: qkv, the attention output, the log-sum-exp and the K / V planes live in shared buffers; the backward re-issues
+        # [qkv projection, attention core] first -- which also leaves THIS block's K / V planes in the shared workspace
+        recompute = list(range(i_qkv, len(self.ops))) if self.ckpt else None
         out = self._conv([att], self._site(name + ".proj_out", ab.proj_out), res=x)
-        self.tape.append(("attn", dict(ab=ab, x=x, g=g, qkv=qkv, att=att, lse=lse, out=out, rec_qkv=rec_qkv,
-                                       rec_proj=self.last_rec, D=D)))
+        entry = dict(ab=ab, x=x, g=g, qkv=qkv, att=att, lse=lse, out=out, rec_qkv=rec_qkv, rec_proj=self.last_rec, D=D,
+                     recompute=recompute)
+        if self.ckpt and split is not None:
+            entry["kv_ws"], entry["kv_always"] = ws, True
+        self.tape.append(("attn", entry))
         return out
 
     def _attn_workspace(self, nbytes: int):

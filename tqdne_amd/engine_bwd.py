@@ -400,7 +400,16 @@ class BackwardPlan:
             self.ops[i][1][7] = self.ws.data_ptr()
             self.ops[i][1][8] = self.ws.numel()
 
+    def _recompute(self, t):
+        """use_checkpoint plans: re-issue the block's forward launches (same pre-bound calls as the forward plan's) so that its shared
+        intermediate buffers hold THIS block's activations again.  The run loop makes the main stream wait for the weight-gradient
+        stream in front of them: a weight gradient of the block swept before may still be reading the shared buffers."""
+        for i in t.get("recompute") or ():
+            fn, args, what, _fl = self.e.ops[i]
+            self.ops.append([fn, list(args), "recompute:" + what])
+
     def _bwd_res(self, t):
+        self._recompute(t)
         rb, srcs, h1, out = t["rb"], t["srcs"], t["h1"], t["out"]
         rec1, rec2, rec_sk = t["rec1"], t["rec2"], t["rec_sk"]
         B, T, Co = self.B, out.T, out.C
@@ -441,6 +450,7 @@ class BackwardPlan:
                 coff += s.C
 
     def _bwd_attn(self, t):
+        self._recompute(t)
         ab, x, qkv, att, out = t["ab"], t["x"], t["qkv"], t["att"], t["out"]
         B, T, Cc = self.B, x.T, x.C
         assert out.gw
@@ -462,7 +472,7 @@ class BackwardPlan:
             e, lib = self.e, self.lib
 
             def attn_bwd(qkv_p, att_p, datt_p, lse_p, delta_p, dqkv_p, ws_p, B_, T_, H_, D_, stream, _t=t):
-                kv = _t.get("kv_ws") if e._last.get("block_kv") else None
+                kv = _t.get("kv_ws") if (e._last.get("block_kv") or _t.get("kv_always")) else None
                 if kv is not None:
                     return lib.tq_attention_bwd_ws_kv(qkv_p, att_p, datt_p, lse_p, delta_p, dqkv_p, ws_p, kv.data_ptr(), B_, T_, H_, D_, stream)
                 return lib.tq_attention_bwd_ws(qkv_p, att_p, datt_p, lse_p, delta_p, dqkv_p, ws_p, B_, T_, H_, D_, stream)
@@ -569,6 +579,8 @@ class BackwardPlan:
                 self._side_evs = {}
             fire, late = self._fire_points(bucket_elems) if on_bucket is not None else ({}, ())
             for i, (fn, args, what) in enumerate(self.ops):
+                if what.startswith("recompute:"):   # (use_checkpoint: shared block-internal buffers are about to be overwritten)
+                    main_t.wait_stream(side)
                 if what.startswith("wgrad:"):   # (the column sums on that stream too: measured equal)
                     ev = self._side_evs.get(i)
                     if ev is None:

@@ -144,6 +144,8 @@ class UNetModel(nn.Module):
             from . import family2d
             family2d.announce()
         # flash_attention is accepted and ignored: the fused kernel is always flash-style (blocks.py:193-230 needs flash_attn)
+        # use_checkpoint (unet.py:129, blocks.py:137, nn.py:137-215): plans of this model keep no activation INSIDE a ResBlock /
+        # AttentionBlock for the backward (shared buffers, engine._ckpt_act) and recompute them there (engine_bwd._recompute); dims=1 only
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
         self.num_res_blocks, self.attention_resolutions = num_res_blocks, tuple(attention_resolutions)
         self.dropout, self.channel_mult, self.conv_kernel_size = dropout, tuple(channel_mult), conv_kernel_size
