@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) voi
     // experiment (round 5): the workgroups of one launch run in lock-step -- every CU in its load burst, then in its MFMA loop, then in
     // its store burst (DESIGN_LOG.md).  Start them apart: workgroup i sleeps (hash(i) % 8) * p.exp_stagger * 64 cycles first, so that the
     // bursts of one round spread over the round (first-round workgroups only matter: later ones start when a CU frees up).
-    if (p.exp_stagger > 0) {
+    if (p.exp_stagger > 0 && blockIdx.x < 256u * (64 * WM * WN == 512 ? 1u : 2u)) {
         const unsigned k = (blockIdx.x * 2654435761u) >> 29;
         for (unsigned i = 0; i < k * (unsigned)p.exp_stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
