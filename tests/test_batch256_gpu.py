@@ -109,6 +109,42 @@ def test_reference_default_batch_256_train_step_and_sampler():
     assert peak_train < 200 * 2**30 and peak_smp < 200 * 2**30
 
 
+@pytest.mark.timeout(600)
+def test_batch_256_train_step_with_use_checkpoint_reports_memory():
+    """the same B = 256 training step with ``use_checkpoint=True`` (block-internal activations shared and recomputed): finite, same loss
+    as without, and the peak memory of the two printed side by side"""
+    import gc
+    from tqdne_amd import LightningEDM, paper_1d_unet_config, rng
+    B, T = 256, 4096
+    g = torch.Generator().manual_seed(256)
+    sig = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev())
+    cond = torch.randn(B, 5, generator=g).to(dev())
+    eps, noise = torch.randn(B, generator=g).to(dev()), torch.randn(B, 3, T, generator=g).to(dev())
+    out = {}
+    for ck in (False, True):
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        edm = LightningEDM(dict(paper_1d_unet_config(), dropout=0.1, use_checkpoint=ck), {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
+        edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
+        edm = edm.to(dev()).train()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        rng.seed_rank(5, 0)
+        loss = edm.step_with_noise(sig, eps, noise, cond=cond)
+        loss.backward()
+        torch.cuda.synchronize()
+        gsum = float(sum(p.grad.double().abs().sum() for p in edm.unet.parameters() if p.grad is not None))
+        out[ck] = (float(loss.detach()), gsum, (torch.cuda.max_memory_allocated() - base) / 2**30)
+        assert torch.isfinite(loss.detach()) and gsum == gsum
+        del edm, loss
+    print(f"B=256 train step, peak memory above weights + inputs: {out[False][2]:.1f} GiB; with use_checkpoint {out[True][2]:.1f} GiB")
+    assert abs(out[True][0] - out[False][0]) < 1e-6 * abs(out[False][0])
+    assert abs(out[True][1] - out[False][1]) < 1e-4 * out[False][1]
+    assert out[True][2] < out[False][2]
+
+
 def test_plan_cache_evicts_and_rebuilt_plan_reproduces():
     """micro UNet, eight batch sizes through a cache of six shapes: the first two are evicted, their re-built plans give the same bits"""
     from conftest import cfg_of, load_golden
