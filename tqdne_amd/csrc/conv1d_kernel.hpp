@@ -781,13 +781,29 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) voi
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    if constexpr (SCH == 2 && ACT >= 1) {  // folded GroupNorm coefficients of sample b -> LDS (read by write16)
-        const float4* gsrc = reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin);
-        const float4* hsrc = reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin);
-        float4* g4 = reinterpret_cast<float4*>(gtab);
-        for (int i = tid; i < (Cin >> 2); i += C::NTHR) { g4[i] = gsrc[i]; g4[(Cin >> 2) + i] = hsrc[i]; }
-        __syncthreads();
+    // Folded GroupNorm coefficients of sample b -> LDS table (read by write16): C_in <= 1024 floats each, i.e. at most ONE float4 of
+    // either array per thread (scheme-2 tiles have >= 256 threads).  Round 5: the two loads are issued HERE and stored to LDS only after
+    // the first chunk's staging loads and the first weight fragments have been requested (gtab_store below), so that the prologue
+    // pays one global round trip, not two in a row (table, barrier, then the chunk).  Branch-free: threads past the table repeat
+    // its last entry (same value to the same slot).
+    static_assert(!(SCH == 2 && ACT >= 1) || C::NTHR >= 256, "one table entry per thread");
+    float4 gt_a = make_float4(0.f, 0.f, 0.f, 0.f), gt_s = gt_a;
+    int gt_i = 0;
+    if constexpr (SCH == 2 && ACT >= 1) {
+        const int n4 = Cin >> 2;
+        gt_i = tid < n4 ? tid : n4 - 1;
+        gt_a = reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin)[gt_i];
+        gt_s = reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin)[gt_i];
     }
+    auto gtab_store = [&]() __attribute__((always_inline)) {
+        if constexpr (SCH == 2 && ACT >= 1) {
+            float4* g4 = reinterpret_cast<float4*>(gtab);
+            g4[gt_i] = gt_a;
+            g4[(Cin >> 2) + gt_i] = gt_s;
+            __syncthreads();
+        }
+    };
+    if constexpr (PW) gtab_store();   // (the input-stationary form stages all its chunks in one pass right below)
     const int npass = PW ? n_ctiles : 1;
     if constexpr (PW) {
         // every chunk's loads in flight together (64 + 32 registers, nothing else is live yet), then one transform + store pass
@@ -857,6 +873,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                 if (KT > 1 || nskip > 0) load_w(1, wb);
             }
         }
+        gtab_store();
         stage_write(0, 0);
         __syncthreads();
 #ifdef TQ_STAMP

@@ -35,6 +35,18 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
     const int tid = threadIdx.x, nthr = blockDim.x;
     double* csum = sh;            // [C][2] channel sums
     double* gstat = sh + 2 * C;   // [32][2] group mean / rstd
+    // (round 5) the affine parameters of this thread's channels are requested FIRST: they used to be loaded in the last step, a third
+    // dependent global round trip behind the statistics and the group reduction
+    constexpr int NPRE = 4;
+    const bool pre = C <= NPRE * nthr;
+    float gam[NPRE], bet[NPRE];
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+        const int c = tid + j * nthr;
+        const int cc = (pre && c < C) ? c : 0;
+        gam[j] = gamma[cc];
+        bet[j] = beta[cc];
+    }
     // thread = (channel, slot part): PARTS threads share one channel's slots so the dependent-load chain is short
     const int PARTS = (C <= 64) ? 4 : ((C <= 128) ? 2 : 1);
     for (int idx = tid; idx < C * PARTS; idx += nthr) {
@@ -95,6 +107,20 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
         }
     }
     __syncthreads();
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int c = tid + j * nthr;
+            if (c < C) {
+                const int g = c / G;
+                const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
+                const float a = gam[j] * rstd;
+                gscale[(size_t)b * C + c] = a;
+                gshift[(size_t)b * C + c] = bet[j] - mean * a;
+            }
+        }
+        return;
+    }
     for (int c = tid; c < C; c += nthr) {
         const int g = c / G;
         const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
