@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5: non-temporal activation loads (nt1) / + non-temporal output stores (nt3) in the scheme-2 convs against the default: per layer, the
 # 18-step sample, and the PMC traffic of the dominant conv (FETCH_SIZE / WRITE_SIZE, separate passes)
-cd ${GRAFT_REPO_ROOT:-.}   # (needs the -DTQ_EXP_NT switch of commit history: non-temporal loads / stores in load16 and the epilogue store; removed after this run)
+cd ${GRAFT_REPO_ROOT:-.}   # (needs tools/experiments/nontemporal.patch applied and libtqdne_nt1.so / libtqdne_nt3.so built with -DTQ_EXP_NT=1 / =3)
 OUT=$PWD/gpurun_out/r05n; mkdir -p $OUT
 L=$PWD/tqdne_amd/lib
 for rep in 1 2; do
