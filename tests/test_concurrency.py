@@ -224,9 +224,10 @@ def test_fused_groupnorm_fold_poisoned_buffers_and_equals_separate_launches():
     # (the backward-capable list runs the k = 5 up-sampling convs where inference runs their two-phase k = 3 form: equal to rounding)
     assert torch.isfinite(y3).all() and float((y3 - y0).abs().max() / y0.abs().max()) < 1e-4
     # (ii) separate launches: a second model object with fusion off (plans are cached per model)
-    old = E.GN_FUSE
+    old, old_wgs = E.GN_FUSE, E.SMALL_TILE_WGS
     try:
         E.GN_FUSE = False
+        E.SMALL_TILE_WGS = 0   # (fused plans never take the 32-position tile; its statistics slots associate the GroupNorm sums differently)
         m2 = UNetModel(**cfg)
         m2.load_state_dict(m.state_dict())
         m2 = m2.to(dev).eval()
@@ -235,7 +236,7 @@ def test_fused_groupnorm_fold_poisoned_buffers_and_equals_separate_launches():
         with torch.no_grad():
             ys = e2.forward(x, t, c, infer=True).clone()
     finally:
-        E.GN_FUSE = old
+        E.GN_FUSE, E.SMALL_TILE_WGS = old, old_wgs
     assert torch.equal(y0, ys), "the fused fold must give the coefficients of tq_gn_finalize bit for bit"
     # (iii) concurrency: 4 lanes x 2 samples at once, three times
     h = B // 4

@@ -96,7 +96,7 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
         for (int j = 0; j < G; ++j) { s1 += csum[2 * (g * G + j)]; s2 += csum[2 * (g * G + j) + 1]; }
         const double n = (double)G * (double)T;
         const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
+        double var = fma(-mean, mean, s2 / n);   // (explicit contraction: the same bits in every kernel this is inlined into)
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)GN_EPS);
         gstat[2 * g] = mean;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
                 const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
                 const float a = gam[j] * rstd;
                 gscale[(size_t)b * C + c] = a;
-                gshift[(size_t)b * C + c] = bet[j] - mean * a;
+                gshift[(size_t)b * C + c] = fmaf(-mean, a, bet[j]);   // (explicit: the same rounding in every kernel this is inlined into)
             }
         }
         return;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
         const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
         const float a = gamma[c] * rstd;
         gscale[(size_t)b * C + c] = a;
-        gshift[(size_t)b * C + c] = beta[c] - mean * a;
+        gshift[(size_t)b * C + c] = fmaf(-mean, a, beta[c]);
     }
 }
 
