@@ -73,10 +73,14 @@ class PlanCache:
         self._d.clear()
 
 
-def _sync_on_evict(_keys):
+def _sync_on_evict(keys):
+    """wait for the devices named in the evicted keys (every key carries ``str(device)``), or for the current one"""
     import torch
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
+    if not torch.cuda.is_available():
+        return
+    devs = {part for k in keys if isinstance(k, tuple) for part in k if isinstance(part, str) and part.startswith("cuda")}
+    for d in devs or {None}:
+        torch.cuda.synchronize(None if d is None else torch.device(d))
 
 
 def plan_cache() -> PlanCache:
