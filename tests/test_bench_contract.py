@@ -22,6 +22,11 @@ def _run(*args, timeout=600, env=None):
     return json.loads(lines[0])
 
 
+def _tiny_params():
+    from tqdne_amd import UNetModel, tiny_1d_unet_config
+    return list(UNetModel(**tiny_1d_unet_config()).parameters())
+
+
 @pytest.mark.timeout(900)
 def test_bench_json_contract_tiny_config():
     d = _run("--config", "tiny", "--batch", "4", "--steps", "2", "--warmup", "1", "--cpu-batch", "1")
@@ -41,6 +46,7 @@ def test_bench_json_contract_tiny_config():
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and c["one_thread"]["cores"] == 1
     assert set(d["kernel_classes"]) >= {"inference_forward_1lane", "train_forward", "train_backward"}
+    assert {"train_ms", "sample_ms", "train_ms_synced", "sample_ms_synced"} <= set(d["parts"]) and "parts_definition" in d
     # same-run parity gate: HIP path vs the CPU oracle child on identical injected inputs, both metrics per checkpoint
     par = d["parity"]
     # (sample_stepK: the sampler's state after K of the 18 steps -- the error growth across the network evaluations)
@@ -76,4 +82,9 @@ def test_bench_runs_the_rccl_path_over_one_rank_when_forced():
     assert d["replicas_equal"] is True and d["replicas"]["weights_moved"] is True
     ex = d["gradient_exchange"]
     assert ex["overlap"] is True and len(ex["buckets_elems"]) >= 1 and ex["hidden_by_overlap_ms"] is not None
+    # (round 5: the range-guard pair rides in the last bucket -- the exchanged elements are the gradients plus the two tail words)
+    ps = _tiny_params()
+    n_par = sum(p_.numel() for p_ in ps)
+    total = sum(ex["buckets_elems"])
+    assert n_par + 2 <= total < n_par + 2 + 64 * len(ps)   # (every tensor starts on a 64-float boundary of the flat buffer)
     assert d["value"] > 0
