@@ -811,7 +811,8 @@ def main():
             tt = torch.tensor([t_after, parts.get("train_ms_synced", 0.0)], device=dev, dtype=torch.float64)   # (both: synced medians)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             exchange.update(train_ms_exchange_after_backward=float(tt[0]), train_ms_exchange_under_backward=float(tt[1]),
-                            hidden_by_overlap_ms=float(tt[0] - tt[1]), buckets_elems=list(trainer.last_bucket_sizes))
+                            hidden_by_overlap_ms=float(tt[0] - tt[1]), buckets_elems=list(trainer.last_bucket_sizes),
+                            tail_words=int(getattr(trainer, "last_tail_words", 0)))
         else:
             exchange.update(hidden_by_overlap_ms=0.0 if not multi else None)
 

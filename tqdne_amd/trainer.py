@@ -133,6 +133,7 @@ class DataParallelTrainer:
         scalar; no host sync here -- the reference's ``loss.item()`` logging, edm.py:138, belongs to the caller)."""
         works = []
         self.last_bucket_sizes = []
+        self.last_tail_words = 0      # words of ours that rode at the end of the last gradient bucket (the range-guard pair: 2)
         hook = None
         if self.exchange and self.overlap and self._hooked:
             def hook(sl):
@@ -146,6 +147,7 @@ class DataParallelTrainer:
             def tail_fill(words):
                 self._skip_fill(words)
                 tail.append(words)
+                self.last_tail_words = words.numel()
         if tail is not None:
             loss, flat = self.module.step_and_backward(batch, on_bucket=hook, bucket_elems=self.bucket_elems, tail_fill=tail_fill)
         elif self._hooked:
