@@ -808,6 +808,7 @@ def main():
             trainer.overlap = False
             t_after = med_train()
             trainer.overlap = True
+            train_half(); sync()   # (the bucket sizes / tail words reported below are those of a step with the exchange under the backward)
             tt = torch.tensor([t_after, parts.get("train_ms_synced", 0.0)], device=dev, dtype=torch.float64)   # (both: synced medians)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             exchange.update(train_ms_exchange_after_backward=float(tt[0]), train_ms_exchange_under_backward=float(tt[1]),
