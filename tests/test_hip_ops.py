@@ -416,10 +416,12 @@ def test_head(cin, cout, T):
     assert rel_err(y2.cpu(), F.conv1d(x, w, b, padding=2)) < 1e-5
 
 
-@pytest.mark.parametrize("cin,cout,T,K", [(16, 1, 77, 5), (32, 2, 129, 3), (48, 2, 129, 3), (128, 3, 61, 1), (128, 4, 200, 5), (64, 3, 60, 5), (64, 3, 1, 5), (64, 6, 190, 5)])
+@pytest.mark.parametrize("cin,cout,T,K", [(16, 1, 77, 5), (32, 2, 129, 3), (48, 2, 129, 3), (128, 3, 61, 1), (128, 4, 200, 5), (64, 3, 60, 5), (64, 3, 1, 5), (64, 6, 190, 5),
+                                          (64, 6, 4064, 5), (64, 8, 130, 3), (64, 16, 257, 5), (32, 16, 64, 1), (64, 6, 59, 1), (64, 5, 100, 5), (64, 12, 100, 5)])
 def test_head_other_shapes(cin, cout, T, K):
-    """the row-per-thread form (C_out <= 4) on ragged lengths (a wave emits 64 - (K - 1) outputs), every tap count and channel count
-    it is dispatched for, and the round-3 kernel for C_out > 4"""
+    """the row-per-thread form (C_out <= 4; round 5: 6 and 8 in one launch -- a wave emits two channels --, 16 in two launches: the heads
+    of the 6-channel envelope representation and of the 16-channel latent) on ragged lengths (a wave emits 64 - (K - 1) outputs), every
+    tap count and channel count it is dispatched for, and the round-3 kernel for the other channel counts (5, 12) and C_in = 48"""
     from tqdne_amd import ops
     g = torch.Generator().manual_seed(cin + cout + T + K)
     B = 3

@@ -308,8 +308,12 @@ __global__ __launch_bounds__(256) void head_conv_row_kernel(const float* __restr
                                                             const float* __restrict__ gshift, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const float* __restrict__ c_out,
                                                             const float* __restrict__ c_skip, const float* __restrict__ skip_src,
-                                                            float* __restrict__ y, int T, int C_in, int ntiles) {
+                                                            float* __restrict__ y, int T, int C_in, int ntiles, int co0, int C_tot) {
+    // Round 5: NCO up to 8 output channels per launch (wave w emits channels w and w + 4) of a head with C_tot of them, starting at
+    // co0 -- the 6-channel head of the reference's real data shape (MovingAverageEnvelope: 3 -> 6 channels) in one launch, the
+    // 16-channel latent head in two; they used to fall through to the LDS kernel above (214 / 232 us against 30 for 3 channels, B = 64).
     constexpr int PAD = KT / 2, NOUT = 64 - (KT - 1), NP = KT * NCO;
+    static_assert(NCO >= 1 && NCO <= 8, "a wave emits at most two output channels");
     extern __shared__ __attribute__((aligned(16))) float shm[];
     const int RS = C_in + 4;                    // floats per staged row
     float* tile = shm;                          // [64][RS]
@@ -319,10 +323,15 @@ __global__ __launch_bounds__(256) void head_conv_row_kernel(const float* __restr
     const int b = blockIdx.x / ntiles, t0 = (blockIdx.x % ntiles) * NOUT;
     // the epilogue's skip-connection operand: requested now, used after the last barrier
     const int to = t0 + lane;
-    const bool emit = wave < NCO && lane < NOUT && to < T;
-    const size_t oo = ((size_t)b * NCO + (wave < NCO ? wave : 0)) * T + (to < T ? to : 0);
-    float skipv = 0.f;
-    if (c_out && emit) skipv = skip_src[oo];
+    const bool emit_t = lane < NOUT && to < T;
+    size_t oo[2];
+    float skipv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int co = wave + 4 * h;
+        oo[h] = ((size_t)b * C_tot + co0 + (co < NCO ? co : 0)) * T + (to < T ? to : 0);
+        if (c_out && emit_t && co < NCO) skipv[h] = skip_src[oo[h]];
+    }
     // ---- 1. stage
     {
         const int ncol = C_in >> 2, rpp = 256 / ncol;   // 4-channel columns, rows per pass
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256) void head_conv_row_kernel(const float* __restr
         for (int co = 0; co < NCO; ++co) acc[k][co] = 0.f;
     const float* wc[NCO];   // per output channel: this wave's (C_in / 4, KT) weight block -- the 4 KT weights of a step are consecutive
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) wc[co] = w + ((size_t)co * C_in + wave * cq) * KT;
+    for (int co = 0; co < NCO; ++co) wc[co] = w + ((size_t)(co0 + co) * C_in + wave * cq) * KT;
     // ONE 4-channel step per loop trip, not unrolled: with several steps in the body hipcc hoists all their scalar loads to the top
     // of the trip and parks 240 scalars in VGPR lanes (210 v_readlane + 146 v_writelane per 120 packed FMAs)
 #pragma unroll 1
@@ -384,15 +393,18 @@ __global__ __launch_bounds__(256) void head_conv_row_kernel(const float* __restr
             if (lane < 4) pr[64 + lane] = 0.f;   // (read by the outputs the workgroup does not emit)
         }
     __syncthreads();
-    if (emit) {
-        const int co = wave;
-        float v = bias ? bias[co] : 0.f;
 #pragma unroll
-        for (int k = 0; k < KT; ++k)
+    for (int h = 0; h < (NCO > 4 ? 2 : 1); ++h) {
+        const int co = wave + 4 * h;
+        if (emit_t && co < NCO) {
+            float v = bias ? bias[co0 + co] : 0.f;
 #pragma unroll
-            for (int wv = 0; wv < 4; ++wv) v += part[((wv * NP) + k * NCO + co) * 68 + lane + k];
-        if (c_out) v = v * c_out[b] + c_skip[b] * skipv;
-        y[oo] = v;
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) v += part[((wv * NP) + k * NCO + co) * 68 + lane + k];
+            if (c_out) v = v * c_out[b] + c_skip[b] * skipv[h];
+            y[oo[h]] = v;
+        }
     }
 }
 }  // namespace
@@ -418,13 +430,16 @@ extern "C" int tq_head_conv_fwd(const float* x, const float* gscale, const float
     if (B <= 0 || T <= 0 || sh == 0) return TQ_ERR_SHAPE;
     // TQDNE_HEAD_FWD=lds: the round-3 kernel for every shape (A/B switch)
     static const int row_form = [] { const char* e = getenv("TQDNE_HEAD_FWD"); return (e && e[0] == 'l') ? 0 : 1; }();
-    if (row_form && C_out <= 4 && (C_in == 16 || C_in == 32 || C_in == 64 || C_in == 128)) {
+    if (row_form && (C_out <= 4 || C_out == 6 || C_out == 8 || C_out == 16) && (C_in == 16 || C_in == 32 || C_in == 64 || C_in == 128)) {
         const int nt = (T + (64 - (ktaps - 1)) - 1) / (64 - (ktaps - 1));
-        const size_t st_ = (size_t)64 * (C_in + 4), sp_ = (size_t)4 * ktaps * C_out * 68;
-        const size_t shr = (st_ > sp_ ? st_ : sp_) * sizeof(float);   // <= 34 KB (the partial sums reuse the staged tile's space)
-#define TQ_HEADR(K, N) hipLaunchKernelGGL((head_conv_row_kernel<K, N>), dim3(B * nt), dim3(256), shr, stream, x, gscale, gshift, w, bias, \
-                                          c_out, c_skip, skip_src, y, T, C_in, nt)
-#define TQ_HEADRK(K) { if (C_out == 1) TQ_HEADR(K, 1); else if (C_out == 2) TQ_HEADR(K, 2); else if (C_out == 3) TQ_HEADR(K, 3); else TQ_HEADR(K, 4); }
+        const int per = C_out <= 8 ? C_out : 8;   // output channels per launch (16 = two launches of 8: the input tile is staged twice)
+        const size_t st_ = (size_t)64 * (C_in + 4), sp_ = (size_t)4 * ktaps * per * 68;
+        const size_t shr = (st_ > sp_ ? st_ : sp_) * sizeof(float);   // <= 54 KB (the partial sums reuse the staged tile's space)
+#define TQ_HEADR(K, N, CO0) hipLaunchKernelGGL((head_conv_row_kernel<K, N>), dim3(B * nt), dim3(256), shr, stream, x, gscale, gshift, w, bias, \
+                                               c_out, c_skip, skip_src, y, T, C_in, nt, CO0, C_out)
+#define TQ_HEADRK(K) { if (per == 1) TQ_HEADR(K, 1, 0); else if (per == 2) TQ_HEADR(K, 2, 0); else if (per == 3) TQ_HEADR(K, 3, 0); \
+                       else if (per == 4) TQ_HEADR(K, 4, 0); else if (per == 6) TQ_HEADR(K, 6, 0); \
+                       else { for (int c0 = 0; c0 < C_out; c0 += 8) TQ_HEADR(K, 8, c0); } }
         if (ktaps == 5) TQ_HEADRK(5)
         else if (ktaps == 3) TQ_HEADRK(3)
         else TQ_HEADRK(1)
