@@ -180,29 +180,32 @@ def test_colsum():
         assert rel_err(obc.cpu(), ref) < 1e-5 and rel_err(oc.cpu(), ref.sum(0)) < 1e-5
 
 
-def test_stem_and_head_backward():
+@pytest.mark.parametrize("nch,T,ws", [(3, 300, True), (6, 300, True), (6, 4064, True), (6, 190, False), (8, 129, True), (4, 128, False)])
+def test_stem_and_head_backward(nch, T, ws):
+    """first / last conv at the NCW boundary: 3 channels (waveforms), 6 (the envelope representation of the reference's real data: the
+    streaming head backward serves up to 8 output channels since round 5), with the two-stage sums through a workspace and with atomics"""
     from tqdne_amd import ops
-    g = torch.Generator().manual_seed(3)
+    g = torch.Generator().manual_seed(3 + nch + T)
     d = dev()
-    B, T = 2, 300
+    B = 2
     # stem
-    x = torch.randn(B, 3, T, generator=g)
+    x = torch.randn(B, nch, T, generator=g)
     sc = torch.rand(B, generator=g) + 0.5
-    w = (torch.randn(64, 3, 5, generator=g) / 4).requires_grad_(True)
+    w = (torch.randn(64, nch, 5, generator=g) / 4).requires_grad_(True)
     dy = torch.randn(B, 64, T, generator=g)
     F.conv1d(x * sc[:, None, None], w, None, padding=2).backward(dy)
-    dw = ops.stem_conv_bwd_weight(cl(dy), x.to(d), w.shape, in_scale=sc.to(d))
+    dw = ops.stem_conv_bwd_weight(cl(dy), x.to(d), w.shape, in_scale=sc.to(d), workspace=ws)
     assert rel_err(dw.cpu(), w.grad) < 1e-5
     # head
     h = torch.randn(B, 64, T, generator=g)
     a, s = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
-    wh = (torch.randn(3, 64, 5, generator=g) / 10).requires_grad_(True)
-    bh = torch.randn(3, generator=g).requires_grad_(True)
+    wh = (torch.randn(nch, 64, 5, generator=g) / 10).requires_grad_(True)
+    bh = torch.randn(nch, generator=g).requires_grad_(True)
     co = torch.rand(B, generator=g) + 0.5
-    dpred = torch.randn(B, 3, T, generator=g)
+    dpred = torch.randn(B, nch, T, generator=g)
     u = (h * a[:, :, None] + s[:, :, None]).requires_grad_(True)
     (F.conv1d(F.silu(u), wh, bh, padding=2) * co[:, None, None]).backward(dpred)
-    G, st, dwh, dbh = ops.head_conv_bwd(dpred.to(d), cl(h), wh.detach().to(d), a.to(d), s.to(d), co.to(d))
+    G, st, dwh, dbh = ops.head_conv_bwd(dpred.to(d), cl(h), wh.detach().to(d), a.to(d), s.to(d), co.to(d), workspace=ws)
     assert rel_err(ncw(G), u.grad) < 1e-5
     assert rel_err(dwh.cpu(), wh.grad) < 1e-5 and rel_err(dbh.cpu(), bh.grad) < 1e-5
     assert rel_err(st.cpu(), ref_slot_sums(u.grad, h)) < 1e-5

@@ -21,3 +21,17 @@ for B in (64, 16):
     co, ck = torch.rand(B, device=dev), torch.rand(B, device=dev)
     t_head = med(lambda: lib.tq_head_conv_fwd(p(h), p(gs), p(gh), p(wh), p(bh), p(co), p(ck), p(x), p(out), B, T, 64, Cio, 5, st()))
     print(f"B={B} channels={Cio} T={T}: stem {t_stem:.1f} us, head {t_head:.1f} us")
+
+# backward of the two ends (training): stem weight gradient and head backward
+from tqdne_amd import ops
+for B in (64,):
+  for (Cio, T) in ((3, 4096), (6, 4064)):
+    x = torch.randn(B, Cio, T, device=dev); dy = torch.randn(B, T, 64, device=dev); sc = torch.rand(B, device=dev)
+    dw = torch.zeros(64, Cio, 5, device=dev); ws = torch.empty(lib.tq_stem_head_bwd_workspace(), dtype=torch.uint8, device=dev)
+    t_s = med(lambda: lib.tq_stem_conv_bwd_weight_ws(p(dy), p(x), p(sc), p(dw), B, Cio, T, 64, 5, p(ws), ws.numel(), st()))
+    h = torch.randn(B, T, 64, device=dev); gs = torch.rand(B, 64, device=dev); gh = torch.randn(B, 64, device=dev)
+    wh = torch.randn(Cio, 64, 5, device=dev); dpred = torch.randn(B, Cio, T, device=dev); co = torch.rand(B, device=dev)
+    G = torch.empty(B, T, 64, device=dev); gst = torch.empty(B, (T + 127) // 128, 64, 2, device=dev)
+    dwh = torch.zeros(Cio, 64, 5, device=dev); dbh = torch.zeros(Cio, device=dev)
+    t_h = med(lambda: lib.tq_head_conv_bwd_ws(p(dpred), p(co), p(h), p(gs), p(gh), p(wh), p(G), p(gst), p(dwh), p(dbh), B, T, 64, Cio, 5, p(ws), ws.numel(), st()))
+    print(f"B={B} channels={Cio} T={T}: stem weight gradient {t_s:.1f} us, head backward {t_h:.1f} us")

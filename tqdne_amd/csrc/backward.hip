@@ -1173,7 +1173,9 @@ __global__ __launch_bounds__(256) void partial_rows_sum_kernel(const float* __re
 //   dF = c_out[b] * dpred;   dW[co][ci][k] += sum_t dF[co][t] z[ci][t+k-pad];   db[co] += sum_t dF[co][t]
 //   G[t][ci] = (sum_{co,k} W[co][ci][k] dF[co][t+pad-k]) * silu'(a h + s),  GN partial sums {sum G, sum G h} per 128-position slot
 // Both sums pair the thread's own element z[ci][t] / G[t][ci] with the SAME 3 x KT values dF[co][t + pad - k].
-template <int KT>
+// Round 5: MAXCO = 8 serves the 6-channel head of the reference's real data shape (3 x 4064 waveforms -> 6 x 4064 through the envelope
+// representation), which used to take the round-3 kernel (atomics, a fifth of the speed).
+template <int KT, int MAXCO = 4>
 __global__ __launch_bounds__(256) void head_bwd_stream_kernel(const float* __restrict__ dpred, const float* __restrict__ c_out,
                                                               const float* __restrict__ h, const float* __restrict__ gscale,
                                                               const float* __restrict__ gshift, const float* __restrict__ w,
@@ -1181,7 +1183,7 @@ __global__ __launch_bounds__(256) void head_bwd_stream_kernel(const float* __res
                                                               float* __restrict__ dw, float* __restrict__ db, float* __restrict__ part,
                                                               int T, int C_in, int C_out, int nslots, int nunits, int upw) {
     extern __shared__ float shm[];
-    constexpr int PAD = KT / 2, TW = STAT_SLOT + 2 * PAD, MAXCO = 4, BLK = 8;
+    constexpr int PAD = KT / 2, TW = STAT_SLOT + 2 * PAD, BLK = 8;
     float* dfs = shm;                          // [MAXCO][TW]  dF of positions t0 - pad .. t0 + 127 + pad
     float* red = dfs + MAXCO * TW;             // [nseg][max(2, MAXCO * KT)][C_in]
     const int nseg = 256 / C_in, L = STAT_SLOT / nseg;
@@ -1529,22 +1531,27 @@ extern "C" int tq_head_conv_bwd_ws(const float* dpred_nct, const float* c_out, c
     const int maxco = C_out <= 4 ? 4 : 16;
     const int nslots = (T + STAT_SLOT - 1) / STAT_SLOT;
     static const bool old_form = [] { const char* e = getenv("TQDNE_STEM_HEAD_BWD"); return e && atoi(e) == 3; }();   // (A/B switch: 3 = round 3's kernels)
-    if (!old_form && C_out <= 4 && ktaps == 5 && C_in >= 32 && C_in <= 256 && 256 % C_in == 0) {   // the streaming form (round 4)
+    if (!old_form && C_out <= 8 && ktaps == 5 && C_in >= 32 && C_in <= 256 && 256 % C_in == 0) {   // the streaming form (round 4; 5 ... 8 channels: round 5)
+        const int mco = C_out <= 4 ? 4 : 8;
         const int nunits = B * nslots;
         const int nwg = nunits < stem_head_wgs(512) ? nunits : stem_head_wgs(512);
         const int upw = (nunits + nwg - 1) / nwg;
-        const size_t sh2 = ((size_t)4 * (STAT_SLOT + 4) + (size_t)256 * 4 * 5) * sizeof(float);
+        const size_t sh2 = ((size_t)mco * (STAT_SLOT + 4) + (size_t)256 * mco * 5) * sizeof(float);   // (<= 45 KB)
         const unsigned grid2 = (unsigned)((nunits + upw - 1) / upw);
-        const int nout2 = C_out * C_in * 5 + 4;   // dw, then db padded to 4
+        const int nout2 = C_out * C_in * 5 + mco;   // dw, then db padded to the kernel's MAXCO
         float* part = (workspace && ws_bytes >= (size_t)grid2 * nout2 * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
-        hipLaunchKernelGGL(head_bwd_stream_kernel<5>, dim3(grid2), dim3(256), sh2, stream, dpred_nct, c_out, x, gscale, gshift, w, g_out,
-                           gstats, dw, db, part, T, C_in, C_out, nslots, nunits, upw);
+        if (mco == 4)
+            hipLaunchKernelGGL((head_bwd_stream_kernel<5, 4>), dim3(grid2), dim3(256), sh2, stream, dpred_nct, c_out, x, gscale, gshift, w, g_out,
+                               gstats, dw, db, part, T, C_in, C_out, nslots, nunits, upw);
+        else
+            hipLaunchKernelGGL((head_bwd_stream_kernel<5, 8>), dim3(grid2), dim3(256), sh2, stream, dpred_nct, c_out, x, gscale, gshift, w, g_out,
+                               gstats, dw, db, part, T, C_in, C_out, nslots, nunits, upw);
         TQ_CHECK_LAUNCH();
         if (part) {
             // (dw's rows first: C_out C_in 5 floats; the bias sums sit behind them in every row)
-            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((nout2 - 4 + 63) / 64), dim3(256), 0, stream, part, (int)grid2, nout2, nout2 - 4, dw);
+            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((nout2 - mco + 63) / 64), dim3(256), 0, stream, part, (int)grid2, nout2, nout2 - mco, dw);
             TQ_CHECK_LAUNCH();
-            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(1), dim3(256), 0, stream, part + (nout2 - 4), (int)grid2, nout2, C_out, db);
+            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(1), dim3(256), 0, stream, part + (nout2 - mco), (int)grid2, nout2, C_out, db);
             TQ_CHECK_LAUNCH();
         }
         return 0;
