@@ -1,6 +1,7 @@
 """Per-launch table of one UNet forward (HIP events around every launch of the plan, on the launch stream):
 name, time, algorithmic GFLOP and MB, fraction of the dense bf16 MFMA peak and of the HBM peak.
-usage: python tools/layer_table.py [B] [T] [reps] [train]"""
+usage: python tools/layer_table.py [B] [T] [reps] [train]      (LAYER_TABLE_CONFIG=tiny: cfg0; LAYER_TABLE_CHANNELS=6 | 16: the paper UNet
+with that many input / output channels -- the envelope representation's 6 x 4064, the latent EDM's 16 x 4096)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,11 +15,13 @@ train = len(sys.argv) > 4 and sys.argv[4] == "train"
 tiny = os.environ.get("LAYER_TABLE_CONFIG", "paper") == "tiny"   # (BASELINE configs[0]: unconditioned, 32 base channels)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-edm = LightningEDM(tiny_1d_unet_config() if tiny else paper_1d_unet_config(), {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
+nch = int(os.environ.get("LAYER_TABLE_CHANNELS", "3"))
+edm = LightningEDM(tiny_1d_unet_config() if tiny else paper_1d_unet_config(in_channels=nch, out_channels=nch),
+                   {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0})
 edm.unet.load_state_dict(bench.perturbed_state(edm.unet, 17))
 edm = edm.to(dev)
 g = torch.Generator().manual_seed(1)
-x = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev)
+x = (0.5 * torch.randn(B, 3 if tiny else nch, T, generator=g)).to(dev)
 cond = None if tiny else torch.randn(B, 5, generator=g).to(dev)
 sig = torch.full((B,), 0.7, device=dev)
 eng = edm.unet._engine(B, T, dev)
