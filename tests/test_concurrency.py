@@ -271,3 +271,41 @@ def test_fused_groupnorm_fold_poisoned_buffers_and_equals_separate_launches():
     with torch.no_grad():
         yr = eng.forward(x, t, c, infer=True).clone()
     assert torch.equal(yr, y0)
+
+
+def test_stochastic_sampler_lanes_are_bit_identical_and_match_the_oracle():
+    """Round 5: the churned sampler (edm.py:198-230) on the lanes of the deterministic one.  Micro UNet, B = 32 (two lanes of 16), 4 steps
+    with injected unit noises: lanes = 2 / 4 integrate exactly what one lane does, and that is the oracle's result; with the sampler's
+    own draws (same torch seed) lanes and one lane agree as well (the noises are drawn for the whole batch in the one-lane order)."""
+    from conftest import cfg_of, load_golden
+    from oracle import edm as OE
+    from tqdne_amd import LightningEDM
+    sd, d = load_golden("micro_unet.npz")
+    cfg = cfg_of(d)
+    nsteps = 4
+    edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0}, num_sampling_steps=nsteps, deterministic_sampling=False)
+    edm.unet.load_state_dict(sd)
+    dev = torch.device("cuda:0")
+    edm = edm.to(dev).eval()
+    g = torch.Generator().manual_seed(77)
+    B, T = 32, 256
+    start = torch.randn(B, 3, T, generator=g, dtype=torch.float64)
+    cond = torch.randn(B, 5, generator=g)
+    churn = [torch.randn(B, 3, T, generator=g, dtype=torch.float64) for _ in range(nsteps)]
+    sig = OE.sampling_sigmas(OE.EDMParams(), nsteps)
+    eps = (start * sig[0]).to(dev)
+    outs = {n: edm.sample_stochastically(eps, sig.to(dev), None, cond.to(dev), churn_noises=[c.to(dev) for c in churn], lanes=n).clone()
+            for n in (1, 2, 4, 2)}
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[4])
+    net = OE.make_net({"unet." + k: v for k, v in sd.items()}, cfg)
+    with torch.no_grad():
+        ref = OE.sample_stochastic(OE.EDMParams(), net, start, churn, nsteps, cond=cond)
+    from conftest import rel_err
+    e = rel_err(outs[2].cpu(), ref)
+    print(f"stochastic sampler, 2 lanes x 16, {nsteps} steps vs oracle: {e:.2e}")
+    assert e < 1e-3
+    torch.manual_seed(5)
+    a = edm.sample_stochastically(eps, sig.to(dev), None, cond.to(dev), lanes=1).clone()
+    torch.manual_seed(5)
+    b = edm.sample_stochastically(eps, sig.to(dev), None, cond.to(dev), lanes=2).clone()
+    assert torch.equal(a, b), "the lanes' draws must be the one-lane loop's draws"

@@ -315,6 +315,12 @@ class LightningEDM(LightningModule):
             res = run.result.clone()
             run.release()
             return res
+        return self._run_lanes(eps, sigmas, cond_sample, cond, lanes, use_graph)
+
+    def _run_lanes(self, eps, sigmas, cond_sample, cond, lanes, use_graph=False, churn=None):
+        """``lanes`` sub-batches integrated concurrently on as many HIP streams (see sample_deterministically); ``churn``: the
+        stochastic sampler's (sigma_hat, coefficients, unit noises per step for the WHOLE batch) -- every lane takes its slice."""
+        B = eps.shape[0]
         dev = eps.device
         h = B // lanes
         cut = lambda t, i: None if t is None else t[i * h:(i + 1) * h].contiguous()
@@ -327,7 +333,11 @@ class LightningEDM(LightningModule):
             for i, st in enumerate(streams):
                 self._lane = engine.CONCURRENT_LANE0 + i
                 with th.cuda.stream(st):
-                    runs.append(self._heun_lane(cut(eps, i), sigmas, cut(cond_sample, i), cut(cond, i), use_graph))
+                    lane_churn = None
+                    if churn is not None:
+                        shat, coef, noises = churn
+                        lane_churn = (shat, coef, lambda k, _i=i: noises[k][_i * h:(_i + 1) * h].contiguous())
+                    runs.append(self._heun_lane(cut(eps, i), sigmas, cut(cond_sample, i), cut(cond, i), use_graph, churn=lane_churn))
             # one sampler step of lane 0, then of lane 1, ...: all queues stay fed well ahead of the GPU
             while not all(r.done for r in runs):
                 for i, (r, st) in enumerate(zip(runs, streams)):
@@ -350,9 +360,12 @@ class LightningEDM(LightningModule):
     def _side_stream(self, dev, i=1):
         return engine.side_stream(dev, i)   # (one pool per process: the number of live streams matters, see engine.side_stream)
 
-    def _heun_lane(self, eps, sigmas, cond_sample, cond, use_graph):
+    def _heun_lane(self, eps, sigmas, cond_sample, cond, use_graph, churn=None):
         """The Heun integration of one (half) batch as a resumable object: ``advance()`` enqueues one sampler step on the current
-        stream with the current lane's plan and buffers; ``result`` is the fp64 state buffer once ``done``."""
+        stream with the current lane's plan and buffers; ``result`` is the fp64 state buffer once ``done``.
+        ``churn`` = (sigma_hat (steps,), coefficients (steps,), noise_of_step): the stochastic sampler's steps (edm.py:198-230) -- the
+        noise increase ``tq_heun_churn`` with this lane's slice ``noise_of_step(i)`` of the step's unit noise, then the Heun step from
+        sigma_hat instead of sigma."""
         lib = _lib.load()
         dev = eps.device
         sigmas = sigmas.to(device=dev, dtype=th.float32).contiguous()
@@ -368,6 +381,10 @@ class LightningEDM(LightningModule):
                 # (``start`` is an argument, not a closure variable: a class object sits in reference cycles of its own, and a
                 # cell holding a view of the caller's start state would keep that whole allocation alive until a cyclic GC pass)
                 r.x, r.xn, r.d, r.x32 = bufs["x"], bufs["xn"], bufs["d"], bufs["x32"]
+                if churn is not None:
+                    if "xh" not in bufs:
+                        bufs["xh"] = th.empty_like(bufs["x"])
+                    r.xh = bufs["xh"]
                 r.x.copy_(start)
                 r.x32.copy_(start)  # fp64 -> fp32 rounding, as sample_curr.to(self.dtype)
                 r.i, r.nsteps = 0, sigmas.numel() - 1
@@ -389,6 +406,23 @@ class LightningEDM(LightningModule):
                 i, n, sp = r.i, r.x.numel(), sigmas.data_ptr()
                 stream = th.cuda.current_stream(dev).cuda_stream
                 s_i, s_n = sp + 4 * i, sp + 4 * (i + 1)
+                if churn is not None:
+                    shat, coef, noise_of_step = churn
+                    unit = noise_of_step(i)
+                    r.keep = r.keep + (unit,)   # (alive until the launches that read it have been enqueued AND run: released with the run)
+                    s_hat = shat.data_ptr() + 4 * i
+                    check(lib.tq_heun_churn(_p(r.x), _p(unit), coef.data_ptr() + 4 * i, float(edm.edm.S_noise), _p(r.xh), _p(r.x32), n,
+                                            stream), "heun churn")
+                    den = r.denoise(s_hat)
+                    check(lib.tq_heun_euler(_p(r.xh), _p(den), s_hat, s_n, _p(r.d), _p(r.xn), _p(r.x32), n, stream), "heun euler")
+                    if i < edm.num_sampling_steps - 1:
+                        den = r.denoise(s_n)
+                        check(lib.tq_heun_correct(_p(r.xh), _p(r.xn), _p(den), _p(r.d), s_hat, s_n, _p(r.x), _p(r.x32), n, stream),
+                              "heun correct")
+                    else:
+                        r.x, r.xn = r.xn, r.x
+                    r.i += 1
+                    return
                 den = r.denoise(s_i)
                 check(lib.tq_heun_euler(_p(r.x), _p(den), s_i, s_n, _p(r.d), _p(r.xn), _p(r.x32), n, stream), "heun euler")
                 if i < edm.num_sampling_steps - 1:
@@ -499,7 +533,7 @@ class LightningEDM(LightningModule):
         return run
 
     @th.no_grad()
-    def sample_stochastically(self, eps, sigmas, cond_sample=None, cond=None, churn_noises=None):
+    def sample_stochastically(self, eps, sigmas, cond_sample=None, cond=None, churn_noises=None, lanes=None):
         """Stochastic (churned) sampler (edm.py:198-230) on the HIP kernels: per step the noise increase ``tq_heun_churn`` (lines
         205-208), the fused denoiser at sigma_hat, ``tq_heun_euler`` and -- except on the last step -- the denoiser at sigma_next
         and ``tq_heun_correct`` (lines 210-228), fp64 state, fp32 network.  sigma_hat and sqrt(sigma_hat^2 - sigma^2) are formed once
@@ -519,6 +553,23 @@ class LightningEDM(LightningModule):
             cond = cond.contiguous().float()
         if cond_sample is not None:
             cond_sample = cond_sample.contiguous().float()
+        B = eps.shape[0]
+        if lanes is None:
+            lanes = sampler_lanes(B)
+        if lanes >= 2 and B % lanes == 0 and B // lanes >= 8:
+            # round 5: the stochastic sampler on the lanes of the deterministic one.  The unit noises of ALL steps are drawn first, for
+            # the whole batch and in the order the one-lane loop draws them (line 207's randn_like per step), then cut per lane: the
+            # result is bit-identical to the one-lane integration of the same draws.
+            nst = sig.numel() - 1
+            if churn_noises is None:
+                noises = [th.randn(eps.shape, dtype=th.float64, device=dev) for _ in range(nst)]
+            else:
+                noises = [churn_noises[i].to(device=dev, dtype=th.float64).contiguous() for i in range(nst)]
+            out = self._run_lanes(eps, sig, cond_sample, cond, lanes, churn=(shat, coef, noises))
+            engs = [e for e in self.unet._engine_cache.values() if e.dev == dev]
+            if engs and engs[0].check_range():
+                return self.sample_stochastically(eps, sigmas, cond_sample, cond, noises, lanes)  # (the plans are on bf16x3 now)
+            return out
         bufs = self._sampler_buffers(eps)
         if "xh" not in bufs:
             bufs["xh"] = th.empty_like(bufs["x"])
