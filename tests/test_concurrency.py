@@ -303,7 +303,6 @@ def test_stochastic_sampler_lanes_are_bit_identical_and_match_the_oracle():
     net = OE.make_net({"unet." + k: v for k, v in sd.items()}, cfg)
     with torch.no_grad():
         ref = OE.sample_stochastic(OE.EDMParams(), net, start, churn, nsteps, cond=cond)
-    from conftest import rel_err
     e = rel_err(outs[2].cpu(), ref)
     print(f"stochastic sampler, 2 lanes x 16, {nsteps} steps vs oracle: {e:.2e}")
     assert e < 1e-3
