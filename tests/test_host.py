@@ -179,3 +179,64 @@ def test_plan_cache_is_bounded_and_evicts_least_recently_used_shape_groups():
     # the model classes use it
     from tqdne_amd import UNetModel, tiny_1d_unet_config
     assert isinstance(UNetModel(**tiny_1d_unet_config())._engine_cache, PlanCache)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The three statements of every C-ABI struct -- include/tqdne_hip.h, tqdne_amd/_lib.py (ctypes) and the maintainer's stub printed
+# in INTEGRATION.md -- must describe the same bytes: a struct built from a stale stub is read past its end by the library.
+
+_C_TYPES = {"int32_t": "c_int", "uint32_t": "c_uint", "float": "c_float", "uint64_t": "c_ulong", "int": "c_int",
+            "unsigned long long": "c_ulong", "double": "c_double"}
+
+
+def _header_struct_fields(name):
+    """[(field, ctypes type name)] of ``typedef struct <name> {...}`` in include/tqdne_hip.h (pointers -> c_void_p)"""
+    import ctypes
+    header = open(os.path.join(ROOT, "include", "tqdne_hip.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(?:const )?((?:unsigned long long|[A-Za-z_][A-Za-z0-9_]*))\s*(\*?)\s*(.*)$", decl)
+        ctype, star, names = m.group(1), m.group(2), m.group(3)
+        for n in names.split(","):
+            n = n.strip()
+            ptr = bool(star) or n.startswith("*")
+            n = n.lstrip("* ")
+            fields.append((n, ctypes.c_void_p if ptr else getattr(ctypes, _C_TYPES[ctype])))
+    return fields
+
+
+def _layout(struct):
+    import ctypes
+    return [(n, getattr(struct, n).offset, getattr(struct, n).size) for n, *_ in struct._fields_], ctypes.sizeof(struct)
+
+
+@pytest.mark.parametrize("name", ["TqConvDesc", "TqConvBwdDesc", "TqPackJob", "TqGnFuse"])
+def test_ctypes_structs_match_the_header(name):
+    import ctypes
+    from tqdne_amd import _lib
+    ref = type(name + "_h", (ctypes.Structure,), {"_fields_": _header_struct_fields(name)})
+    assert _layout(getattr(_lib, name)) == _layout(ref)
+
+
+def test_integration_md_stub_matches_the_header_and_the_binding():
+    """INTEGRATION.md's ``class TqConvDesc(ctypes.Structure)`` (the stub a maintainer of the reference would copy) is executed as
+    printed and held against the binding: same field names, offsets, sizes and total size."""
+    import ctypes
+    from tqdne_amd import _lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", doc, re.S)
+    stub = next(b for b in blocks if "class TqConvDesc(ctypes.Structure)" in b)
+    classes = re.findall(r"^(class (\w+)\(ctypes\.Structure\):.*?)(?=^\S)", stub, re.S | re.M)
+    assert classes, "no ctypes.Structure in the stub"
+    for src, name in classes:
+        ns = {"ctypes": ctypes}
+        exec(src, ns)
+        assert _layout(ns[name]) == _layout(getattr(_lib, name)), name
+    # the argument list the stub binds tq_conv1d_fwd with is the binding's
+    n_ptr = int(re.search(r"tq_conv1d_fwd\.argtypes = \[ctypes\.POINTER\(TqConvDesc\)\] \+ \[ctypes\.c_void_p\] \* (\d+)", stub).group(1))
+    assert n_ptr == len(_lib._PROTOS["tq_conv1d_fwd"][1]) - 1
