@@ -1,6 +1,6 @@
 """The reference's DEFAULT per-device batch: ``-b 256`` (experiments/train_1d_edm.py:83-85) on the paper UNet, 3 x 4096 -- four times
-the bench's batch.  Plans keep every activation in static buffers (``use_checkpoint`` is a no-op here: DESIGN.md section 1), so
-B = 256 is a memory and an index-range question:
+the bench's batch.  Plans keep every activation in static buffers (``use_checkpoint=True`` shares the block-internal ones and
+recomputes them in the backward, DESIGN.md section 1: measured below), so B = 256 is a memory and an index-range question:
 
   * one training step (dropout off so that chunks are comparable): finite loss and gradients, and the same loss / gradients as the
     mean over four B = 64 steps on the four quarters of the batch (a (b, t)-split weight gradient and a GroupNorm per sample: only
@@ -167,3 +167,47 @@ def test_plan_cache_evicts_and_rebuilt_plan_reproduces():
         y2 = net(x, t, c)
         assert torch.equal(y, y2)
         assert net._engine_cache.get((1, T, str(dev()), 0)).uid > uid_before   # a NEW plan (captured graphs are keyed by the uid)
+
+
+def test_evicted_training_plan_gives_its_memory_back_without_a_gc_pass():
+    """round-5 advisor finding (medium): a plan that has run a backward sits in a reference cycle with its backward plan, so after an
+    eviction its buffers used to survive until a cyclic-GC pass -- variable-shape training leaked a plan per shape.  Here: training
+    steps on PLAN_SHAPES + 2 batch sizes with the cyclic collector OFF; the allocated memory after the evictions must be what
+    PLAN_SHAPES plans need, not what PLAN_SHAPES + 2 need, and the first plan must be gone."""
+    import gc
+    import weakref
+    from conftest import cfg_of, load_golden
+    from tqdne_amd import LightningEDM, _cache
+    sd, d = load_golden("micro_unet.npz")
+    edm = LightningEDM(cfg_of(d), {"learning_rate": 1e-4, "max_steps": 10, "eta_min": 0.0}).to(dev())
+    edm.unet.load_state_dict(sd)
+    edm.train()
+    T = 2048
+    g = torch.Generator().manual_seed(5)
+
+    def step(B):
+        batch = {"signal": torch.randn(B, 3, T, generator=g).to(dev()), "cond": torch.randn(B, 5, generator=g).to(dev())}
+        loss, _ = edm.step_and_backward(batch)
+        return float(loss)
+
+    gc.collect()
+    gc.disable()
+    try:
+        sizes = [8 * (i + 1) for i in range(_cache.PLAN_SHAPES + 2)]   # growing: the evicted plans are the SMALL ones, so the bound is strict
+        step(sizes[0])
+        first = weakref.ref(edm.unet._engine(sizes[0], T, dev()))
+        assert first()._bwd is not None and first()._bwd.e is first()
+        mem = []
+        for B in sizes[1:]:
+            step(B)
+            torch.cuda.synchronize()
+            mem.append(torch.cuda.memory_allocated())
+        assert edm.unet._engine_cache.evictions == 2
+        assert first() is None, "the evicted training plan is still alive (plan <-> backward-plan cycle not broken)"
+        # plans scale with the batch: adding B = 24 next to two live plans costs plan(24); adding B = 64 while B = 16 is evicted must
+        # cost about plan(64) - plan(16), clearly less than plan(64) - plan(8)
+        per_b = (mem[1] - mem[0]) / sizes[2]
+        grow_last = mem[-1] - mem[-2]
+        assert grow_last < per_b * (sizes[-1] - sizes[0]), (grow_last, per_b)
+    finally:
+        gc.enable()

@@ -311,3 +311,23 @@ def test_stochastic_sampler_lanes_are_bit_identical_and_match_the_oracle():
         torch.manual_seed(5)
         res[n] = edm.sample_stochastically(eps, sig.to(dev), None, cond.to(dev), lanes=n).clone()
     assert torch.equal(res[2], res[4]) and rel_err(res[1].cpu(), res[2].cpu()) < 1e-5, "the lanes' draws must be the one-lane loop's draws"
+    # round 6 (advisor): a step's noise is drawn when the first lane reaches the step and dropped after the last lane took its slice --
+    # the same bits as the same draws made up front, and never more than one step alive at a time while the host enqueues
+    torch.manual_seed(5)
+    upfront = [torch.randn(B, 3, T, dtype=torch.float64, device=dev) for _ in range(nsteps)]
+    assert torch.equal(edm.sample_stochastically(eps, sig.to(dev), None, cond.to(dev), churn_noises=upfront, lanes=2), res[2])
+    peak = []
+    cls = type(edm)._StepNoises
+    orig = cls.take
+
+    def take(self, *a):
+        out = orig(self, *a)
+        peak.append(len(self.live))
+        return out
+    cls.take = take
+    try:
+        torch.manual_seed(5)
+        again = edm.sample_stochastically(eps, sig.to(dev), None, cond.to(dev), lanes=4)
+    finally:
+        cls.take = orig
+    assert torch.equal(again, res[4]) and max(peak) <= 1 and len(peak) == 4 * nsteps

@@ -162,7 +162,7 @@ def test_plan_cache_is_bounded_and_evicts_least_recently_used_shape_groups():
     (B, T, device) GROUPS (all lanes of a shape together) and tells its owner which keys went (round-4 verdict: the cache was unbounded)."""
     from tqdne_amd._cache import PlanCache, plan_cache, PLAN_SHAPES
     gone = []
-    c = PlanCache(3, group=lambda k: k[:3], on_evict=gone.extend)
+    c = PlanCache(3, group=lambda k: k[:3], on_evict=lambda items: gone.extend(k for k, _ in items))
     for lane in range(4):
         c[(16, 4096, "cuda:0", 64 + lane)] = f"lane{lane}"
     c[(64, 4096, "cuda:0", 0)] = "train"
@@ -179,6 +179,49 @@ def test_plan_cache_is_bounded_and_evicts_least_recently_used_shape_groups():
     # the model classes use it
     from tqdne_amd import UNetModel, tiny_1d_unet_config
     assert isinstance(UNetModel(**tiny_1d_unet_config())._engine_cache, PlanCache)
+
+
+def test_plan_cache_hands_over_live_values_releases_them_and_postpones_under_capture():
+    """round-5 advisor findings: (1) the owner's callback sees the evicted VALUES while they are still referenced (it synchronises, then
+    breaks the plan <-> backward-plan cycle through ``release()``; only then are the buffers let go); (2) no eviction -- hence no
+    device synchronisation -- while ``can_evict()`` says no (a stream capture is in progress): the cache runs over its cap and catches
+    up at the next insertion."""
+    import gc
+    import weakref
+    from tqdne_amd._cache import PlanCache, _sync_on_evict
+
+    class Plan:   # a plan and its backward plan reference each other (engine.UNetEngine._bwd <-> engine_bwd.BackwardPlan.e)
+        def __init__(self):
+            self._bwd = type("Bwd", (), {})()
+            self._bwd.e = self
+            self.released = False
+
+        def release(self):
+            self._bwd.e = None
+            self._bwd = None
+            self.released = True
+
+    gc.disable()
+    try:
+        seen = []
+        c = PlanCache(2, on_evict=lambda items: (seen.extend(v.released for _, v in items), _sync_on_evict(items)))
+        a = Plan()
+        ra = weakref.ref(a)
+        c["a"] = a
+        del a
+        c["b"] = Plan()
+        c["c"] = Plan()          # evicts "a": its cycle is broken by release(), so it dies WITHOUT a cyclic-GC pass
+        assert seen == [False] and ra() is None
+        allow = [False]
+        c2 = PlanCache(2, can_evict=lambda: allow[0], on_evict=_sync_on_evict)
+        for k in "abcd":
+            c2[k] = Plan()
+        assert len(c2) == 4 and c2.evictions == 0
+        allow[0] = True
+        c2["e"] = Plan()
+        assert len(c2) == 2 and c2.evictions == 3 and "e" in c2 and "d" in c2
+    finally:
+        gc.enable()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -17,12 +17,15 @@ SCRATCH_ENTRIES = max(16, int(os.environ.get("TQDNE_SCRATCH_CACHE_ENTRIES", "64"
 class PlanCache:
     """dict-like (``get`` / ``[]=`` / ``values`` / ``items`` / ``in`` / ``len``), least-recently-used eviction by group.
 
-    ``group(key)``: the eviction unit of a key (default: the key itself).  ``on_evict(keys)``: called after a group was dropped
-    (before its buffers can be handed to anybody else) -- the owners synchronise the device there: launches of an evicted plan may
-    still be in flight on a side stream, and the caching allocator only orders re-use against the stream a block was allocated on."""
+    ``group(key)``: the eviction unit of a key (default: the key itself).  ``on_evict(items)``: called with the ``(key, value)`` pairs
+    of the dropped groups while the cache still holds the LAST references to them -- the owners synchronise the device there (launches
+    of an evicted plan may still be in flight on a side stream, and the caching allocator only orders re-use against the stream a block
+    was allocated on) and break the values' reference cycles, so that dropping them right afterwards frees their device memory.
+    ``can_evict()``: False postpones the eviction to a later insertion (the cache then runs over its cap meanwhile): a device
+    synchronisation inside a stream capture would invalidate the capture."""
 
-    def __init__(self, cap: int, group=None, on_evict=None):
-        self.cap, self._group, self._on_evict = cap, (group or (lambda k: k)), on_evict
+    def __init__(self, cap: int, group=None, on_evict=None, can_evict=None):
+        self.cap, self._group, self._on_evict, self._can_evict = cap, (group or (lambda k: k)), on_evict, can_evict
         self._d: "OrderedDict[object, dict]" = OrderedDict()   # group -> {key: value}, least recently used first
         self.evictions = 0
 
@@ -38,14 +41,17 @@ class PlanCache:
         g = self._group(key)
         grp = self._d.get(g)
         if grp is None:
-            dropped = []
-            while len(self._d) >= self.cap:
-                _, old = self._d.popitem(last=False)
-                dropped += list(old.keys())
-                self.evictions += 1
-                old.clear()
-            if dropped and self._on_evict is not None:
-                self._on_evict(dropped)
+            if len(self._d) >= self.cap and (self._can_evict is None or self._can_evict()):
+                dropped = []
+                while len(self._d) >= self.cap:
+                    _, old = self._d.popitem(last=False)
+                    dropped.append(old)
+                    self.evictions += 1
+                if self._on_evict is not None:   # (synchronise first, THEN let go of the buffers)
+                    self._on_evict([kv for old in dropped for kv in old.items()])
+                for old in dropped:
+                    old.clear()
+                del dropped
             grp = self._d[g] = {}
         grp[key] = value
         self._d.move_to_end(g)
@@ -73,22 +79,33 @@ class PlanCache:
         self._d.clear()
 
 
-def _sync_on_evict(keys):
-    """wait for the devices named in the evicted keys (every key carries ``str(device)``), or for the current one"""
+def _not_capturing() -> bool:
     import torch
-    if not torch.cuda.is_available():
-        return
-    devs = {part for k in keys if isinstance(k, tuple) for part in k if isinstance(part, str) and part.startswith("cuda")}
-    for d in devs or {None}:
-        torch.cuda.synchronize(None if d is None else torch.device(d))
+    return not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+
+
+def _sync_on_evict(items):
+    """wait for the devices named in the evicted keys (every key carries ``str(device)``), or for the current one; then take the evicted
+    values apart where they sit in reference cycles (``release()`` of an execution plan: plan <-> backward plan), so that their
+    activation / gradient buffers go back to the allocator with the last reference instead of waiting for a cyclic-GC pass that the
+    caching allocator never triggers"""
+    import torch
+    if torch.cuda.is_available():
+        devs = {part for k, _ in items if isinstance(k, tuple) for part in k if isinstance(part, str) and part.startswith("cuda")}
+        for d in devs or {None}:
+            torch.cuda.synchronize(None if d is None else torch.device(d))
+    for _, v in items:
+        rel = getattr(v, "release", None)
+        if callable(rel):
+            rel()
 
 
 def plan_cache() -> PlanCache:
     """cache of execution plans keyed (B, T, device[, lane]): grouped by the first three entries"""
-    return PlanCache(PLAN_SHAPES, group=lambda k: k[:3], on_evict=_sync_on_evict)
+    return PlanCache(PLAN_SHAPES, group=lambda k: k[:3], on_evict=_sync_on_evict, can_evict=_not_capturing)
 
 
 def scratch_cache() -> PlanCache:
     """cache of per-shape scratch buffers of the EDM / consistency wrappers (scalars, noised copies, sampler state): small next to the
     plans, bounded per entry"""
-    return PlanCache(SCRATCH_ENTRIES, on_evict=_sync_on_evict)
+    return PlanCache(SCRATCH_ENTRIES, on_evict=_sync_on_evict, can_evict=_not_capturing)

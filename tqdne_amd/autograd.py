@@ -43,14 +43,19 @@ class _EDMLossFn(th.autograd.Function):
         ctx.module, ctx.bufs, ctx.shape, ctx.nparams = module, bufs, tuple(sample.shape), len(params)
         ctx.cond = cond
         ctx.concat = cond_sample is not None  # the stem then saw a pre-scaled, concatenated input
+        # the plan that holds this forward's activations stays with the graph (the reference keeps its activations alive the same
+        # way): looked up again in backward it could be a NEW plan if the bounded cache evicted this one in between
+        ctx.eng = module.unet._engine(B, sample.shape[2], dev, module._lane)
+        ctx.fwd_id = ctx.eng._fwd_count
+        ctx.scalars = module._scalars(B, dev)
         return bufs["loss"][0].clone()
 
     @staticmethod
     def backward(ctx, gloss):
-        module, bufs = ctx.module, ctx.bufs
-        B, _, T = ctx.shape
-        eng = module.unet._engine(B, T, bufs["x"].device, module._lane)
-        sc = module._scalars(B, bufs["x"].device)
+        eng, bufs, sc = ctx.eng, ctx.bufs, ctx.scalars
+        if eng._fwd_count != ctx.fwd_id:
+            raise RuntimeError("another forward of the same shape ran between this loss and its backward: the execution plan's static "
+                               "buffers no longer hold its activations (call backward before the next step of that shape)")
         grads = eng.backward(bufs["dpred"], gloss, c_out=sc[1], in_scale=None if ctx.concat else sc[0])
         return (None, None, None, None, None, None) + tuple(grads)
 
@@ -90,12 +95,11 @@ def edm_loss_and_grads(module, sample, eps, unit_noise, cond, cond_sample=None, 
             for i, st in enumerate(streams):
                 module._lane = i if lanes == 1 else engine.CONCURRENT_LANE0 + i
                 with th.cuda.stream(st):
-                    loss = _EDMLossFn.forward(_Ctx, module, cut(sample, i) if lanes > 1 else sample, cut(eps, i) if lanes > 1 else eps,
+                    ctx = _Ctx()
+                    loss = _EDMLossFn.forward(ctx, module, cut(sample, i) if lanes > 1 else sample, cut(eps, i) if lanes > 1 else eps,
                                               cut(unit_noise, i) if lanes > 1 else unit_noise, cut(cond, i) if lanes > 1 else cond,
                                               cut(cond_sample, i) if lanes > 1 else cond_sample, *params)
-                    bufs = _Ctx.bufs
-                    Bl, _, T = _Ctx.shape
-                    eng = module.unet._engine(Bl, T, dev, module._lane)
+                    bufs, eng = ctx.bufs, ctx.eng
                     scale = th.full((), 1.0 / lanes, device=dev)
                     grads = eng.backward(bufs["dpred"], scale, clone=False, on_bucket=on_bucket if lanes == 1 else None,
                                          bucket_elems=bucket_elems, tail_fill=tail_fill if lanes == 1 else None)

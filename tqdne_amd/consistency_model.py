@@ -55,12 +55,17 @@ class _ICTLossFn(torch.autograd.Function):
               "pseudo-Huber loss")
         ctx.module, ctx.shape = module, tuple(sample.shape)
         ctx.dpred = bufs["dpred"]
+        # (the plan stays with the graph: a later look-up could find a NEW plan if the bounded cache evicted this one in between)
+        ctx.eng = module.net._engine(B, sample.shape[2], dev)
+        ctx.fwd_id = ctx.eng._fwd_count
         return bufs["loss"][0].clone()
 
     @staticmethod
     def backward(ctx, gloss):
-        B, _, T = ctx.shape
-        eng = ctx.module.net._engine(B, T, ctx.dpred.device)
+        eng = ctx.eng
+        if eng._fwd_count != ctx.fwd_id:
+            raise RuntimeError("another forward of the same shape ran between this loss and its backward: the execution plan's static "
+                               "buffers no longer hold its activations")
         grads = eng.backward(ctx.dpred, gloss)
         return (None,) * 6 + tuple(grads)
 

@@ -336,7 +336,7 @@ class LightningEDM(LightningModule):
                     lane_churn = None
                     if churn is not None:
                         shat, coef, noises = churn
-                        lane_churn = (shat, coef, lambda k, _i=i: noises[k][_i * h:(_i + 1) * h].contiguous())
+                        lane_churn = (shat, coef, lambda k, _i=i, _st=st: noises.take(k, _i, h, _st))
                     runs.append(self._heun_lane(cut(eps, i), sigmas, cut(cond_sample, i), cut(cond, i), use_graph, churn=lane_churn))
             # one sampler step of lane 0, then of lane 1, ...: all queues stay fed well ahead of the GPU
             while not all(r.done for r in runs):
@@ -356,6 +356,40 @@ class LightningEDM(LightningModule):
         for r in runs:
             r.release()
         return out
+
+    class _StepNoises:
+        """The churned sampler's unit noises, one (B, C, T) fp64 draw per step for the WHOLE batch, handed out per lane.  Step k is drawn
+        when the FIRST lane asks for it -- the lanes advance step-major (``_run_lanes``), so this is lane 0 on the caller's stream and
+        the draws come in the one-lane loop's order (edm.py:207's ``randn_like`` per step) -- and let go once the last lane has taken
+        its slice: at most a step or two are alive instead of all ``num_sampling_steps`` (0.45 GB at B = 256; round-5 advisor).
+        Stream safety: the draw is recorded as an event that every other lane's stream waits for, and each slice is registered with
+        the lane's stream (``record_stream``), so the allocator does not hand the block out again before the lane's launches ran."""
+
+        def __init__(self, shape, dev, lanes, given=None):
+            self.shape, self.dev, self.lanes, self.given = tuple(shape), dev, lanes, given
+            self.live = {}   # step -> [tensor, event, slices still to hand out]
+            self.drawn = 0
+
+        def take(self, k, lane, h, stream):
+            ent = self.live.get(k)
+            if ent is None:
+                if self.given is not None:
+                    t = self.given[k].to(device=self.dev, dtype=th.float64).contiguous()
+                else:
+                    assert k == self.drawn, "noises are drawn in step order"
+                    t = th.randn(self.shape, dtype=th.float64, device=self.dev)
+                self.drawn = max(self.drawn, k + 1)
+                ev = th.cuda.Event()
+                ev.record(th.cuda.current_stream(self.dev))
+                ent = self.live[k] = [t, ev, self.lanes, th.cuda.current_stream(self.dev)]
+            t, ev, left, src = ent
+            if stream != src:
+                stream.wait_event(ev)
+                t.record_stream(stream)
+            ent[2] = left - 1
+            if ent[2] == 0:
+                del self.live[k]
+            return t[lane * h:(lane + 1) * h]
 
     def _side_stream(self, dev, i=1):
         return engine.side_stream(dev, i)   # (one pool per process: the number of live streams matters, see engine.side_stream)
@@ -408,8 +442,7 @@ class LightningEDM(LightningModule):
                 s_i, s_n = sp + 4 * i, sp + 4 * (i + 1)
                 if churn is not None:
                     shat, coef, noise_of_step = churn
-                    unit = noise_of_step(i)
-                    r.keep = r.keep + (unit,)   # (alive until the launches that read it have been enqueued AND run: released with the run)
+                    unit = noise_of_step(i)   # (a slice registered with this lane's stream: safe to let go once the launch is enqueued)
                     s_hat = shat.data_ptr() + 4 * i
                     check(lib.tq_heun_churn(_p(r.x), _p(unit), coef.data_ptr() + 4 * i, float(edm.edm.S_noise), _p(r.xh), _p(r.x32), n,
                                             stream), "heun churn")
@@ -459,6 +492,9 @@ class LightningEDM(LightningModule):
         key = (nsig, None if cond is None else tuple(cond.shape), None if cond_sample is None else tuple(cond_sample.shape),
                eng.uid, eng.plan_epoch, self.num_sampling_steps)
         cache = bufs.setdefault("loop_graphs", {})   # one captured loop per key (a sweep over step counts re-uses them)
+        live = {e.uid for e in self.unet._engine_cache.values()}
+        for k_ in [k_ for k_ in cache if k_[3] not in live]:   # graphs of evicted plans: their launches point into freed buffers
+            del cache[k_]
         g = cache.get(key)
         if g is None:
             st = dict(key=key, sig=th.empty(nsig, dtype=th.float32, device=dev), start=th.empty_like(bufs["x"]),
@@ -557,18 +593,19 @@ class LightningEDM(LightningModule):
         if lanes is None:
             lanes = sampler_lanes(B)
         if lanes >= 2 and B % lanes == 0 and B // lanes >= 8:
-            # round 5: the stochastic sampler on the lanes of the deterministic one.  The unit noises of ALL steps are drawn first, for
-            # the whole batch and in the order the one-lane loop draws them (line 207's randn_like per step), then cut per lane: the
-            # result is bit-identical to the one-lane integration of the same draws.
-            nst = sig.numel() - 1
-            if churn_noises is None:
-                noises = [th.randn(eps.shape, dtype=th.float64, device=dev) for _ in range(nst)]
-            else:
-                noises = [churn_noises[i].to(device=dev, dtype=th.float64).contiguous() for i in range(nst)]
+            # round 5: the stochastic sampler on the lanes of the deterministic one.  A step's unit noise is drawn for the whole batch,
+            # in the order the one-lane loop draws them (line 207's randn_like per step), when the first lane reaches the step, and cut
+            # per lane (_StepNoises): the result does not depend on the number of lanes (>= 2), and equals the one-lane integration of
+            # the same draws bit for bit where the one-lane plan uses the same tiles (it does at B = 64; a small solo batch takes the
+            # small position tile on some levels, engine.SMALL_TILE_WGS, which associates the GroupNorm sums differently: ~1e-6).
+            rng_state = th.cuda.get_rng_state(dev) if churn_noises is None else None
+            noises = self._StepNoises(eps.shape, dev, lanes, churn_noises)
             out = self._run_lanes(eps, sig, cond_sample, cond, lanes, churn=(shat, coef, noises))
             engs = [e for e in self.unet._engine_cache.values() if e.dev == dev]
-            if engs and engs[0].check_range():
-                return self.sample_stochastically(eps, sigmas, cond_sample, cond, noises, lanes)  # (the plans are on bf16x3 now)
+            if engs and engs[0].check_range():   # (the plans are on bf16x3 now: the same draws again)
+                if rng_state is not None:
+                    th.cuda.set_rng_state(rng_state, dev)
+                return self.sample_stochastically(eps, sigmas, cond_sample, cond, churn_noises, lanes)
             return out
         bufs = self._sampler_buffers(eps)
         if "xh" not in bufs:

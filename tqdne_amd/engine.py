@@ -755,9 +755,8 @@ class UNetEngine:
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)   # (padding rows t >= T stay zero)
             self._keep.append(ws)
             fn, args, *rest = self.ops[i]
+            # (only D = 32 / 64 blocks are listed: their inference op is the pre-split launch, another entry point with another workspace)
             self.ops[i] = (fn, args[:3] + (ws.data_ptr(),) + args[4:], *rest)
-            if self.ops_infer[i] is not self.ops[i] and self.ops_infer[i][0] is fn:   # (D = 128: one op serves both lists)
-                self.ops_infer[i] = self.ops[i]
             self.tape[ti][1]["kv_ws"] = ws
         self._block_kv = True
 
@@ -1011,6 +1010,17 @@ class UNetEngine:
             self._range_poll(False)
         self._mark_use(stream)
         return self.out_nct
+
+    def release(self):
+        """Called by the bounded plan cache when this plan is evicted (after the device has been synchronised): the plan and its
+        backward plan reference each other (``_bwd`` <-> ``BackwardPlan.e``, and the backward plan's attention closures hold the
+        plan), so without this the activation, gradient and scratch buffers -- several GB at B = 64 -- would outlive the eviction
+        until a cyclic-GC pass, which the caching allocator never asks for.  The plan stays usable for whoever still holds it (an
+        autograd graph whose backward has not run yet: ``ctx.eng``): a later ``backward`` builds a fresh backward plan."""
+        bwd, self._bwd = self._bwd, None
+        if bwd is not None:
+            bwd.e = None
+            bwd.ops = []
 
     # ------------------------------------------------------------------ backward
     def backward(self, dpred: torch.Tensor, gloss: torch.Tensor, c_out=None, in_scale=None, clone: bool = True, on_bucket=None,
