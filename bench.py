@@ -90,6 +90,27 @@ def conv_flops_per_sample(unet, T):
     return total
 
 
+# SURVEY.md 8d byte model: fused-minimum activation bytes per sample and forward (every conv / attention core reads its input and
+# writes its output once in fp32; everything else fused; probed with hooks over the imported reference).
+# Weights W = 4 bytes x parameters, read once per call; train = 3 B A + 3 W + 7 W (Adam) + 3 W (EMA: read ema, p; write ema).
+ALGO_A = {"paper": 174.7e6, "tiny": 74.3e6, "latent_unet": 175.2e6, "ae_enc": 130.7e6, "ae_dec": 176.6e6}
+AE_BASE = dict(model_channels=64, channel_mult=(1, 2, 4), attention_resolutions=(), num_res_blocks=2, dims=1, conv_kernel_size=5, dropout=0.1)
+EMA_DECAY = 0.999   # the reference's 1-D trainer always runs the EMA callback (experiments/train_1d_edm.py:55, tqdne/ema.py:24-28)
+
+
+def step_bytes(A, W, B, nfe, train=True, sample=True, ema=True):
+    """algorithmic HBM bytes of [one train step] + [one nfe-evaluation sample] at batch B"""
+    return ((3 * B * A + (13 if ema else 10) * W) if train else 0) + ((nfe * (B * A + W)) if sample else 0)
+
+
+def hbm_block(nbytes, ms, note=None):
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    d = dict(bound="hbm", achieved=gbps, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbps / HBM_PEAK_GBS, algorithmic_bytes_per_step=nbytes)
+    if note:
+        d["note"] = note
+    return d
+
+
 PARITY_TRAJECTORY = (1, 6, 12)   # sampler steps whose state is compared on the way to the final sample (error growth over the NFEs)
 
 
@@ -108,33 +129,60 @@ def parity_inputs(cfg, B, T):
 
 def _cpu_baseline_worker(cfg_name, B, T, nsample_steps, seed, nthreads, reps, parity_path=None):
     """Runs in a child process: time the CPU oracle (oracle/ = our PyTorch-CPU restatement, a "port") on a bounded
-    sample of the same workload: full train steps (fwd + bwd + Adam) and 18-step samples at batch B; one untimed warm-up of
-    each half (a train step and a 2-step sample), then ``reps`` timed repetitions, printed one JSON line each."""
+    sample of the same workload: full train steps (fwd + bwd + Adam + EMA) and 18-step samples at batch B; one untimed warm-up of
+    each half (a train step and a 2-step sample), then ``reps`` timed repetitions, printed one JSON line each.
+    ``cfg_name``: "paper" / "tiny" (EDM on 3 x T), "latent" (BASELINE configs[3]: frozen autoencoder 3 x T <-> 16 x T / 4 + paper-shape
+    latent UNet: train = encode + latent step, sample = latent sample + decode), "consistency" (configs[4]: train = nothing, sample =
+    ONE network evaluation under the consistency forward)."""
     import torch
     from oracle import edm as OE
     from tqdne_amd import UNetModel, paper_1d_unet_config, tiny_1d_unet_config
 
     torch.set_num_threads(nthreads)
-    cfg = paper_1d_unet_config() if cfg_name == "paper" else tiny_1d_unet_config()
+    latent = cfg_name == "latent"
+    cfg = tiny_1d_unet_config() if cfg_name == "tiny" else paper_1d_unet_config(**(dict(in_channels=16, out_channels=16) if latent else {}))
     torch.manual_seed(0)
     sd = perturbed_state(UNetModel(**cfg), 17)
     g = torch.Generator().manual_seed(seed)
     sig = 0.5 * torch.randn(B, 3, T, generator=g)
     cond = torch.randn(B, 5, generator=g) if cfg.get("cond_features") else None
     params = {("unet." + k): v.clone().requires_grad_(v.is_floating_point() and k != "time_embed.W") for k, v in sd.items()}
-    opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=1e-4)
+    trainable = [p for p in params.values() if p.requires_grad]
+    opt = torch.optim.Adam(trainable, lr=1e-4)
+    ema = [q.detach().clone() for q in trainable]
     p = OE.EDMParams()
     net = OE.make_net(params, cfg)
+    C_l, T_l = 3, T
+    if latent:
+        from oracle import autoencoder as OA
+        from tqdne_amd import LightningAutoencoder
+        enc_cfg, dec_cfg = dict(AE_BASE, in_channels=3, out_channels=32), dict(AE_BASE, in_channels=16, out_channels=3)
+        ae_sd = perturbed_state(LightningAutoencoder(enc_cfg, dec_cfg, {"learning_rate": 1e-4, "max_steps": 1000, "eta_min": 0.0}), 19)
+        C_l, T_l = 16, T // 4
 
     def train():
+        if cfg_name == "consistency":
+            return
+        x = sig
+        if latent:
+            with torch.no_grad():
+                x = OA.encode(ae_sd, enc_cfg, sig, torch.randn(B, C_l, T_l, generator=g))[0]
         opt.zero_grad()
-        loss = OE.loss_step(p, net, sig, torch.randn(B, generator=g), torch.randn(B, 3, T, generator=g), cond=cond)
+        loss = OE.loss_step(p, net, x, torch.randn(B, generator=g), torch.randn(B, C_l, T_l, generator=g), cond=cond)
         loss.backward()
         opt.step()
+        with torch.no_grad():   # tqdne/ema.py:24-28
+            torch._foreach_lerp_(ema, trainable, 1 - EMA_DECAY)
 
     def sample(n):
         with torch.no_grad():
-            OE.sample_deterministic(p, net, torch.randn(B, 3, T, generator=g, dtype=torch.float64), n, cond=cond)
+            if cfg_name == "consistency":
+                from oracle import consistency as OC
+                OC.sample(net, torch.randn(B, 3, T, generator=g), cond=cond)
+                return
+            z = OE.sample_deterministic(p, net, torch.randn(B, C_l, T_l, generator=g, dtype=torch.float64), n, cond=cond)
+            if latent:
+                OA.decode(ae_sd, dec_cfg, z.float())
 
     if parity_path:
         # same-run parity gate: the oracle's denoiser output, loss (dropout off) and full sample for the injected inputs, on the
@@ -251,15 +299,39 @@ def parity_block(gpu, cpu_path, args):
     return blk
 
 
+def _cpu_extra(cfg_name, B, T, args, reps, timeout_s, what):
+    """bounded CPU-oracle baseline of one of the extra configurations (all visible cores, <= 64 threads): median of ``reps``
+    repetitions after a warm-up; None when it does not finish"""
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        ncores = os.cpu_count() or 1
+    nth = max(1, min(ncores, 64))
+    got = _cpu_run(cfg_name, B, T, args.sample_steps, 99, nth, reps, timeout_s)
+    if not got:
+        return dict(value=None, unit="waveforms/s", cores=nth, kind="port", sample=f"{what}: did not finish within {timeout_s} s")
+    tt, tsm = _median([x["t_train"] for x in got]), _median([x["t_sample"] for x in got])
+    return dict(value=B / (tt + tsm), unit="waveforms/s", cores=nth, kind="port", train_s=tt, sample_s=tsm,
+                sample=f"{what}, B={B}: warm-up, then median of {len(got)} repetition(s), CPU oracle, {nth} threads")
+
+
 def other_configs(dev, args):
-    """BASELINE.json configs[0], [3], [4] and the reference's real data shape next to the headline (configs[1]): parity-test cases,
-    reported with the same step definition (1 train step + one 18-step sample; cfg4: one consistency sample) so that the small / latent /
-    consistency paths have a number in the driver's record.
-      cfg0  tiny UNet (32 base channels, no attention, unconditioned), B = 4, 3 x 4096 -- with its own CPU-oracle baseline at B = 4
-      cfg3  latent EDM: frozen autoencoder 3 x 16384 <-> 16 x 4096 + paper-shape latent UNet, B = 16 (sample = 18 steps + decode)"""
+    """BASELINE.json configs[0], [3], [4], the reference's real data shape and the reference's default batch next to the headline
+    (configs[1]): parity-test cases, reported with the same step definition (1 train step incl. EMA + one 18-step sample; cfg4: one
+    consistency sample) so that the small / latent / consistency paths have a number in the driver's record.  Every entry carries
+    ``hbm_roofline`` (SURVEY.md 8d byte model over the measured time, against 8 TB/s) and, where a bounded CPU run fits, ``cpu_baseline``.
+      cfg0  tiny UNet (32 base channels, no attention, unconditioned), B = 4, 3 x 4096 -- CPU oracle at B = 4 in full
+      cfg3  latent EDM: frozen autoencoder 3 x 16384 <-> 16 x 4096 + paper-shape latent UNet, B = 16 and B = 64 (sample = 18 steps + decode)
+      cfg4  consistency 1-step sampling, B = 64
+      6 x 4064  the reference's data shape through the GPU MovingAverageEnvelope
+      B = 256   the reference's default per-device batch (train_1d_edm.py:83-85), with and without use_checkpoint"""
     from tqdne_amd import LightningAutoencoder, LightningEDM, paper_1d_unet_config, rng, tiny_1d_unet_config
     from tqdne_amd.trainer import DataParallelTrainer
     res = []
+    nfe = 2 * args.sample_steps - 1
+    opt = {"learning_rate": 1e-4, "max_steps": 100000, "eta_min": 0.0}
+    cpu = not args.no_cpu_baseline
+    nparam = lambda mod: sum(p.numel() for p in mod.parameters())
 
     def med(fn, n=5):
         fn(); fn()
@@ -272,17 +344,22 @@ def other_configs(dev, args):
             ts.append(1e3 * (time.perf_counter() - t0))
         return _median(ts)
 
+    def entry(config, B, unit, ms, ms_train, nbytes, **parts):
+        return dict(config=config, value=B / (ms * 1e-3), unit=unit, ms_per_step=ms,
+                    train_wf_s=B / (ms_train * 1e-3), sample_wf_s=B / ((ms - ms_train) * 1e-3),
+                    parts=dict(train_ms=ms_train, sample_ms=ms - ms_train, **parts), hbm_roofline=hbm_block(nbytes, ms))
+
     # ---- cfg0
     try:
         torch.manual_seed(args.seed)
         cfg = tiny_1d_unet_config()
-        edm = LightningEDM(cfg, {"learning_rate": 1e-4, "max_steps": 100000, "eta_min": 0.0}, num_sampling_steps=args.sample_steps)
+        edm = LightningEDM(cfg, opt, num_sampling_steps=args.sample_steps)
         edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
         edm = edm.to(dev)
         B, T = 4, 4096
         g = torch.Generator().manual_seed(4321)
         batch = {"signal": (0.5 * torch.randn(B, 3, T, generator=g)).to(dev)}
-        tr = DataParallelTrainer(edm, world_size=1)
+        tr = DataParallelTrainer(edm, world_size=1, ema_decay=EMA_DECAY)
         sig = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
         eps0 = torch.randn(B, 3, T, generator=g, dtype=torch.float64).to(dev) * sig[0]
 
@@ -297,21 +374,11 @@ def other_configs(dev, args):
             tr.train_step(batch)
 
         ms, ms_train = med(step), med(train_only)
-        r = dict(config="cfg0: tiny 1-D EDM UNet (32 base channels, 2 res blocks, no attention), B=4, 3x4096: 1 train step + "
-                        f"{args.sample_steps}-step Heun sample",
-                 value=B / (ms * 1e-3), unit="waveforms/s", ms_per_step=ms, parts=dict(train_ms=ms_train, sample_ms=ms - ms_train))
-        if not args.no_cpu_baseline:
-            try:
-                ncores = len(os.sched_getaffinity(0))
-            except Exception:
-                ncores = os.cpu_count() or 1
-            nth = max(1, min(ncores, 64))
-            reps = _cpu_run("tiny", B, T, args.sample_steps, 99, nth, 2, 120)
-            if reps:
-                tt, tsm = _median([x["t_train"] for x in reps]), _median([x["t_sample"] for x in reps])
-                r["cpu_baseline"] = dict(value=B / (tt + tsm), unit="waveforms/s", cores=nth, kind="port", train_s=tt, sample_s=tsm,
-                                         sample=f"tiny UNet, B={B}, 3x{T} in full: warm-up, then median of {len(reps)} x (1 train "
-                                                f"step + 1 x {args.sample_steps}-step sample), CPU oracle, {nth} threads")
+        r = entry("cfg0: tiny 1-D EDM UNet (32 base channels, 2 res blocks, no attention), B=4, 3x4096: 1 train step + "
+                  f"{args.sample_steps}-step Heun sample", B, "waveforms/s", ms, ms_train,
+                  step_bytes(ALGO_A["tiny"], 4 * nparam(edm.unet), B, nfe))
+        if cpu:
+            r["cpu_baseline"] = _cpu_extra("tiny", B, T, args, 2, 120, f"tiny UNet, 3x{T} in full (1 train step + 1 x {args.sample_steps}-step sample)")
         res.append(r)
         del edm, tr
     except Exception as e:   # (a reported extra: never takes the headline line down)
@@ -319,36 +386,40 @@ def other_configs(dev, args):
     # ---- cfg3
     try:
         torch.manual_seed(args.seed)
-        base = dict(model_channels=64, channel_mult=(1, 2, 4), attention_resolutions=(), num_res_blocks=2, dims=1, conv_kernel_size=5,
-                    dropout=0.1)
-        ae = LightningAutoencoder(dict(base, in_channels=3, out_channels=32), dict(base, in_channels=16, out_channels=3),
+        ae = LightningAutoencoder(dict(AE_BASE, in_channels=3, out_channels=32), dict(AE_BASE, in_channels=16, out_channels=3),
                                   {"learning_rate": 1e-4, "max_steps": 1000, "eta_min": 0.0})
         ae.load_state_dict(perturbed_state(ae, 19))
         ae = ae.to(dev).eval()
-        edm = LightningEDM(paper_1d_unet_config(in_channels=16, out_channels=16), {"learning_rate": 1e-4, "max_steps": 100000, "eta_min": 0.0},
-                           num_sampling_steps=args.sample_steps, autoencoder=ae)
+        edm = LightningEDM(paper_1d_unet_config(in_channels=16, out_channels=16), opt, num_sampling_steps=args.sample_steps, autoencoder=ae)
         edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
         edm = edm.to(dev)
-        B, T = 16, 16384
-        g = torch.Generator().manual_seed(4322)
-        batch = {"signal": (0.5 * torch.randn(B, 3, T, generator=g)).to(dev), "cond": torch.randn(B, 5, generator=g).to(dev)}
-        tr = DataParallelTrainer(edm, world_size=1)
+        T = 16384
+        tr = DataParallelTrainer(edm, world_size=1, ema_decay=EMA_DECAY)
+        W_u, W_e, W_d = 4 * nparam(edm.unet), 4 * nparam(ae.encoder), 4 * nparam(ae.decoder)
+        for B in (16, 64):
+            g = torch.Generator().manual_seed(4322)
+            batch = {"signal": (0.5 * torch.randn(B, 3, T, generator=g)).to(dev), "cond": torch.randn(B, 5, generator=g).to(dev)}
 
-        def step3():
-            edm.train()
-            tr.train_step(batch)
-            edm.eval()
-            edm.sample((B, 3, T), cond=batch["cond"])
+            def step3():
+                edm.train()
+                tr.train_step(batch)
+                edm.eval()
+                edm.sample((B, 3, T), cond=batch["cond"])
 
-        def train3():
-            edm.train()
-            tr.train_step(batch)
+            def train3():
+                edm.train()
+                tr.train_step(batch)
 
-        ms, ms_train = med(step3, 3), med(train3, 3)
-        res.append(dict(config="cfg3: 1-D latent EDM: frozen autoencoder 3x16384 <-> 16x4096 + paper-shape latent UNet, B=16: 1 train step "
-                               f"(encode + latent UNet fwd/bwd + Adam) + {args.sample_steps}-step latent Heun sample + decode",
-                        value=B / (ms * 1e-3), unit="waveforms/s (3x16384)", ms_per_step=ms,
-                        parts=dict(train_ms=ms_train, sample_ms=ms - ms_train)))
+            ms, ms_train = med(step3, 3), med(train3, 3)
+            # train = encode + latent UNet step; sample = 35 latent evaluations + decode
+            nbytes = (B * ALGO_A["ae_enc"] + W_e) + step_bytes(ALGO_A["latent_unet"], W_u, B, nfe) + (B * ALGO_A["ae_dec"] + W_d)
+            r = entry(f"cfg3: 1-D latent EDM: frozen autoencoder 3x16384 <-> 16x4096 + paper-shape latent UNet, B={B}: 1 train step "
+                      f"(encode + latent UNet fwd/bwd + Adam + EMA) + {args.sample_steps}-step latent Heun sample + decode",
+                      B, "waveforms/s (3x16384)", ms, ms_train, nbytes)
+            if cpu and B == 16:
+                r["cpu_baseline"] = _cpu_extra("latent", 2, T, args, 1, 150, "latent EDM (encode + latent step; latent sample + decode), 3x16384")
+            res.append(r)
+            del batch
         del edm, ae, tr
     except Exception as e:
         res.append(dict(config="cfg3", error=repr(e)))
@@ -368,10 +439,14 @@ def other_configs(dev, args):
         u4 = torch.rand(B, 3, T, generator=g).to(dev)
         ms1 = med(lambda: cm.sample_from(eps4, [], [], None, cond4), 7)
         ms2 = med(lambda: cm.sample_from(eps4, [1.0], [u4], None, cond4), 7)
-        res.append(dict(config="cfg4: consistency-model sampling (consistency_model.py:81-106) on the paper UNet, B=64, 3x4096: step = ONE "
-                               "1-step sample of the batch (1 network evaluation); parts: the reference's default sigmas=[1.0] call (2 evaluations)",
-                        value=B / (ms1 * 1e-3), unit="waveforms/s", ms_per_step=ms1,
-                        parts=dict(one_step_sample_ms=ms1, two_step_sample_ms=ms2, two_step_waveforms_per_s=B / (ms2 * 1e-3))))
+        r = dict(config="cfg4: consistency-model sampling (consistency_model.py:81-106) on the paper UNet, B=64, 3x4096: step = ONE "
+                        "1-step sample of the batch (1 network evaluation); parts: the reference's default sigmas=[1.0] call (2 evaluations)",
+                 value=B / (ms1 * 1e-3), unit="waveforms/s", ms_per_step=ms1,
+                 parts=dict(one_step_sample_ms=ms1, two_step_sample_ms=ms2, two_step_waveforms_per_s=B / (ms2 * 1e-3)),
+                 hbm_roofline=hbm_block(B * ALGO_A["paper"] + 4 * nparam(net), ms1))
+        if cpu:
+            r["cpu_baseline"] = _cpu_extra("consistency", 4, T, args, 3, 90, "paper UNet under the consistency forward, 1 network evaluation, 3x4096")
+        res.append(r)
         del cm, net
     except Exception as e:
         res.append(dict(config="cfg4", error=repr(e)))
@@ -381,8 +456,7 @@ def other_configs(dev, args):
     try:
         from tqdne_amd.representation import MovingAverageEnvelope
         torch.manual_seed(args.seed)
-        edm = LightningEDM(paper_1d_unet_config(in_channels=6, out_channels=6), {"learning_rate": 1e-4, "max_steps": 100000, "eta_min": 0.0},
-                           num_sampling_steps=args.sample_steps)
+        edm = LightningEDM(paper_1d_unet_config(in_channels=6, out_channels=6), opt, num_sampling_steps=args.sample_steps)
         edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
         edm = edm.to(dev)
         B, T = 64, 4064
@@ -390,7 +464,7 @@ def other_configs(dev, args):
         wave = (0.5 * torch.randn(B, 3, T, generator=g)).to(dev)
         cond6 = torch.randn(B, 5, generator=g).to(dev)
         rep = MovingAverageEnvelope()
-        tr = DataParallelTrainer(edm, world_size=1)
+        tr = DataParallelTrainer(edm, world_size=1, ema_decay=EMA_DECAY)
 
         def train6():
             edm.train()
@@ -405,14 +479,61 @@ def other_configs(dev, args):
             return rep.invert_representation(rep.get_representation(wave))
 
         ms, ms_train, ms_rep = med(step6, 3), med(train6, 3), med(repr6, 5)
-        res.append(dict(config="reference data shape: 3x4064 waveforms through MovingAverageEnvelope (GPU) -> 6x4064, paper UNet 6 -> 6 channels, "
-                               f"B=64: 1 train step (representation + fwd/bwd + Adam) + {args.sample_steps}-step Heun sample + inverse representation",
-                        value=B / (ms * 1e-3), unit="waveforms/s (3x4064)", ms_per_step=ms,
-                        parts=dict(train_ms=ms_train, sample_ms=ms - ms_train, representation_fwd_inv_ms=ms_rep)))
+        # (the 3 x 4096 figure scaled to 4064 positions, plus the three extra stem-input / head-output channels)
+        A6 = ALGO_A["paper"] * T / 4096 + 4.0 * T * 6
+        res.append(entry("reference data shape: 3x4064 waveforms through MovingAverageEnvelope (GPU) -> 6x4064, paper UNet 6 -> 6 channels, "
+                         f"B=64: 1 train step (representation + fwd/bwd + Adam + EMA) + {args.sample_steps}-step Heun sample + inverse representation",
+                         B, "waveforms/s (3x4064)", ms, ms_train, step_bytes(A6, 4 * nparam(edm.unet), B, nfe),
+                         representation_fwd_inv_ms=ms_rep))
         del edm, tr
     except Exception as e:
         res.append(dict(config="6x4064", error=repr(e)))
     torch.cuda.empty_cache()
+    # ---- the reference's default per-device batch, -b 256 (experiments/train_1d_edm.py:83-85), paper UNet 3 x 4096: the train step
+    # with every activation kept and with use_checkpoint=True (block-internal activations recomputed in the backward), and the step
+    for ckpt in (False, True):
+        try:
+            torch.manual_seed(args.seed)
+            edm = LightningEDM(dict(paper_1d_unet_config(), use_checkpoint=ckpt), opt, num_sampling_steps=args.sample_steps)
+            edm.unet.load_state_dict(perturbed_state(edm.unet, 17))
+            edm = edm.to(dev)
+            B, T = 256, 4096
+            g = torch.Generator().manual_seed(4325)
+            batch = {"signal": (0.5 * torch.randn(B, 3, T, generator=g)).to(dev), "cond": torch.randn(B, 5, generator=g).to(dev)}
+            tr = DataParallelTrainer(edm, world_size=1, ema_decay=EMA_DECAY)
+            torch.cuda.reset_peak_memory_stats(dev)
+            base = torch.cuda.memory_allocated(dev)
+
+            def train256():
+                edm.train()
+                tr.train_step(batch)
+
+            ms_train = med(train256, 3)
+            peak = (torch.cuda.max_memory_allocated(dev) - base) / 2 ** 30
+            W_ = 4 * nparam(edm.unet)
+            r = dict(config=f"reference default batch: paper UNet, B=256, 3x4096, use_checkpoint={ckpt}: 1 train step (dropout 0.1, Adam, EMA)",
+                     value=B / (ms_train * 1e-3), unit="waveforms/s (train step only)", ms_per_step=ms_train, train_wf_s=B / (ms_train * 1e-3),
+                     parts=dict(train_ms=ms_train, peak_memory_gib_above_weights_and_inputs=peak),
+                     hbm_roofline=hbm_block(step_bytes(ALGO_A["paper"], W_, B, nfe, sample=False), ms_train))
+            if not ckpt:
+                sig = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
+                eps0 = torch.randn(B, 3, T, generator=g, dtype=torch.float64).to(dev) * sig[0]
+
+                def sample256():
+                    edm.eval()
+                    edm.sample_deterministically(eps0, sig, None, batch["cond"])
+
+                ms_s = med(sample256, 2)
+                r["parts"]["sample_ms"] = ms_s
+                r["sample_wf_s"] = B / (ms_s * 1e-3)
+                r["step_wf_s"] = B / ((ms_train + ms_s) * 1e-3)
+                r["hbm_roofline_step"] = hbm_block(step_bytes(ALGO_A["paper"], W_, B, nfe), ms_train + ms_s)
+                del eps0
+            res.append(r)
+            del edm, tr, batch
+        except Exception as e:
+            res.append(dict(config=f"B=256 use_checkpoint={ckpt}", error=repr(e)))
+        torch.cuda.empty_cache()
     return res
 
 
@@ -505,12 +626,41 @@ def init_distributed(backend: str, rank: int, world: int, dev=None, init_timeout
     wd.cancel()
     wd = Watchdog(first_timeout_s, "first_collective", rank, world, dict(backend=backend))
     ones = torch.ones(1, device=dev if dev is not None else "cpu")
-    dist.all_reduce(ones)
+    all_reduce_(ones)
     n = int(ones.item())   # (synchronises: the collective has run)
     wd.cancel()
     if n != world:
         raise SystemExit(f"first collective summed {n} ranks, expected {world}")
     return n
+
+
+def _host_staged() -> bool:
+    """the dry-run backend (gloo) exchanges host tensors: device tensors are staged through the host around every collective"""
+    import torch.distributed as dist
+    return dist.get_backend() == "gloo"
+
+
+def all_reduce_(t, op=None):
+    import torch.distributed as dist
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and _host_staged():
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def all_gather_(t, world):
+    import torch.distributed as dist
+    if t.is_cuda and _host_staged():
+        out = [torch.zeros_like(t, device="cpu") for _ in range(world)]
+        dist.all_gather(out, t.cpu())
+        return out
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return out
 
 
 def replica_checksum(params) -> "torch.Tensor":
@@ -528,9 +678,7 @@ def gather_checksums(cs: "torch.Tensor", world: int, collective: bool = None):
     import torch.distributed as dist
     if not (world > 1 if collective is None else collective):
         return [int(cs[0].item())]
-    out = [torch.zeros_like(cs) for _ in range(world)]
-    dist.all_gather(out, cs)
-    return [int(t[0].item()) for t in out]
+    return [int(t[0].item()) for t in all_gather_(cs, world)]
 
 
 def op_class(name):
@@ -594,6 +742,8 @@ def main():
     ap.add_argument("--no-tables", action="store_true", help="skip the per-class traced passes after the timed region")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gradient all-reduce after the backward instead of under it")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg0 / cfg3 extras of the headline run")
+    ap.add_argument("--no-ema", action="store_true", help="train step without the EMA of the weights (the reference's 1-D trainer "
+                                                          "always keeps one: train_1d_edm.py:55; A/B switch)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true", help="replay the whole sampler integration from one HIP graph (neutral at B=64: GPU-bound)")
@@ -613,8 +763,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Dry run of the N > 1 program on a 1-GPU box: TQDNE_BENCH_BACKEND=gloo (collectives over gloo, device tensors staged through the
+    # host) + TQDNE_BENCH_SHARE_DEVICE=1 (every rank on cuda:0).  Everything else is the program the driver runs on a node -- the
+    # self-launch through torch.distributed.run, per-rank shards and seeds, the rank-0 broadcast, the bucketed exchange issued from inside
+    # the backward sweep, the max-over-ranks timing, the checksums, exit codes 3 / 4 -- but the number is NOT a scaling number (the ranks
+    # share one GPU, the exchange blocks the host) and the line says so.
+    backend = os.environ.get("TQDNE_BENCH_BACKEND", "nccl").lower()
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"TQDNE_BENCH_BACKEND={backend!r}: expected nccl (RCCL) or gloo (dry run)")
+    share_device = os.environ.get("TQDNE_BENCH_SHARE_DEVICE", "0") == "1"
+    dev_index = 0 if share_device else local_rank
+    if not share_device and world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} GPU(s) visible (dry run on one GPU: TQDNE_BENCH_BACKEND=gloo "
+                         "TQDNE_BENCH_SHARE_DEVICE=1)")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     first_collective_ranks = 1
     # TQDNE_BENCH_FORCE_RCCL=1: at N = 1 too, create the RCCL communicator and run every collective of the N > 1 path (broadcast,
@@ -635,7 +798,7 @@ def main():
         from tqdne_amd.engine import reserve_side_streams
         reserve_side_streams(dev)
     if multi:
-        first_collective_ranks = init_distributed("nccl", rank, world, dev)
+        first_collective_ranks = init_distributed(backend, rank, world, dev)
 
     import __graft_entry__
     if rank == 0:
@@ -692,7 +855,9 @@ def main():
         gpu_parity = dict(denoise=den, loss=lss, sample=smp, **traj)
         del pd
 
-    trainer = DataParallelTrainer(edm, world_size=world, overlap=not args.no_overlap, force_exchange=force_rccl) if do_train else None
+    ema_decay = None if args.no_ema else EMA_DECAY
+    trainer = DataParallelTrainer(edm, world_size=world, overlap=not args.no_overlap, force_exchange=force_rccl,
+                                  ema_decay=ema_decay) if do_train else None
     # replicas: every rank's weights right after the trainer's rank-0 broadcast (compared across ranks in the JSON line)
     cs_start = replica_checksum(edm.unet.parameters())
     sigmas = edm.edm.sampling_sigmas(args.sample_steps).to(dev)
@@ -747,15 +912,14 @@ def main():
     rccl_ranks = 1
     if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce_(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # self-evidence of the collective: a ones tensor summed over RCCL counts the ranks that took part, and every rank's own
         # time per step is gathered (the headline uses the MAX, as the contract asks)
         ones = torch.ones(1, device=dev)
-        dist.all_reduce(ones)
+        all_reduce_(ones)
         rccl_ranks = int(ones.item())
-        allr = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(allr, torch.tensor([1e3 * dt_rank / args.steps], device=dev, dtype=torch.float64))
+        allr = all_gather_(torch.tensor([1e3 * dt_rank / args.steps], device=dev, dtype=torch.float64), world)
         rank_ms = [float(t.item()) for t in allr]
     # replicas after the timed steps: data parallelism is only correct if every rank applied the same update to the same weights
     sums_start = gather_checksums(cs_start, world, multi)
@@ -810,7 +974,7 @@ def main():
             trainer.overlap = True
             train_half(); sync()   # (the bucket sizes / tail words reported below are those of a step with the exchange under the backward)
             tt = torch.tensor([t_after, parts.get("train_ms_synced", 0.0)], device=dev, dtype=torch.float64)   # (both: synced medians)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            all_reduce_(tt, op=dist.ReduceOp.MAX)
             exchange.update(train_ms_exchange_after_backward=float(tt[0]), train_ms_exchange_under_backward=float(tt[1]),
                             hidden_by_overlap_ms=float(tt[0] - tt[1]), buckets_elems=list(trainer.last_bucket_sizes),
                             tail_words=int(getattr(trainer, "last_tail_words", 0)))
@@ -890,14 +1054,14 @@ def main():
         # Per sample and forward every conv / attention core reads its input and writes its output once in fp32 (A), weights W
         # once per call: forward = B*A + W, sample = NFE * forward, train = 3*B*A + 3*W + 7*W (Adam).  A from hooks over the
         # imported reference.
-        A_W = {"paper": (174.7e6, 62.3e6), "tiny": (74.3e6, 14.2e6)}.get(args.config)
+        A_W = {"paper": (ALGO_A["paper"], 62.3e6), "tiny": (ALGO_A["tiny"], 14.2e6)}.get(args.config)
         hbm_step = None
         if A_W and T == 4096:
             A_, W_ = A_W
             if cm is not None:
                 algo_bytes = world * (B * A_ + W_)
-            else:
-                algo_bytes = world * (((3 * B * A_ + 10 * W_) if do_train else 0) + ((nfe * (B * A_ + W_)) if do_sample else 0))
+            else:   # (EMA: + 3 W per train step)
+                algo_bytes = world * step_bytes(A_, W_, B, nfe, train=do_train, sample=do_sample, ema=ema_decay is not None)
             gbps = algo_bytes / (dt / args.steps) / 1e9
             hbm_step = dict(bound="hbm", achieved=gbps, peak=8000.0 * world, unit="GB/s", frac=gbps / (8000.0 * world),
                             algorithmic_bytes_per_step=algo_bytes,
@@ -911,7 +1075,7 @@ def main():
             metric = "waveforms/sec (train step + 18-step EDM sample), 3ch x 4096"
             workload = (f"{args.config} 1-D EDM UNet ({sum(p.numel() for p in edm.unet.parameters())} params), "
                         f"B={B}/GPU, 3x{T}: " + " + ".join(
-                            (["1 train step (dropout 0.1, Adam, cosine LR"
+                            (["1 train step (dropout 0.1, Adam, cosine LR" + (f", EMA {ema_decay}" if ema_decay is not None else "")
                               + (", gradient all-reduce " + ("under" if not args.no_overlap else "after") + " the backward" if world > 1 else "") + ")"]
                              if do_train else [])
                             + ([f"{args.sample_steps}-step Heun sample ({nfe} NFE)"] if do_sample else [])))
@@ -930,6 +1094,9 @@ def main():
                                 "throughput time inside the timed steps); *_ms_synced: median of 5 calls each followed by a synchronisation "
                                 "(the definition train_ms / sample_ms had in rounds 1-3: ~2 ms more per training step); other_configs' parts "
                                 "are synced medians",
+            "collective_backend": ("rccl" if backend == "nccl" else "gloo (DRY RUN of the N > 1 program: collectives over gloo, staged "
+                                   "through the host" + (", all ranks share cuda:0" if share_device else "") + " -- not a scaling number)") if multi else None,
+            "shared_device": share_device,
             "rccl_forced_at_world1": force_rccl,
             "rccl_ranks": rccl_ranks, "rccl_ranks_ok": rccl_ranks == world and first_collective_ranks == world,
             "replicas_equal": replicas["after_broadcast"] and replicas["after_timed_steps"], "replicas": replicas,
@@ -940,6 +1107,11 @@ def main():
             "roofline": roofline,
             "hbm_roofline_whole_step": hbm_step,
         }
+        # the two parts reported separately, whole job (the per-rank halves are timed one after the other on every rank)
+        if "train_ms" in parts:
+            out["train_wf_s"] = world * B / (parts["train_ms"] * 1e-3)
+        if "sample_ms" in parts:
+            out["sample_wf_s"] = world * B / (parts["sample_ms"] * 1e-3)
         if "sample_ms" in parts:
             out["whole_forward_mfma_frac"] = B * flops_fwd * nfe / (parts["sample_ms"] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS
         if "train_ms" in parts:
@@ -948,6 +1120,8 @@ def main():
             out["kernel_classes"] = tables
         if args.mode in ("train", "sample"):
             out["metric"] += " [DEBUG: partial workload, not the headline metric]"
+        if multi and (backend != "nccl" or share_device):
+            out["metric"] += " [DRY RUN: gloo / shared device, not a scaling number]"
         if not args.no_cpu_baseline and world == 1 and cm is None:  # (a reported baseline of the same workload: rank 0 at N = 1 only)
             log("timing the CPU oracle (bounded sample, subprocess) ...")
             import tempfile
@@ -957,7 +1131,7 @@ def main():
                 out["parity"] = parity_block(gpu_parity, ppath, args)
         if (world == 1 and cm is None and args.mode == "step" and args.config == "paper" and B == 64 and T == 4096
                 and not args.no_other_configs):
-            log("other BASELINE configurations (cfg0 tiny B=4, cfg3 latent B=16) ...")
+            log("other BASELINE configurations (cfg0, cfg3 B=16/64, cfg4, 6x4064, B=256) ...")
             out["other_configs"] = other_configs(dev, args)
         print(json.dumps(out), file=result_out, flush=True)
     if multi:

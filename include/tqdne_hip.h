@@ -55,7 +55,8 @@ typedef struct ihipStream_t* hipStream_t;
 #define TQ_WFMT_F16_MX8 1
 /* F16_MX6: as F16_MX8 with e2m3 (fp6) correction operands and per-lane E8M0 block scales (one per 16 channels): 12 instead of 16
  * MFMA passes per 64 channels and corrections that do not clamp; same shapes, same fp16 RANGE of the activation operand (pack
- * mode 3). */
+ * mode 3).  Round 6: additionally 64 | C_out for the k = 5 launches with a TQ_CONV_GN | TQ_CONV_SILU prologue (tq_conv1d_fwd,
+ * tq_conv1d_fwd_skip: the 64-channel ResBlock convs; tile of 64 channels x 128 positions). */
 #define TQ_WFMT_F16_MX6 2
 
 /* EXPERIMENT (only in builds with TQ_BUILD_EXPERIMENTS_BIT; otherwise TqConvDesc.gn_fuse is reserved and must be NULL: a non-NULL
@@ -126,7 +127,7 @@ typedef struct TqConvBwdDesc {
     float dropout_p;
     uint64_t dropout_seed;
     /* ABI 5.  Contraction scheme of the data gradient: TQ_WFMT_BF16X3 (0: fp32 range, packed_w_t from pack mode 1) or
-     * TQ_WFMT_F16_MX6 (packed_w_t from pack mode 5; 64 | C_dy and 128 | C_dx0 + C_dx1): dy is staged times the exact power of two
+     * TQ_WFMT_F16_MX6 (packed_w_t from pack mode 5; 64 | C_dy and 64 | C_dx0 + C_dx1): dy is staged times the exact power of two
      * that brings max|dy| into [2^13, 2^14) -- gradients are far below fp16's normal range otherwise -- and the accumulators are
      * multiplied by its inverse, so the result has the accuracy of the forward scheme (~2^-15 relative) at half the MFMA cycles of
      * bf16x3.  dy_amax: DEVICE pointer to a TQ_AMAX_WORDS block as tq_colsum(..., amax_out) / tq_gn_bwd_apply_colsum fill it for the same

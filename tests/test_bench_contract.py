@@ -80,3 +80,26 @@ def test_bench_runs_the_rccl_path_over_one_rank_when_forced():
     # (round 5: the range-guard pair rides in the last bucket of the step instead of a collective of its own)
     assert ex["tail_words"] == 2
     assert d["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_dry_run_on_one_gpu():
+    """The WHOLE N > 1 program of bench.py on the 1-GPU box (round-5 verdict item 2): ``python bench.py --gpus 2`` self-launches two
+    ranks through torch.distributed.run; with TQDNE_BENCH_BACKEND=gloo + TQDNE_BENCH_SHARE_DEVICE=1 they share cuda:0 and exchange over
+    gloo (host staged).  Per-rank shards and seeds, rank-0 broadcast, bucketed exchange issued from inside the backward sweep, the range
+    flags in the last bucket, max-over-ranks timing, per-rank times, replica checksums, ONE aggregated JSON line on stdout, exit code 0."""
+    d = _run("--gpus", "2", "--config", "tiny", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-tables",
+             env={"TQDNE_BENCH_BACKEND": "gloo", "TQDNE_BENCH_SHARE_DEVICE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["rccl_ranks_ok"] is True and d["scaling"] == "weak"
+    assert "gloo" in d["collective_backend"] and d["shared_device"] is True and "DRY RUN" in d["metric"]
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job aggregate over both ranks
+    assert len(d["rank_ms_per_step"]["all"]) == 2 and d["rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.0001
+    rep = d["replicas"]
+    assert d["replicas_equal"] is True and rep["weights_moved"] is True
+    assert len(rep["checksum_after_broadcast"]) == 2 and len(set(rep["checksum_after_timed_steps"])) == 1
+    ex = d["gradient_exchange"]
+    assert ex["rccl_ranks"] == 2 and ex["overlap"] is True and len(ex["buckets_elems"]) >= 1 and ex["tail_words"] == 2
+    assert ex["hidden_by_overlap_ms"] is not None
+    assert "cpu_baseline" not in d and "other_configs" not in d   # (rank 0 at N = 1 only)
+    assert d["train_wf_s"] > 0 and d["sample_wf_s"] > 0

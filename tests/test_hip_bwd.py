@@ -336,6 +336,38 @@ def test_dgrad_f16_mx6_chain_concat_stats_and_accumulate():
     assert rel_err(torch.cat([ncw(base0), ncw(base1)], 1), u.grad + 1e-5) < TOL
 
 
+@pytest.mark.parametrize("C0,C1,Co,k,T,scale", [(64, 0, 64, 5, 4096, 1e-6), (128, 64, 64, 5, 333, 3e-5), (64, 0, 128, 3, 200, 1.0),
+                                                 (192, 0, 64, 1, 130, 1e-7), (64, 0, 256, 5, 127, 1e-4)])
+def test_dgrad_f16_mx6_64_channel_tile(C0, C1, Co, k, T, scale):
+    """round 6: data gradients whose produced channel count is a multiple of 64 but not of 128 (the 64- and 192-channel inputs of the
+    T = 4096 level) in the fp16 + MX-fp6 scheme on the 64-channel x 128-position tile: plain, and with the GN + SiLU chain, the
+    statistics (two 64-position waves share a slot: LDS hand-over) and the split over two concat sources -- vs fp64"""
+    from tqdne_amd import _lib, ops
+    g = torch.Generator().manual_seed(C0 + C1 + Co + k + T)
+    B, Cin = 2, C0 + C1
+    w = torch.randn(Co, Cin, k, generator=g) / math.sqrt(Cin * k)
+    dy = torch.randn(B, Co, T, generator=g)
+    dy = torch.where(torch.rand(dy.shape, generator=g) < 0.02, dy * 30.0, dy) * scale
+    d = dev()
+    ref = F.conv_transpose1d(dy.double(), w.double(), padding=k // 2)
+    g0, g1, _ = ops.conv1d_bwd_data(cl(dy), w.to(d), split=C0 if C1 else None, wfmt=_lib.TQ_WFMT_F16_MX6)
+    got = torch.cat([ncw(g0), ncw(g1)], 1) if C1 else ncw(g0)
+    e = rel_err(got, ref)
+    print(f"dgrad (64-channel tile) {Co} -> {C0}+{C1} k{k} T={T} at |dy| ~ {scale:g}: {e:.2e}")
+    assert e < TOL
+    if k == 5:
+        x = torch.randn(B, Cin, T, generator=g) + 0.3
+        a, sh = torch.randn(B, Cin, generator=g), torch.randn(B, Cin, generator=g)
+        u = (x * a[:, :, None] + sh[:, :, None]).double().requires_grad_(True)
+        F.conv1d(F.silu(u), w.double(), None, padding=2).backward(dy.double())
+        xs = (cl(x[:, :C0]), cl(x[:, C0:]) if C1 else None)
+        g0, g1, st = ops.conv1d_bwd_data(cl(dy), w.to(d), x0=xs[0], x1=xs[1], gscale=a.to(d), gshift=sh.to(d), silu=True, stats=True,
+                                         split=C0 if C1 else None, wfmt=_lib.TQ_WFMT_F16_MX6)
+        got = torch.cat([ncw(g0), ncw(g1)], 1) if C1 else ncw(g0)
+        assert rel_err(got, u.grad) < TOL
+        assert rel_err(st.cpu(), ref_slot_sums(u.grad.float(), x)) < TOL
+
+
 def test_dgrad_f16_mx6_refuses_unsupported_shapes_and_missing_amax():
     import ctypes as C
     from tqdne_amd import _lib, ops
@@ -346,7 +378,7 @@ def test_dgrad_f16_mx6_refuses_unsupported_shapes_and_missing_amax():
     assert lib.tq_conv1d_bwd_data(C.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), None, None, None) == -1  # no amax
     am = torch.zeros(_lib.TQ_AMAX_WORDS, dtype=torch.int32, device=dev())
     d.dy_amax = am.data_ptr()
-    d.C_dx0 = 64      # 128 does not divide the produced channels
+    d.C_dx0 = 96      # 64 does not divide the produced channels (round 6: 64 | C_dx is served by the 64-channel tile)
     assert lib.tq_conv1d_bwd_data(C.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), None, None, None) == -2
     d.C_dx0, d.C_dy = 128, 32
     assert lib.tq_conv1d_bwd_data(C.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), None, None, None) == -2

@@ -124,6 +124,51 @@ def test_conv_pointwise_input_stationary(cin0, cin1, cout, T, gn):
         assert rel_err(st.cpu(), ref_stats(ref)) < TOL, wfmt
 
 
+@pytest.mark.parametrize("C0,C1,T,p,res,skip", [(64, 0, 4096, 0.0, True, None), (128, 64, 333, 0.0, False, None), (64, 0, 200, 0.3, True, None),
+                                                 (64, 0, 700, 0.0, False, (128, 64)), (64, 0, 129, 0.3, False, (128, 0)), (128, 0, 64, 0.0, False, None)])
+def test_conv_64_channel_mx6_tile(C0, C1, T, p, res, skip):
+    """round 6: the 64-channel ResBlock convs (k = 5, GN + SiLU [+ dropout] prologue, emb, residual or fused 1x1 skip conv) in the
+    fp16 + MX-fp6 scheme on the 64-channel x 128-position tile (2 x 2 waves of 32 x 64; the two position halves of a workgroup share one
+    statistics slot through LDS) -- output and statistics vs fp32 PyTorch; with dropout vs the bf16x3 launch of the same seed."""
+    from tqdne_amd import _lib, ops
+    g = torch.Generator().manual_seed(C0 + C1 + T + int(100 * p))
+    B, Co, Cin = 2, 64, C0 + C1
+    x0 = torch.randn(B, C0, T, generator=g) * 1.5
+    x1 = torch.randn(B, C1, T, generator=g) + 0.5 if C1 else None
+    a, sh = torch.rand(B, Cin, generator=g) + 0.5, torch.randn(B, Cin, generator=g)
+    w = torch.randn(Co, Cin, 5, generator=g) / math.sqrt(5 * Cin)
+    b, emb = torch.randn(Co, generator=g), torch.randn(B, Co, generator=g)
+    r = torch.randn(B, Co, T, generator=g) if res else None
+    d = dev()
+    srcs = [C0, C1] + (list(skip) if skip else [])
+    assert _lib.forward_wfmt(Co, srcs, fused_skip=skip is not None, k5_act=True) == _lib.TQ_WFMT_F16_MX6 or not _lib.MX6_C64 or os.environ.get("TQDNE_CONV_SCHEME")
+    kw = dict(x1=cl(x1) if C1 else None, gscale=a.to(d), gshift=sh.to(d), silu=True, emb=emb.to(d), dropout_p=p, dropout_seed=13, dropout_site=5)
+    sk = None
+    if skip:
+        s0 = torch.randn(B, skip[0], T, generator=g)
+        s1 = torch.randn(B, skip[1], T, generator=g) if skip[1] else None
+        wsk = torch.randn(Co, sum(skip), 1, generator=g) / math.sqrt(sum(skip))
+        bsk = torch.randn(Co, generator=g)
+        sk = (cl(s0), cl(s1) if skip[1] else None, wsk.to(d), bsk.to(d))
+        kw["skip"] = sk
+    else:
+        kw["residual"] = cl(r) if res else None
+    y, st = ops.conv1d(cl(x0), w.to(d), b.to(d), wfmt=_lib.TQ_WFMT_F16_MX6, **kw)
+    if p == 0.0:
+        xin = F.silu((torch.cat([x0, x1], 1) if C1 else x0) * a[:, :, None] + sh[:, :, None])
+        ref = F.conv1d(xin, w, b, padding=2) + emb[:, :, None]
+        if res:
+            ref = ref + r
+        if skip:
+            ref = ref + F.conv1d(torch.cat([s0, s1], 1) if skip[1] else s0, wsk, bsk)
+    else:   # the mask is the kernel's own counter hash: same seed / site in the three-product scheme
+        ref = ncw(ops.conv1d(cl(x0), w.to(d), b.to(d), wfmt=_lib.TQ_WFMT_BF16X3, **kw)[0])
+    e = rel_err(ncw(y), ref)
+    print(f"64-channel f16+mx6 tile {C0}+{C1} -> 64, T={T}, p={p}, skip={skip}: {e:.2e}")
+    assert e < TOL
+    assert rel_err(st.cpu(), ref_stats(ref)) < TOL
+
+
 def test_conv_fused_everything():
     """GN scale/shift + SiLU + two concat sources + emb + residual, ragged T."""
     from tqdne_amd import ops

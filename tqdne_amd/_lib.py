@@ -44,13 +44,18 @@ def attn_v_format() -> int:
     return TQ_KV_V_F16
 
 
-def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False) -> int:
+MX6_C64 = os.environ.get("TQDNE_CONV_MX6_C64", "1") != "0"   # A/B switch of round 6's 64-channel fp16 + MX-fp6 tile (0: bf16x3 as before)
+
+
+def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False, k5_act: bool = False) -> int:
     """Contraction scheme of a forward conv launch (include/tqdne_hip.h, TQ_WFMT_*): fp16 + block-scaled corrections where the kernel
     is built for the shape (stride 1 incl. the nearest-upsampling convs, 128 | C_out, 64 | every source's channels incl. a fused skip
-    conv's), bf16x3 elsewhere.  TQDNE_CONV_SCHEME: f16mx6 (default: e2m3 corrections with per-lane block scales), f16mx8 (round 1's
-    e4m3 corrections with uniform scales), bf16x3 (the fp32-range three-product scheme everywhere)."""
+    conv's; round 6: also 64 | C_out for the ResBlock convs -- ``k5_act``: k = 5, GN + SiLU prologue, f16mx6 only), bf16x3 elsewhere.
+    TQDNE_CONV_SCHEME: f16mx6 (default: e2m3 corrections with per-lane block scales), f16mx8 (round 1's e4m3 corrections with uniform
+    scales), bf16x3 (the fp32-range three-product scheme everywhere)."""
     v = requested_scheme()
-    ok = stride == 1 and C_out % 128 == 0 and all(c % 64 == 0 for c in sources if c)
+    co_ok = C_out % 128 == 0 or (C_out % 64 == 0 and k5_act and not upsample and v == "f16mx6" and MX6_C64)
+    ok = stride == 1 and co_ok and all(c % 64 == 0 for c in sources if c)
     if fused_skip:
         ok = ok and os.environ.get("TQDNE_FUSED_SKIP_MX8", "1") != "0"
     if not ok or v == "bf16x3":

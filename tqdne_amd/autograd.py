@@ -149,17 +149,22 @@ def edm_loss(module, sample, eps, unit_noise, cond, cond_sample=None):
 
 class _DenoiseFn(th.autograd.Function):
     """D(x; sigma) = c_skip x + c_out F(c_in x; c_noise) (reference edm.py:105-113) as an ordinary differentiable call: the HIP
-    forward in training mode (dropout active), and in backward the hand-written HIP backward seeded with the incoming gradient.
-    Differentiable with respect to the UNet parameters (what training code needs); not with respect to the input."""
+    forward keeping what a backward reads (dropout in training mode only), and in backward the hand-written HIP backward seeded with the incoming gradient.
+    Differentiable with respect to the UNet parameters (what training code needs) and, when ``sample.requires_grad``, the input
+    sample: d D / d x = c_skip + c_out (dF / d x_in) c_in, the middle factor being the stem conv's data gradient."""
 
     @staticmethod
     def forward(ctx, module, sample, sigma, cond, cond_sample, *params):
-        seed = rng.next_dropout_seed()
-        out = module._denoise_static(sample, sigma, 1, cond, train=True, dropout_seed=seed, cond_sample=cond_sample)
+        train = module.training
+        out = module._denoise_static(sample, sigma, 1, cond, train=train, dropout_seed=rng.next_dropout_seed() if train else 0,
+                                     cond_sample=cond_sample)
         ctx.module, ctx.shape, ctx.dev, ctx.lane = module, tuple(sample.shape), sample.device, module._lane
         ctx.concat = cond_sample is not None
         ctx.eng = module.unet._engine(sample.shape[0], sample.shape[2], sample.device, module._lane)
         ctx.fwd_id = ctx.eng._fwd_count
+        ctx.want_dx = bool(sample.requires_grad)
+        # (c_in / c_skip of THIS call: the module's scalar buffer is overwritten by the next call of the shape)
+        ctx.in_skip = module._scalars(sample.shape[0], sample.device)[[0, 2]].clone() if ctx.want_dx else None
         return out.clone()
 
     @staticmethod
@@ -171,13 +176,55 @@ class _DenoiseFn(th.autograd.Function):
         B, _, T = ctx.shape
         sc = module._scalars(B, ctx.dev)
         one = th.ones((), device=ctx.dev)
-        grads = eng.backward(gout.contiguous().float(), one, c_out=sc[1], in_scale=None if ctx.concat else sc[0])
-        return (None, None, None, None, None) + tuple(grads)
+        gout = gout.contiguous().float()
+        grads = eng.backward(gout, one, c_out=sc[1], in_scale=None if ctx.concat else sc[0], want_dx=ctx.want_dx)
+        dx = None
+        if ctx.want_dx:
+            c_in, c_skip = ctx.in_skip[0], ctx.in_skip[1]
+            dx = eng._bwd.last_dx   # (already times c_in where the stem load applied it; the concatenated input was pre-scaled)
+            if ctx.concat:
+                dx = dx[:, :ctx.shape[1]] * c_in[:, None, None]
+            dx = dx + c_skip[:, None, None] * gout
+        return (None, dx, None, None, None) + tuple(grads)
 
 
 def denoise_with_grad(module, sample, sigma, cond, cond_sample=None):
     """``LightningEDM.forward`` under autograd (train mode, grad enabled): see _DenoiseFn."""
-    if sample.requires_grad:
-        raise NotImplementedError("the HIP backward produces parameter gradients only; detach the input sample")
+    for name, t in (("sigma", sigma), ("cond", cond), ("cond_sample", cond_sample)):
+        if t is not None and t.requires_grad:
+            raise NotImplementedError(f"the HIP backward has no gradient with respect to {name}; detach it")
     params = list(module.unet.parameters())
     return _DenoiseFn.apply(module, sample, sigma, cond, cond_sample, *params)
+
+
+class _UNetFn(th.autograd.Function):
+    """``UNetModel.forward`` (reference unet.py:360-398) as an ordinary differentiable call: HIP forward (dropout in training mode
+    only) keeping what a backward reads, HIP backward seeded with the incoming gradient.  Gradients: every parameter, and the input
+    ``x`` when it requires one (the stem conv's data gradient); ``timesteps`` / ``cond`` have none (no reference caller differentiates
+    them) and raise when they ask for one."""
+
+    @staticmethod
+    def forward(ctx, model, x, timesteps, cond, *params):
+        train = model.training
+        eng = model._engine(x.shape[0], x.shape[2], x.device)
+        y = eng.forward(x, timesteps, cond, train=train, dropout_seed=rng.next_dropout_seed() if train else 0)
+        ctx.eng, ctx.fwd_id, ctx.want_dx = eng, eng._fwd_count, bool(x.requires_grad)
+        return y.clone()
+
+    @staticmethod
+    def backward(ctx, gy):
+        eng = ctx.eng
+        if eng._fwd_count != ctx.fwd_id:
+            raise RuntimeError("another forward of the same shape ran between this forward and its backward: the execution plan's "
+                               "static buffers no longer hold its activations (call backward before the next forward)")
+        one = th.ones((), device=gy.device)
+        grads = eng.backward(gy.contiguous().float(), one, want_dx=ctx.want_dx)
+        return (None, eng._bwd.last_dx if ctx.want_dx else None, None, None) + tuple(grads)
+
+
+def unet_with_grad(model, x, timesteps, cond):
+    """``UNetModel.forward`` with grad enabled: see _UNetFn."""
+    for name, t in (("timesteps", timesteps), ("cond", cond)):
+        if t is not None and t.requires_grad:
+            raise NotImplementedError(f"the HIP backward has no gradient with respect to {name}; detach it")
+    return _UNetFn.apply(model, x, timesteps, cond, *model.parameters())

@@ -126,7 +126,7 @@ struct Cfg {
 // tiles: no per-chunk barrier / load round trip (a 1x1 chunk has 1/5 of the MFMA work to hide one under) and no re-staging of
 // the same rows by 3 channel-tile workgroups (qkv).
 template <int KT, int STRIDE, int UPS, int WM, int WN, int EPI, int ACT, bool FUSE, int SCH, bool PW = false, int TBW = 8, int NCB = 2>
-__global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) void conv1d_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2 && SCH == 0) ? 3 : 2)) void conv1d_mfma_kernel(const ConvArgs p) {
     static_assert(SCH == 0 || STRIDE == 1, "the fp16-range schemes serve stride-1 launches");
     static_assert(EPI != 1 || SCH == 0 || (SCH == 2 && ACT == 0 && !FUSE && !PW), "data gradients: bf16x3, or fp16 + MX-fp6 on a dy scaled into the fp16 range");
     // NCB == 4 (round 4): 256 channels x 128 positions as 4 x 2 waves of 64 channels x 64 positions -- every activation fragment read
@@ -134,11 +134,16 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2) ? 3 : 2)) voi
     // cost a quarter of the matrix rate; 16 reads + 16 weight loads per 48 MFMAs run 13 % faster than 32 + 8)
     static_assert(NCB == 2 || (NCB == 4 && TBW == 4 && WM == 4 && WN == 2 && SCH == 2 && KT > 1 && STRIDE == 1 && UPS == 0 && EPI == 0 && !FUSE && !PW),
                   "64-channel waves: the fp16 + MX-fp6 forward tile of 256 x 128");
-    static_assert(TBW == 8 || (TBW == 4 && NCB == 4) || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW) ||
+    // C64 (round 6): the fp16 + MX-fp6 tile of the 64-channel layers -- 64 channels x 128 positions as 2 x 2 waves of 32 channels x 64
+    // positions, two workgroups per CU (the 64-channel ResBlock convs at T = 4096 and the data gradients whose input-channel count is a
+    // multiple of 64 but not of 128 ran in bf16x3: twice the matrix work)
+    constexpr bool C64 = TBW == 4 && NCB == 2 && SCH == 2 && WM == 2 && WN == 2;
+    static_assert(!C64 || (STRIDE == 1 && UPS == 0 && !PW && EPI != 2), "64-channel fp16 + MX-fp6 tile: stride-1 forward and data-gradient launches");
+    static_assert(TBW == 8 || (TBW == 4 && NCB == 4) || C64 || (TBW == 4 && SCH == 0 && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 2 && !PW) ||
                   (TBW == 2 && (SCH == 0 || (SCH == 2 && WM == 4)) && STRIDE == 1 && UPS == 0 && EPI == 0 && WN == 1 && !PW),
                   "slim tile: bf16x3 forward, 2 x 2 waves; small tile (32 positions per workgroup): stride-1 forward, one wave column");
     static_assert(!PW || (KT == 1 && STRIDE == 1 && UPS == 0 && SCH >= 1 && !FUSE && WN == 1 && EPI != 1), "PW: 1x1, fp16-range schemes");
-    static_assert(SCH != 2 || WN == 1 || NCB == 4 || (WN == 2 && WM == 4 && TBW == 8 && STRIDE == 1 && UPS == 0 && EPI == 0 && !PW),
+    static_assert(SCH != 2 || WN == 1 || NCB == 4 || C64 || (WN == 2 && WM == 4 && TBW == 8 && STRIDE == 1 && UPS == 0 && EPI == 0 && !PW),
                   "scheme 2 tiles are 128 positions wide (experiment: 128 channels x 256 positions, 8 waves)");
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW, NCB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1205,7 +1210,7 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
         // data gradient: acc = d loss / d xhat.  Chain through dropout, SiLU and the folded GroupNorm scale of the
         // FORWARD conv's prologue:  g = acc * mask/(1-p) * silu'(u), u = a*x + s  (the GN statistics' own dependence
         // on x is handled by tq_gn_bwd_finalize / tq_gn_bwd_apply from the partial sums (sum g, sum g*x) emitted here)
-        const int slot = (t0 >> 7) + wn;
+        const int slot = (t0 >> 7) + (TBW == 8 ? wn : 0);   // (TBW == 4: the workgroup's 128 positions are ONE slot, see below)
         const int Ctot = p.C_out;
         // as in the forward epilogue: t-block outer, channel block inner, so the two halves of a 128-byte line are stored together
         float* dst[2]; const float* fx[2]; int cs[2], cc[2];
@@ -1273,10 +1278,37 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                         s2[cbk][j] += __shfl_xor(s2[cbk][j], o);
                     }
                 }
-                if ((lane & 15) == 0 && slot < p.nslots) {
-                    float* st = p.stats + (((size_t)b * p.nslots + slot) * Ctot + co) * 2;
-                    *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
-                    *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
+                if constexpr (TBW == 8) {
+                    if ((lane & 15) == 0 && slot < p.nslots) {
+                        float* st = p.stats + (((size_t)b * p.nslots + slot) * Ctot + co) * 2;
+                        *reinterpret_cast<float4*>(st) = make_float4(s1[cbk][0], s2[cbk][0], s1[cbk][1], s2[cbk][1]);
+                        *reinterpret_cast<float4*>(st + 4) = make_float4(s1[cbk][2], s2[cbk][2], s1[cbk][3], s2[cbk][3]);
+                    }
+                }
+            }
+            if constexpr (TBW == 4) {
+                // 64-position waves: the two waves of a channel half cover the two halves of ONE 128-position slot; the second hands its
+                // sums over through LDS (the staging buffers are idle once every wave has left its MFMA stream: first barrier)
+                __syncthreads();
+                float* red = reinterpret_cast<float*>(lds) + (wm * 4 + (lane >> 4)) * 16;   // [wm][kq][cbk][j][2]
+                if (wn == 1 && (lane & 15) == 0) {
+#pragma unroll
+                    for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { red[(cbk * 4 + j) * 2] = s1[cbk][j]; red[(cbk * 4 + j) * 2 + 1] = s2[cbk][j]; }
+                }
+                __syncthreads();
+                if (wn == 0 && (lane & 15) == 0 && slot < p.nslots) {
+#pragma unroll
+                    for (int cbk = 0; cbk < 2; ++cbk) {
+                        const int co = co_wave + cbk * 16 + 4 * (lane >> 4);
+                        float a1[4], a2[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { a1[j] = s1[cbk][j] + red[(cbk * 4 + j) * 2]; a2[j] = s2[cbk][j] + red[(cbk * 4 + j) * 2 + 1]; }
+                        float* st = p.stats + (((size_t)b * p.nslots + slot) * Ctot + co) * 2;
+                        *reinterpret_cast<float4*>(st) = make_float4(a1[0], a2[0], a1[1], a2[1]);
+                        *reinterpret_cast<float4*>(st + 4) = make_float4(a1[2], a2[2], a1[3], a2[3]);
+                    }
                 }
             }
         }
@@ -1358,6 +1390,7 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
             if (a.C0 % 64 || a.C1) return TQ_ERR_SHAPE;
             if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
             if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 2>(a, s);
+            if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT, FUSE, 2, false, 4>(a, s);   // (round 6: 64 / 192 input channels)
             return TQ_ERR_SHAPE;
         }
         if constexpr (STRIDE == 1 && EPI != 1) {
@@ -1394,6 +1427,9 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
             }
 #endif
             if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 2>(a, s);
+            if constexpr (KT == 5 && UPS == 0 && EPI == 0 && ACT >= 2) {   // round 6: the 64-channel ResBlock convs (with or without the fused skip conv)
+                if (a.C_out % 64 == 0 && !(a.flags & TQ_CONV_POLY2)) return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT, FUSE, 2, false, 4>(a, s);
+            }
         }
         return TQ_ERR_SHAPE;
     }

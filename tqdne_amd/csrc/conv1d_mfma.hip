@@ -191,7 +191,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.t_tile = 0;
     if (d->wfmt == TQ_WFMT_F16_MX6) {
         if (!d->dy_amax) return TQ_ERR_ARG;
-        if (d->C_dy % 64 || a.C_out % 128) return TQ_ERR_SHAPE;
+        if (d->C_dy % 64 || a.C_out % 64) return TQ_ERR_SHAPE;
         a.wfmt = TQ_WFMT_F16_MX6;
         a.in_amax = d->dy_amax;
     } else if (d->wfmt != TQ_WFMT_BF16X3) {

@@ -168,7 +168,9 @@ class LightningEDM(LightningModule):
         )
         if cond_sample is not None:
             cond_sample = cond_sample.contiguous()
-        if self.training and th.is_grad_enabled():
+        if th.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.unet.parameters())):
+            # an ordinary differentiable call, as in the reference: parameter gradients, and d / d sample when the sample asks for it
+            # (dropout only in training mode)
             from .autograd import denoise_with_grad
             return denoise_with_grad(self, sample, sigma, cond, cond_sample)
         y = self._denoise_static(sample, sigma, 1, cond, cond_sample=cond_sample, infer=True).clone()

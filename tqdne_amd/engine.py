@@ -440,10 +440,13 @@ class UNetEngine:
             T_out = 2 * T_in if upsample else T_in
             pad = site.K // 2
         srcs_c = [s0.C, (s1.C if s1 else 0)] + ([a.C for a in skip[0]] if skip is not None else [])
-        wfmt = _lib.forward_wfmt(site.C_out, srcs_c, stride, upsample, fused_skip=skip is not None) if launch else 0
+        k5_act = site.K == 5 and gn is not None and silu and stride == 1 and not upsample and qkv_planes is None
+        wfmt = _lib.forward_wfmt(site.C_out, srcs_c, stride, upsample, fused_skip=skip is not None, k5_act=k5_act) if launch else 0
         # the small tile where it is built (see SMALL_TILE_B): the ResBlock convs of a small-batch plan
-        small = (launch and (self.B <= SMALL_TILE_B or (self.solo and self.B * ((T_out + 127) // 128) <= SMALL_TILE_WGS)) and stride == 1 and not upsample and site.K == 5 and gn is not None and silu
-                 and qkv_planes is None and wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX6) and not GN_FUSE)
+        small = (launch and (self.B <= SMALL_TILE_B or (self.solo and self.B * ((T_out + 127) // 128) <= SMALL_TILE_WGS)) and k5_act
+                 and wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX6) and not GN_FUSE)
+        if small and wfmt == _lib.TQ_WFMT_F16_MX6 and site.C_out % 128:
+            wfmt = _lib.TQ_WFMT_BF16X3   # (the small tile's fp16 + MX-fp6 form is the 128-channel one)
         if launch and ckpt_tag is not None and self.ckpt:
             out = self._ckpt_act(ckpt_tag, site.C_out, T_out, stats, slot=32 if small else STAT_SLOT)
         else:
@@ -1024,12 +1027,14 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, dpred: torch.Tensor, gloss: torch.Tensor, c_out=None, in_scale=None, clone: bool = True, on_bucket=None,
-                 bucket_elems: int = 4 << 20, tail_fill=None):
+                 bucket_elems: int = 4 << 20, tail_fill=None, want_dx: bool = False):
         """Gradients of every UNet parameter for d loss / d pred = gloss * dpred, for the last train-mode forward.
-        Returns a list aligned with ``model.parameters()`` (None for frozen parameters).  ``on_bucket``: see BackwardPlan.run."""
+        Returns a list aligned with ``model.parameters()`` (None for frozen parameters).  ``on_bucket``: see BackwardPlan.run.
+        ``want_dx``: the gradient with respect to the forward's input as well (``self._bwd.last_dx``)."""
         if self._bwd is None:
             self._bwd = BackwardPlan(self)
-        return self._bwd.run(dpred, gloss, clone=clone, on_bucket=on_bucket, bucket_elems=bucket_elems, tail_fill=tail_fill)
+        return self._bwd.run(dpred, gloss, clone=clone, on_bucket=on_bucket, bucket_elems=bucket_elems, tail_fill=tail_fill,
+                             want_dx=want_dx)
 
 
 class SeqEngine(UNetEngine):

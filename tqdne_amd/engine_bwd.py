@@ -49,6 +49,7 @@ BWD_STREAMS = int(__import__("os").environ.get("TQDNE_BWD_STREAMS", "2"))
 # TQDNE_DGRAD_SCHEME=bf16x3 keeps round 3's three-product scheme everywhere.
 FUSE_APPLY_COLSUM = __import__("os").environ.get("TQDNE_FUSE_APPLY_COLSUM", "1") != "0"
 DGRAD_SCHEME = __import__("os").environ.get("TQDNE_DGRAD_SCHEME", "f16mx6").lower()
+DGRAD_MX6_C64 = __import__("os").environ.get("TQDNE_DGRAD_MX6_C64", "1") != "0"
 N_AMAX = 160   # blocks for max|dy| (one per gradient tensor that feeds a data gradient), kept in the tail of the flat buffer
 
 
@@ -274,8 +275,10 @@ class BackwardPlan:
         amax = self.amax_ptr((amax_of if amax_of is not None else dy).data_ptr(), create=False)
         # (and only where the forward scheme requested for the model is the same one: TQDNE_CONV_SCHEME=bf16x3 / f16mx8 means
         # fp32-range three-product data gradients too)
+        # (round 6: 64 | C_in through the 64-channel tile -- the 64- and 192-channel inputs of the T = 4096 level; TQDNE_DGRAD_MX6_C64=0: as before)
+        cin_ok = site.C_in % 128 == 0 or (site.C_in % 64 == 0 and DGRAD_MX6_C64)
         mx6 = (DGRAD_SCHEME == "f16mx6" and _lib.requested_scheme() == "f16mx6"
-               and amax is not None and site.C_out % 64 == 0 and site.C_in % 128 == 0
+               and amax is not None and site.C_out % 64 == 0 and cin_ok
                and getattr(self.e, "scheme", "auto") == "auto" and getattr(self.m, "_conv_scheme", "auto") == "auto")
         want = 5 if mx6 else 1
         if site.packed_t is None:
@@ -510,9 +513,37 @@ class BackwardPlan:
         x.gw = True
 
     # ------------------------------------------------------------------ run
+    def _input_gradient(self, last, stream):
+        """d loss / d x (B, C_in, T) of the last forward: the stem conv's data gradient (reference: plain autograd through
+        ``input_blocks[0]``, unet.py:233,389-391), as a generic transposed conv of d stem_out into a 32-channel channels-last buffer
+        (the packer zero-fills the weight rows of the channels the model does not have), times the per-sample input scale where
+        the stem load applied one (EDM's c_in).  Built on first use: training never asks for it."""
+        e, m, lib = self.e, self.m, self.lib
+        stem, so = m.input_blocks[0][0], e.stem_out
+        cin, K = stem.in_channels, stem.kernel_size[0]
+        if cin > 32:
+            raise NotImplementedError("input gradient for more than 32 input channels")
+        if getattr(self, "dx_op", None) is None:
+            self.dx_btc = self._empty(self.B, so.T, 32)
+            self.stem_packed_t = torch.empty(lib.tq_conv_weight_pack_bytes(stem.out_channels, cin, K, 1), dtype=torch.uint8, device=self.dev)
+            bd = TqConvBwdDesc()
+            bd.B, bd.T, bd.C_dy, bd.C_dx0, bd.C_dx1, bd.ktaps, bd.flags = self.B, so.T, stem.out_channels, 32, 0, K, 0
+            self._keep.append(bd)
+            self.dx_op = [lib.tq_conv1d_bwd_data, [C.byref(bd), _p(so.grad), _p(self.stem_packed_t), None, None, None, None,
+                                                   _p(self.dx_btc), None, None], "dgrad:stem"]
+        check(lib.tq_pack_conv_weight(stem.weight.data_ptr(), stem.out_channels, cin, K, 1, self.stem_packed_t.data_ptr(), stream),
+              "pack^T stem")
+        fn, args, what = self.dx_op
+        check(fn(*args, stream), what)
+        dx = self.dx_btc[:, :, :cin].permute(0, 2, 1).contiguous()
+        if last["in_scale"] is not None:
+            dx.mul_(last["in_scale"][:, None, None])
+        return dx
+
     def run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True, on_bucket=None, bucket_elems: int = 4 << 20,
-            tail_fill=None):
-        """``on_bucket(flat_slice)``: called from inside the sweep, right after the launch that finalises the last gradient of
+            tail_fill=None, want_dx: bool = False):
+        """``want_dx``: also form d loss / d x of the forward's input; left in ``self.last_dx`` (B, C_in, T).
+        ``on_bucket(flat_slice)``: called from inside the sweep, right after the launch that finalises the last gradient of
         each bucket of >= ``bucket_elems`` floats has been enqueued (buckets = contiguous slices of the flat buffer in the
         order the sweep completes them; every rank cuts them identically).  The data-parallel trainer starts the slice's
         all-reduce there, so the exchange runs under the rest of the backward.
@@ -621,6 +652,7 @@ class BackwardPlan:
         self._embedding_backward(last)
         for lo, hi in late:
             on_bucket(self.flat[lo:hi])
+        self.last_dx = self._input_gradient(last, stream) if want_dx else None
         out = self.flat.clone() if clone else self.flat  # clone: autograd may keep the returned tensors alive
         res = []
         for p_ in self.param_order:

@@ -68,7 +68,8 @@ def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=Fal
     d.dropout_site, d.dropout_p, d.dropout_seed = dropout_site, dropout_p, dropout_seed
     if wfmt is None:
         srcs = [C0, C1] + ([skip[0].shape[2], 0 if skip[1] is None else skip[1].shape[2]] if skip is not None else [])
-        wfmt = _lib.forward_wfmt(C_out, srcs, stride, upsample, fused_skip=skip is not None)
+        wfmt = _lib.forward_wfmt(C_out, srcs, stride, upsample, fused_skip=skip is not None,
+                                 k5_act=K == 5 and gscale is not None and silu and stride == 1 and not upsample and t_tile == 0)
     d.wfmt = wfmt
     pmode = _lib.PACK_MODE[wfmt]
     wp = pack_conv_weight(weight, pmode)

@@ -63,6 +63,13 @@ def shard_batch(batch: dict, rank: int, world_size: int) -> dict:
     return out
 
 
+class _Done:
+    """handle of a collective that has already completed (host-staged gloo exchange)"""
+
+    def wait(self):
+        return True
+
+
 class DataParallelTrainer:
     def __init__(self, module, world_size: int = 1, bucket_bytes: int = 16 << 20, ema_decay=None, fused_optimizer=None,
                  overlap: bool = True, process_group=None, force_exchange: bool = False):
@@ -115,7 +122,12 @@ class DataParallelTrainer:
                 by_dtype.setdefault(p.dtype, []).append(p)
             for ps in by_dtype.values():
                 flat = torch.cat([p.detach().reshape(-1) for p in ps])
-                dist.broadcast(flat, src=0, group=self.group)
+                if self._host_staged(flat):
+                    h = flat.cpu()
+                    dist.broadcast(h, src=0, group=self.group)
+                    flat.copy_(h)
+                else:
+                    dist.broadcast(flat, src=0, group=self.group)
                 o = 0
                 views = []
                 for p in ps:
@@ -123,9 +135,19 @@ class DataParallelTrainer:
                     o += p.numel()
                 torch._foreach_copy_(ps, views)
 
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        """device tensors over the gloo backend (the dry-run configuration of bench.py / the 1-GPU tests: ranks sharing a device) go
+        through host memory: the product backend for GPUs is "nccl" = RCCL, which takes device tensors as they are"""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def _allreduce_async(self, t: torch.Tensor):
         """start the sum all-reduce of ``t`` (in place); returns a handle with ``wait()``.  NCCL/RCCL: the collective is
         enqueued on the process group's own stream behind everything the current stream holds so far."""
+        if self._host_staged(t):
+            h = t.cpu()   # (synchronises: the slice is final on the current stream at this point)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return _Done()
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True, group=self.group)
 
     def train_step(self, batch):

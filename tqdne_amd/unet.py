@@ -220,11 +220,15 @@ class UNetModel(nn.Module):
             from . import family2d
             return family2d.unet_forward(self, x, timesteps, cond)
         engine.require_device(x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # an ordinary differentiable module, like the reference's (unet.py:360-398): ``loss = f(unet(x, t, c)); loss.backward()``
+            # runs the HIP backward (parameter gradients; d / d x when x asks for it)
+            from .autograd import unet_with_grad
+            return unet_with_grad(self, x, timesteps, cond)
         eng = self._engine(x.shape[0], x.shape[2], x.device)
-        train = self.training and torch.is_grad_enabled()
-        y = eng.forward(x, timesteps, cond, train=train).clone()
-        if not train and eng.check_range():   # activations near the fp16 range: the plan is on bf16x3 now, repeat
-            y = eng.forward(x, timesteps, cond, train=train).clone()
+        y = eng.forward(x, timesteps, cond, train=False, infer=True).clone()
+        if eng.check_range():   # activations near the fp16 range: the plan is on bf16x3 now, repeat
+            y = eng.forward(x, timesteps, cond, train=False, infer=True).clone()
         return y
 
     def _apply(self, fn, *a, **k):  # parameters moved (.to / .cuda): compiled plans hold stale pointers
