@@ -25,7 +25,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define TQ_ABI_VERSION 6
+#define TQ_ABI_VERSION 7
 
 #define TQ_ERR_ARG (-1)   /* null / inconsistent pointer arguments */
 #define TQ_ERR_SHAPE (-2) /* unsupported shape */
@@ -289,6 +289,11 @@ int tq_colsum(const float* dy, int B, int T, int C, float* out_bc, int bc_stride
  * dx[b,t,:] (+)= d_up[b,2t,:] + d_up[b,2t+1,:] */
 int tq_zero_stuff(const float* dy, float* out, int B, int T_out, int T_in, int C, hipStream_t stream);
 int tq_pair_sum(const float* d_up, float* dx, int B, int T, int C, int accumulate, hipStream_t stream);
+/* ABI 7.  Upsample (blocks.py:56-66) trained in its two-phase k = 3 form (TQ_CONV_POLY2 forward; data gradient = tq_conv1d_bwd_data with
+ * ktaps 3 and C_dy = 2 C_out on the output gradient (B, 2T, C_out) read as (B, T, 2 C_out); weight gradient = tq_conv1d_bwd_weight of that
+ * k = 3 conv): folds dw2 (2 C_out, C_in, 3) = [d even-phase taps | d odd-phase taps] back onto the conv's five taps, dw (C_out, C_in, 5)
+ * (overwritten): dw0 = dA0 + dB0, dw1 = dA0 + dB1, dw2 = dA1 + dB1, dw3 = dA1 + dB2, dw4 = dA2 + dB2. */
+int tq_upsample_poly_wgrad_fold(const float* dw2, float* dw, int C_out, int C_in, hipStream_t stream);
 /* stem conv weight gradient (atomically added into zeroed dw (C_out, C_in, K)) */
 int tq_stem_conv_bwd_weight(const float* dy, const float* x_nct, const float* in_scale, float* dw, int B, int C_in, int T,
                             int C_out, int ktaps, hipStream_t stream);

@@ -131,6 +131,36 @@ def test_upsample_backward(C, T, k):
     assert rel_err(dw.cpu(), w.grad) < TOL
 
 
+@pytest.mark.parametrize("Cin,C,T", [(128, 128, 64), (256, 256, 200), (256, 128, 127), (64, 64, 333)])
+def test_upsample_backward_in_the_two_phase_form(Cin, C, T):
+    """round 6: Upsample (nearest x2 + conv k = 5) differentiated as its two-phase k = 3 conv -- the output gradient (B, 2T, C) read as
+    (B, T, 2C): data gradient = k = 3 data gradient with the two-phase weights (both schemes), weight gradient = k = 3 weight gradient
+    folded onto the five taps (tq_upsample_poly_wgrad_fold) -- vs autograd through F.interpolate + conv1d"""
+    import ctypes as Ct
+    from tqdne_amd import _lib, ops
+    g = torch.Generator().manual_seed(Cin + C + T)
+    x = torch.randn(2, Cin, T, generator=g, requires_grad=True)
+    w = (torch.randn(C, Cin, 5, generator=g) / math.sqrt(5 * Cin)).requires_grad_(True)
+    y = F.conv1d(F.interpolate(x, scale_factor=2, mode="nearest"), w, None, padding=2)
+    dy = torch.randn(y.shape, generator=g) * 1e-4
+    y.backward(dy)
+    wd = w.detach()
+    w2 = torch.empty(2 * C, Cin, 3)   # (engine.UNetEngine.repack: even outputs (w0+w1, w2+w3, w4), odd ones (w0, w1+w2, w3+w4))
+    w2[:C, :, 0], w2[:C, :, 1], w2[:C, :, 2] = wd[:, :, 0] + wd[:, :, 1], wd[:, :, 2] + wd[:, :, 3], wd[:, :, 4]
+    w2[C:, :, 0], w2[C:, :, 1], w2[C:, :, 2] = wd[:, :, 0], wd[:, :, 1] + wd[:, :, 2], wd[:, :, 3] + wd[:, :, 4]
+    d = dev()
+    dyv = cl(dy).reshape(2, T, 2 * C)     # (B, 2T, C) channels-last IS (B, T, 2C): row m = [row 2m | row 2m + 1]
+    for wfmt in (_lib.TQ_WFMT_BF16X3, _lib.TQ_WFMT_F16_MX6):
+        if wfmt == _lib.TQ_WFMT_F16_MX6 and Cin % 64:
+            continue
+        dx, _, _ = ops.conv1d_bwd_data(dyv, w2.to(d), wfmt=wfmt)
+        assert rel_err(ncw(dx), x.grad) < TOL, wfmt
+    dw2 = ops.conv1d_bwd_weight(dyv, cl(x.detach()), (2 * C, Cin, 3))
+    dw = torch.empty(C, Cin, 5, device=d)
+    assert _lib.load().tq_upsample_poly_wgrad_fold(dw2.data_ptr(), dw.data_ptr(), C, Cin, None) == 0
+    assert rel_err(dw.cpu(), w.grad) < TOL
+
+
 @pytest.mark.parametrize("C0,C1,Co,T", [(64, 0, 64, 256), (128, 64, 128, 200), (64, 32, 64, 130)])
 def test_groupnorm_silu_conv_full_backward(C0, C1, Co, T):
     """GN32 (over a virtual concat, groups may straddle) -> SiLU -> conv: dx, dgamma, dbeta, dW vs autograd."""

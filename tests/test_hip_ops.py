@@ -141,7 +141,7 @@ def test_conv_64_channel_mx6_tile(C0, C1, T, p, res, skip):
     r = torch.randn(B, Co, T, generator=g) if res else None
     d = dev()
     srcs = [C0, C1] + (list(skip) if skip else [])
-    assert _lib.forward_wfmt(Co, srcs, fused_skip=skip is not None, k5_act=True) == _lib.TQ_WFMT_F16_MX6 or not _lib.MX6_C64 or os.environ.get("TQDNE_CONV_SCHEME")
+    # (the plans select this tile only with TQDNE_CONV_MX6_C64=1 -- measured neutral to slower, _lib.MX6_C64 -- the launch is asked for here)
     kw = dict(x1=cl(x1) if C1 else None, gscale=a.to(d), gshift=sh.to(d), silu=True, emb=emb.to(d), dropout_p=p, dropout_seed=13, dropout_site=5)
     sk = None
     if skip:

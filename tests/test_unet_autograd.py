@@ -72,10 +72,11 @@ def test_unet_module_backward_parameters_and_input(which, mode):
     assert worst < TOL and ex < TOL and n == len(sd) - 1
     # .grad accumulates over a second call, as with any nn.Module
     g1 = {n_: p.grad.clone() for n_, p in m.named_parameters() if p.grad is not None}
+    gmax = max(float(v.abs().max()) for v in g1.values())
     m(x.to(dev()), t.to(dev()), c.to(dev())).square().mean().backward()
     for n_, p in m.named_parameters():
-        if p.grad is not None:
-            assert rel_err(p.grad.cpu(), 2 * g1[n_].cpu(), elem=False) < 1e-4, n_
+        if p.grad is not None:   # (tensors whose true gradient is zero hold rounding noise only: measured against the largest gradient)
+            assert float((p.grad - 2 * g1[n_]).abs().max()) < 1e-4 * max(float(g1[n_].abs().max()), 1e-3 * gmax), n_
 
 
 def test_unet_forward_without_grad_is_not_recorded_and_non_leaf_inputs_work():

@@ -25,7 +25,7 @@ PACK_MODE_T = {TQ_WFMT_BF16X3: 1, TQ_WFMT_F16_MX6: 5}                      # ...
 
 
 DEFAULT_SCHEME = "f16mx6"
-ABI_VERSION = 6   # include/tqdne_hip.h TQ_ABI_VERSION
+ABI_VERSION = 7   # include/tqdne_hip.h TQ_ABI_VERSION
 
 
 def requested_scheme() -> str:
@@ -44,7 +44,11 @@ def attn_v_format() -> int:
     return TQ_KV_V_F16
 
 
-MX6_C64 = os.environ.get("TQDNE_CONV_MX6_C64", "1") != "0"   # A/B switch of round 6's 64-channel fp16 + MX-fp6 tile (0: bf16x3 as before)
+# Round 6's 64-channel fp16 + MX-fp6 tile (64 channels x 128 positions): built, parity-green, and measured NEUTRAL TO SLOWER against the
+# bf16x3 tile of 64 x 256 on every 64-channel layer of the paper UNet (profiles/r06_b_c64_tile_ab.txt: sample 159.6 vs 159.4 ms, train
+# 23.4 vs 23.4 ms; fused-skip launches +5 ... +12 %): those layers are bound by their load / convert / store phases, not by matrix work.
+# Off by default; TQDNE_CONV_MX6_C64=1 selects it.
+MX6_C64 = os.environ.get("TQDNE_CONV_MX6_C64", "0") == "1"
 
 
 def forward_wfmt(C_out: int, sources, stride: int = 1, upsample: bool = False, fused_skip: bool = False, k5_act: bool = False) -> int:
@@ -169,6 +173,7 @@ _PROTOS = {
     "tq_colsum": (I, [VP, I, I, I, VP, I, VP, VP, VP, VP, VP]),
     "tq_zero_stuff": (I, [VP, VP, I, I, I, I, VP]),
     "tq_pair_sum": (I, [VP, VP, I, I, I, I, VP]),
+    "tq_upsample_poly_wgrad_fold": (I, [VP, VP, I, I, VP]),
     "tq_stem_conv_bwd_weight": (I, [VP] * 4 + [I] * 5 + [VP]),
     "tq_head_conv_bwd": (I, [VP] * 10 + [I] * 5 + [VP]),
     "tq_stem_head_bwd_workspace": (SZ, []),

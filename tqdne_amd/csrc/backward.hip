@@ -1067,6 +1067,31 @@ extern "C" int tq_pair_sum(const float* d_up, float* dx, int B, int T, int C, in
     return 0;
 }
 
+// Round 6: Upsample (blocks.py:56-66: nearest x2, then conv k = 5) trained in its two-phase k = 3 form (TQ_CONV_POLY2: even outputs see the
+// taps A = (w0+w1, w2+w3, w4), odd ones B = (w0, w1+w2, w3+w4) of the un-upsampled rows).  Its weight gradient is the plain k = 3 weight
+// gradient of that conv -- d W2 (2 C_out, C_in, 3) = [dA | dB], with the output gradient (B, 2T, C_out) read as (B, T, 2 C_out) -- folded
+// back onto the five taps by the transpose of the tap sums:  dw0 = dA0 + dB0, dw1 = dA0 + dB1, dw2 = dA1 + dB1, dw3 = dA1 + dB2,
+// dw4 = dA2 + dB2.  3/5 of the multiply-adds of the k = 5 gradient over the upsampled gather.
+namespace {
+__global__ __launch_bounds__(256) void poly_wgrad_fold_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // (co, ci) pair
+    if (i >= n) return;
+    const float* a = dw2 + (size_t)i * 3;
+    const float* b = dw2 + ((size_t)n + i) * 3;
+    const float a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2];
+    float* o = dw + (size_t)i * 5;
+    o[0] = a0 + b0; o[1] = a0 + b1; o[2] = a1 + b1; o[3] = a1 + b2; o[4] = a2 + b2;
+}
+}  // namespace
+
+extern "C" int tq_upsample_poly_wgrad_fold(const float* dw2, float* dw, int C_out, int C_in, hipStream_t stream) {
+    if (!dw2 || !dw || C_out <= 0 || C_in <= 0) return TQ_ERR_ARG;
+    const int n = C_out * C_in;
+    hipLaunchKernelGGL(poly_wgrad_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dw2, dw, n);
+    TQ_CHECK_LAUNCH();
+    return 0;
+}
+
 // =================================================================================================
 // Round 4: streaming forms of the stem weight gradient and of the head backward.  The round 1-3 kernels below (thread per output
 // element, both operands from LDS: two LDS reads per FMA; 512-2048 workgroups x 960 atomics) took 260 us and 188 us at B = 64 for

@@ -1095,9 +1095,35 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[cbk][j] = 0.f; s2[cbk][j] = 0.f; }
     }
+    // Residual (TQ_CONV_RES; RES_EARLY launches took it as the accumulators' start value): ALL of the wave's loads are issued first --
+    // branch-free, rows past the tensor clamped to its last row -- and waited for once.  Round 6: inside the store loop each load was
+    // followed by s_waitcnt vmcnt(0) (hipcc drains the counter at the loop's joins), which also waits for the PREVIOUS stores: sixteen
+    // store-complete + load round trips in a row per wave.
+    const bool res_epi = (!RES_EARLY || poly) && (p.flags & TQ_CONV_RES);
+    float4 rq[TBW][NCB];
+#ifdef TQ_ABL_EPI_SERIAL   // (A/B build: the loads inside the store loop, as in rounds 1-5)
+    if (false) {
+#else
+    if (res_epi) {   // (wave-uniform)
+#endif
+#pragma unroll
+        for (int tb = 0; tb < TBW; ++tb) {
+            const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+            const int tc = t < p.T_out ? t : p.T_out - 1;
+#pragma unroll
+            for (int cbk = 0; cbk < NCB; ++cbk) {
+                const int co = co_real + cbk * 16 + 4 * (lane >> 4);
+                const size_t o = poly ? ((size_t)b * 2 * p.T_out + 2 * tc + ph) * Cr + co : ((size_t)b * p.T_out + tc) * p.C_out + co;
+                rq[tb][cbk] = *reinterpret_cast<const float4*>(p.res + o);
+            }
+        }
+    }
 #pragma unroll
     for (int tb = 0; tb < TBW; ++tb) {
-        const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+        int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+        // (opaque to the optimiser: the store addresses are recomputed here -- shared with the load batch above they would be sixteen
+        // 64-bit values live across it, which hipcc sends to scratch)
+        asm volatile("" : "+v"(t));
         if (t < p.T_out) {
 #pragma unroll
             for (int cbk = 0; cbk < NCB; ++cbk) {
@@ -1105,8 +1131,12 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                 const size_t o = poly ? ((size_t)b * 2 * p.T_out + 2 * t + ph) * Cr + co : ((size_t)b * p.T_out + t) * p.C_out + co;
                 float4 v = make_float4(acc[cbk][tb][0] + add[cbk].x, acc[cbk][tb][1] + add[cbk].y,
                                        acc[cbk][tb][2] + add[cbk].z, acc[cbk][tb][3] + add[cbk].w);
-                if ((!RES_EARLY || poly) && (p.flags & TQ_CONV_RES)) {   // (RES_EARLY: it entered as the accumulators' start value)
+                if (res_epi) {
+#ifdef TQ_ABL_EPI_SERIAL
                     const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+#else
+                    const float4 r = rq[tb][cbk];
+#endif
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
 #ifdef TQ_ABL_NOEPI
@@ -1229,9 +1259,33 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s1[cbk][j] = 0.f; s2[cbk][j] = 0.f; }
         }
+        // Round 6: the loads of the epilogue -- the forward input x (chain through GN / SiLU, GN-backward sums) or, for accumulating
+        // launches, the gradient already in place -- are issued for the whole wave tile FIRST (branch-free, clamped rows) and waited for
+        // once.  Inside the store loop every load was followed by s_waitcnt vmcnt(0), i.e. by a wait for the previous stores as well:
+        // sixteen dependent round trips per wave.  (A launch that needs both kinds keeps the in-loop loads for the second.)
+        const bool need_x = p.bflags & (TQ_BWD_GN | TQ_BWD_SILU | TQ_BWD_STATS);
+        const bool accum = p.bflags & TQ_BWD_ACCUM;
+        f32x4 lq[TBW][2];   // (a vector type like the accumulators: as HIP float4 structs the batch stayed in scratch memory)
+#ifdef TQ_ABL_EPI_SERIAL   // (A/B build: the loads inside the store loop, as in rounds 1-5)
+        if (false) {
+#else
+        if (need_x || accum) {   // (wave-uniform)
+#endif
+#pragma unroll
+            for (int tb = 0; tb < TBW; ++tb) {
+                const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+                const int tc = t < p.T_out ? t : p.T_out - 1;
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk) {
+                    const size_t o = ((size_t)b * p.T_out + tc) * cs[cbk] + cc[cbk];
+                    lq[tb][cbk] = *reinterpret_cast<const f32x4*>((need_x ? fx[cbk] : dst[cbk]) + o);
+                }
+            }
+        }
 #pragma unroll
         for (int tb = 0; tb < TBW; ++tb) {
-            const int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+            int t = t0 + wn * C::WT + tb * 16 + (lane & 15);
+            asm volatile("" : "+v"(t));   // (store addresses recomputed, not kept live across the load batch: see the forward epilogue)
             if (t < p.T_out) {
 #pragma unroll
                 for (int cbk = 0; cbk < 2; ++cbk) {
@@ -1240,9 +1294,13 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                     float v[4] = {acc[cbk][tb][0], acc[cbk][tb][1], acc[cbk][tb][2], acc[cbk][tb][3]};
                     if constexpr (SCH == 2) { v[0] *= dy_unscale; v[1] *= dy_unscale; v[2] *= dy_unscale; v[3] *= dy_unscale; }
                     float xv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bflags & (TQ_BWD_GN | TQ_BWD_SILU | TQ_BWD_STATS)) {
-                        const float4 x4 = *reinterpret_cast<const float4*>(fx[cbk] + o);
-                        xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                    if (need_x) {
+#ifdef TQ_ABL_EPI_SERIAL
+                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(fx[cbk] + o);
+#else
+                        const f32x4 x4 = lq[tb][cbk];
+#endif
+                        xv[0] = x4[0]; xv[1] = x4[1]; xv[2] = x4[2]; xv[3] = x4[3];
                     }
                     if (p.bflags & TQ_BWD_SILU) {
                         const float a4[4] = {ga[cbk].x, ga[cbk].y, ga[cbk].z, ga[cbk].w};
@@ -1256,9 +1314,14 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
                         for (int j = 0; j < 4; ++j)
                             v[j] = (drop_hash(dkey, e0 + j) >= p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
                     }
-                    if (p.bflags & TQ_BWD_ACCUM) {
-                        const float4 r = *reinterpret_cast<const float4*>(dst[cbk] + o);
-                        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                    if (accum) {
+#ifdef TQ_ABL_EPI_SERIAL
+                        f32x4 r = *reinterpret_cast<const f32x4*>(dst[cbk] + o);
+#else
+                        f32x4 r = lq[tb][cbk];
+                        if (need_x) r = *reinterpret_cast<const f32x4*>(dst[cbk] + o);
+#endif
+                        v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
                     }
                     *reinterpret_cast<float4*>(dst[cbk] + o) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll

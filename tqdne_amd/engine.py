@@ -65,6 +65,10 @@ FUSE_SKIP = os.environ.get("TQDNE_FUSE_SKIP", "1") != "0"  # A/B switch for the 
 # what the 49 launches cost comes back as the fold's dependent-load chain on the tail of the producing launch -> off by default
 # (an experiment since round 4: only libraries built with TQDNE_BUILD_EXPERIMENTS=1 carry it)
 GN_FUSE = os.environ.get("TQDNE_GN_FUSE", "0") == "1"
+# Round 6: the TRAINING forward of Upsample runs in the two-phase k = 3 form too (it was the inference form only), and its gradients are
+# those of that k = 3 conv (engine_bwd._bwd_up_poly): 3/5 of the multiply-adds in all three passes, no (B, 2T, C) scratch gradient, no
+# tq_pair_sum.  TQDNE_POLYPHASE_TRAIN=0: the k = 5 launches over the upsampled gather, as before.
+POLY_TRAIN = os.environ.get("TQDNE_POLYPHASE_TRAIN", "1") != "0"
 FUSE_SKIP_CO = 32  # smallest output-channel multiple fused (measured: 128 -> +3.9 %, 64 -> +1.3 % more on the bench step)
 # Small position tile (TqConvDesc.t_tile = 32) for the ResBlock convs of launch-bound plans: a plan whose batch is at most SMALL_TILE_B
 # samples launches 16-64 workgroups of the default tiles per conv on 256 compute units (tiny UNet, B = 4: 12-30 us per conv launch).
@@ -84,11 +88,12 @@ CONCURRENT_LANE0 = 8   # plan-cache lane ids from here on: sub-batch plans that 
 class ConvRec:
     """Everything the backward of one fused conv launch needs (the forward descriptor is reused for the weight gradient)."""
 
-    __slots__ = ("site", "desc", "srcs", "gn", "out", "stride", "upsample", "silu", "dropout")
+    __slots__ = ("site", "desc", "srcs", "gn", "out", "stride", "upsample", "silu", "dropout", "poly")
 
     def __init__(self, site, desc, srcs, gn, out, stride, upsample, silu, dropout):
         self.site, self.desc, self.srcs, self.gn, self.out = site, desc, srcs, gn, out
         self.stride, self.upsample, self.silu, self.dropout = stride, upsample, silu, dropout
+        self.poly = None   # (derived two-phase k = 3 site, its descriptor): the TRAINING forward of this Upsample ran in that form
 
 
 _SIDE_STREAMS: dict = {}
@@ -509,6 +514,8 @@ class UNetEngine:
                     and emb_ptr is None and os.environ.get("TQDNE_POLYPHASE_UPSAMPLE", "1") != "0"):
                 self._poly_desc = None
                 infer_op = self._polyphase_op(site, d, s0, s1, out, flops)
+                if POLY_TRAIN and s1 is None:
+                    op = infer_op   # (one form for both kinds of forward; the backward plan differentiates that form)
             if qkv_planes is not None:  # (ws, H, D): K / V straight into the attention kernel's pre-split planes
                 ws, H_, D_ = qkv_planes
                 # V planes in the plan's format (fp16 hi / lo unless the plan is on the fp32-range scheme): under the range guard
@@ -525,6 +532,8 @@ class UNetEngine:
         if launch and skip is not None and stats:
             out.prod = [d]
         self.last_rec = ConvRec(site, d, list(srcs), gn, out, stride, upsample, silu, dropout_site is not None)
+        if launch and upsample and POLY_TRAIN and s1 is None and self.poly_sites and self.poly_sites[-1][1] is site:
+            self.last_rec.poly = (self.poly_sites[-1][0], self._last_poly_desc)
         return out
 
     def _polyphase_op(self, site: ConvSite, d: TqConvDesc, s0: Act, s1: Optional[Act], out: Act, flops: int):
@@ -549,6 +558,7 @@ class UNetEngine:
             d2.range_flag = self.range_flag.data_ptr()
         self._keep.append(d2)
         self._poly_desc = d2
+        self._last_poly_desc = d2
         return (self.lib.tq_conv1d_fwd, (
             C.byref(d2), _p(s0.buf), _p(s1.buf) if s1 else None, None, None, _p(ps.packed), _p(site.bias), None, None,
             _p(out.buf), _p(out.stats)), "conv:" + site.name + "+polyphase", flops)

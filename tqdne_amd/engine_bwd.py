@@ -49,7 +49,7 @@ BWD_STREAMS = int(__import__("os").environ.get("TQDNE_BWD_STREAMS", "2"))
 # TQDNE_DGRAD_SCHEME=bf16x3 keeps round 3's three-product scheme everywhere.
 FUSE_APPLY_COLSUM = __import__("os").environ.get("TQDNE_FUSE_APPLY_COLSUM", "1") != "0"
 DGRAD_SCHEME = __import__("os").environ.get("TQDNE_DGRAD_SCHEME", "f16mx6").lower()
-DGRAD_MX6_C64 = __import__("os").environ.get("TQDNE_DGRAD_MX6_C64", "1") != "0"
+DGRAD_MX6_C64 = __import__("os").environ.get("TQDNE_DGRAD_MX6_C64", "0") == "1"   # (off by default: see _lib.MX6_C64)
 N_AMAX = 160   # blocks for max|dy| (one per gradient tensor that feeds a data gradient), kept in the tail of the flat buffer
 
 
@@ -241,20 +241,7 @@ class BackwardPlan:
             colsum = (None, 0, site.bias, None)
         bc, stride, c1, c2 = colsum if colsum is not None else (None, 0, None, None)
         if FUSE_COLSUM is False and colsum is not None:   # A/B switch: the column sums as their own pass over dy
-            T_dy = rec.out.T if rec.out is not None else rec.desc.T_out
-            amax = self.amax_ptr(dy.data_ptr())
-            wr = self._grad_writer.get(dy.data_ptr())
-            if FUSE_APPLY_COLSUM and wr is not None and wr[0][0] is lib.tq_gn_bwd_apply:
-                # the launch that writes dy last is a tq_gn_bwd_apply: it forms the sums from its registers (its op is rewritten in
-                # place; the gradients are final no earlier than before, so g() still records the current position)
-                op = wr[0]
-                op[0] = lib.tq_gn_bwd_apply_colsum
-                op[1] = op[1] + [bc, stride, _p(self.g(c1)) if c1 is not None else None, _p(self.g(c2)) if c2 is not None else None, amax]
-                op[2] = "gn_bwd_apply+colsum:" + site.name
-            else:
-                self.ops.append([lib.tq_colsum, [_p(dy), self.B, T_dy, site.C_out, bc, stride,
-                                                 _p(self.g(c1)) if c1 is not None else None, _p(self.g(c2)) if c2 is not None else None, None, amax],
-                                 "colsum:" + site.name])
+            self._colsum_pass(dy, rec.out.T if rec.out is not None else rec.desc.T_out, site.C_out, bc, stride, c1, c2, site.name)
             bc, stride, c1, c2 = None, 0, None, None
             self._wgrad_ops[-1] = len(self.ops)
         self.op_flops[len(self.ops)] = 2 * site.C_in * site.C_out * site.K * rec.desc.T_out * self.B
@@ -263,6 +250,24 @@ class BackwardPlan:
                                                            _p(self.g(site.weight)), None, 0, bc, stride,
                                                            _p(self.g(c1)) if c1 is not None else None,
                                                            _p(self.g(c2)) if c2 is not None else None], "wgrad:" + site.name])
+
+    def _colsum_pass(self, dy, T_dy, C_dy, bc, stride, c1, c2, name):
+        """column sums (bias / per-sample embedding gradients) and max|dy| of the gradient tensor ``dy`` (B, T_dy, C_dy): inside the
+        tq_gn_bwd_apply launch that writes dy last where there is one, else a tq_colsum pass of their own"""
+        lib = self.lib
+        amax = self.amax_ptr(dy.data_ptr())
+        wr = self._grad_writer.get(dy.data_ptr())
+        if FUSE_APPLY_COLSUM and wr is not None and wr[0][0] is lib.tq_gn_bwd_apply:
+            # the launch that writes dy last is a tq_gn_bwd_apply: it forms the sums from its registers (its op is rewritten in
+            # place; the gradients are final no earlier than before, so g() still records the current position)
+            op = wr[0]
+            op[0] = lib.tq_gn_bwd_apply_colsum
+            op[1] = op[1] + [bc, stride, _p(self.g(c1)) if c1 is not None else None, _p(self.g(c2)) if c2 is not None else None, amax]
+            op[2] = "gn_bwd_apply+colsum:" + name
+        else:
+            self.ops.append([lib.tq_colsum, [_p(dy), self.B, T_dy, C_dy, bc, stride,
+                                             _p(self.g(c1)) if c1 is not None else None, _p(self.g(c2)) if c2 is not None else None, None, amax],
+                             "colsum:" + name])
 
     def _dgrad(self, rec, dy, T, dsts, accumulate, chain=True, stats=True, amax_of=None):
         """dy (B,T,C_out of the forward conv) -> gradient wrt the forward conv's (activated) inputs.
@@ -275,7 +280,7 @@ class BackwardPlan:
         amax = self.amax_ptr((amax_of if amax_of is not None else dy).data_ptr(), create=False)
         # (and only where the forward scheme requested for the model is the same one: TQDNE_CONV_SCHEME=bf16x3 / f16mx8 means
         # fp32-range three-product data gradients too)
-        # (round 6: 64 | C_in through the 64-channel tile -- the 64- and 192-channel inputs of the T = 4096 level; TQDNE_DGRAD_MX6_C64=0: as before)
+        # (round 6: 64 | C_in through the 64-channel tile -- the 64- and 192-channel inputs of the T = 4096 level -- with TQDNE_DGRAD_MX6_C64=1; measured slower)
         cin_ok = site.C_in % 128 == 0 or (site.C_in % 64 == 0 and DGRAD_MX6_C64)
         mx6 = (DGRAD_SCHEME == "f16mx6" and _lib.requested_scheme() == "f16mx6"
                and amax is not None and site.C_out % 64 == 0 and cin_ok
@@ -501,7 +506,41 @@ class BackwardPlan:
         self._dgrad(rec, dyz, x.T, [self.grad(x)], accumulate=x.gw, chain=False, amax_of=dout)
         x.gw = True
 
+    def _bwd_up_poly(self, t):
+        """Upsample whose training forward ran in the two-phase k = 3 form (engine.POLY_TRAIN): the gradients of THAT conv, with the
+        output gradient (B, 2T, C) read as (B, T, 2C) -- row m of the view = [row 2m | row 2m + 1] = the two phases' channel blocks.
+          bias:    column sums of d out over the real (B, 2T, C) view (+ its max|.| for the fp16-range data gradient)
+          weights: k = 3 weight gradient d W2 (2C, C_in, 3), folded onto the five taps (tq_upsample_poly_wgrad_fold)
+          input:   k = 3 data gradient with the transposed two-phase weights, written (or accumulated) straight into d x"""
+        from ._lib import TqConvDesc
+        from .engine import ConvRec
+        lib = self.lib
+        x, out, rec = t["x"], t["out"], t["rec"]
+        ps, d2 = rec.poly
+        site = rec.site
+        assert out.gw and len(rec.srcs) == 1
+        dout = out.grad
+        self._colsum_pass(dout, out.T, site.C_out, None, 0, site.bias, None, site.name)
+        dw = TqConvDesc()
+        dw.B, dw.T_in, dw.T_out, dw.C_in0, dw.C_in1, dw.C_out = self.B, x.T, x.T, x.C, 0, 2 * site.C_out
+        dw.ktaps, dw.stride, dw.pad, dw.upsample, dw.flags = 3, 1, 1, 0, 0
+        self._keep.append(dw)
+        dW2 = self._empty(2 * site.C_out, site.C_in, 3)
+        self.ws_bytes = max(getattr(self, "ws_bytes", 0), lib.tq_conv1d_bwd_weight_workspace(C.byref(dw)))
+        self._wgrad_ops.append(len(self.ops))
+        self.op_flops[len(self.ops)] = 2 * site.C_in * 2 * site.C_out * 3 * x.T * self.B
+        self.ops.append([lib.tq_conv1d_bwd_weight_colsum, [C.byref(dw), _p(dout), _p(x.buf), None, None, None, _p(dW2), None, 0,
+                                                           None, 0, None, None], "wgrad:" + site.name + "+polyphase"])
+        # (named like a weight gradient: it follows it on the weight-gradient stream)
+        self.ops.append([lib.tq_upsample_poly_wgrad_fold, [_p(dW2), _p(self.g(site.weight)), site.C_out, site.C_in],
+                         "wgrad:fold:" + site.name])
+        rec2 = ConvRec(ps, d2, rec.srcs, None, None, 1, False, False, False)
+        self._dgrad(rec2, dout, x.T, [self.grad(x)], accumulate=x.gw, chain=False)
+        x.gw = True
+
     def _bwd_up(self, t):
+        if getattr(t["rec"], "poly", None) is not None:
+            return self._bwd_up_poly(t)
         x, out, rec = t["x"], t["out"], t["rec"]
         assert out.gw
         dout = out.grad
