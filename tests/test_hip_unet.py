@@ -571,7 +571,11 @@ def test_inference_forward_matches_backward_capable_forward(which):
     eng2.set_kv_v_format(_lib.TQ_KV_V_BF16)
     b2 = eng2.forward(x, t, cond, infer=True).clone()
     eng2.set_kv_v_format(_lib.TQ_KV_V_F16)
-    assert torch.equal(a2, a)
+    from tqdne_amd import engine as _E
+    if _E.POLY_TRAIN:   # round 6: forwards a backward may follow run the two-phase form too (their gradients are that conv's)
+        assert torch.equal(a2, b2) and 0 < rel_err(a2.cpu(), a.cpu()) < 4e-5
+    else:
+        assert torch.equal(a2, a)
     npoly = sum(op[2].endswith("+polyphase") for op in eng2.ops_infer)
     # (micro at T = 248: the up-sampling conv over 124 rows qualifies since round 5 -- a last tile of more than 64 rows --, the one over 62 does not)
     assert npoly == (3 if which == "paper" else 1)
@@ -677,8 +681,13 @@ def test_conv_scheme_bf16x3_moves_the_data_gradients_too(monkeypatch):
             assert all(d.wfmt == _lib.TQ_WFMT_BF16X3 for d, _s, _p in eng._wfmt_sites)
         else:
             assert any(w == _lib.TQ_WFMT_F16_MX6 for w in wf), wf
-        grads[scheme] = torch.cat([p.grad.reshape(-1) for p in edm.unet.parameters() if p.grad is not None]).cpu()
-    assert rel_err(grads["f16mx6"], grads["bf16x3"]) < TOL
+        grads[scheme] = {n: p.grad.detach().cpu().clone() for n, p in edm.unet.named_parameters() if p.grad is not None}
+    # per tensor, the suite's gradient metric (against the tensor's own scale, floored at 1e-3 of the largest gradient): the two schemes
+    # differ by their rounding (2^-15 vs 2^-16 per product) only
+    gmax = max(float(v.abs().max()) for v in grads["bf16x3"].values())
+    worst = max(grad_err(grads["f16mx6"][n], grads["bf16x3"][n], gmax, n) for n in grads["bf16x3"])
+    flat = lambda d: torch.cat([v.reshape(-1) for v in d.values()])
+    assert worst < TOL and rel_err(flat(grads["f16mx6"]), flat(grads["bf16x3"]), elem=False) < 1e-4
 
 
 def test_attention_backward_reuses_the_training_forwards_kv_planes():
