@@ -140,7 +140,8 @@ def test_batch_256_train_step_with_use_checkpoint_reports_memory():
         assert torch.isfinite(loss.detach()) and gsum == gsum
         del edm, loss
     print(f"B=256 train step, peak memory above weights + inputs: {out[False][2]:.1f} GiB; with use_checkpoint {out[True][2]:.1f} GiB")
-    assert abs(out[True][0] - out[False][0]) < 1e-6 * abs(out[False][0])
+    # (the loss is a float-atomics sum over 3.1 M elements: the order of the adds, hence its last bits, varies from launch to launch)
+    assert abs(out[True][0] - out[False][0]) < 5e-6 * abs(out[False][0])
     assert abs(out[True][1] - out[False][1]) < 1e-4 * out[False][1]
     assert out[True][2] < out[False][2]
 
