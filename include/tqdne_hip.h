@@ -79,6 +79,21 @@ typedef struct TqGnFuse {
     float* mean_rstd;             /* (B, 32, 2) out, nullable */
 } TqGnFuse;
 
+/* ABI 7.  Consumer-side GroupNorm fold (TqConvDesc.gn_fold; optional, NULL = off): the launch forms the folded coefficients of ITS OWN
+ * prologue (TQ_CONV_GN) from the partial statistics of its (up to two, concatenated) source tensors -- every workgroup folds its sample,
+ * the arithmetic of tq_gn_finalize, bit-identical coefficients -- and WRITES them to the gscale / gshift arguments of the call (and
+ * mean_rstd), where the weight / data gradients of the same conv read them later.  Replaces the tq_gn_finalize launch in front of the
+ * conv in launch-bound plans.  Built for the small tile (t_tile = 32: tq_conv1d_fwd, tq_conv1d_fwd_skip); other launches return TQ_ERR_SHAPE.
+ * Host pointer, read at launch. */
+typedef struct TqGnFold {
+    const float* stats0;   /* (B, ceil(T_in / slot0), C_in0, 2) partial statistics of source 0 */
+    const float* stats1;   /* (B, ceil(T_in / slot1), C_in1, 2) or NULL */
+    int32_t slot0, slot1;  /* positions per statistics slot of each source: 128 (0 = 128) or 32 */
+    const float* gamma;    /* (C_in0 + C_in1) affine parameters of the GroupNorm */
+    const float* beta;
+    float* mean_rstd;      /* (B, 32, 2) out, nullable */
+} TqGnFold;
+
 typedef struct TqConvDesc {
     int32_t B, T_in, T_out;
     int32_t C_in0, C_in1; /* channels of the two concatenated sources (C_in1 = 0: single source) */
@@ -108,6 +123,7 @@ typedef struct TqConvDesc {
      * association order. */
     int32_t t_tile;
     int32_t reserved2;
+    const TqGnFold* gn_fold; /* ABI 7: consumer-side GroupNorm fold (see TqGnFold), NULL = off */
 } TqConvDesc;
 
 /* flags of TqConvBwdDesc.flags: which stages the FORWARD conv applied to its input */

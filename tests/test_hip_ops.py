@@ -626,6 +626,52 @@ def test_conv_small_tile_equals_the_default_tile(cin0, cin1, cout, T, wf, p, ski
         assert rel_err(a2.cpu(), a3.cpu()) < 1e-5 and rel_err(h2.cpu(), h3.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("cin0,cin1,cout,T,wf,slots,skipc", [
+    (32, 0, 32, 300, 0, (128, 0), 0), (64, 32, 64, 257, 0, (32, 128), 0), (128, 128, 128, 96, 2, (32, 32), 0), (128, 0, 256, 65, 2, (128, 0), 0),
+    (256, 256, 256, 130, 2, (128, 32), 256), (64, 32, 64, 100, 0, (128, 128), 96), (128, 128, 128, 4096, 2, (128, 128), 0),
+])
+def test_conv_small_tile_folds_its_own_group_norm(cin0, cin1, cout, T, wf, slots, skipc):
+    """round 6, TqConvDesc.gn_fold (consumer side): the small-tile launch forms its GroupNorm coefficients from the sources' partial
+    statistics itself -- every workgroup folds its sample in its prologue -- instead of a tq_gn_finalize launch in front of it: the
+    coefficients it WRITES (gscale, gshift, mean / rstd: the backward reads them) and its output are BIT-identical to the two-launch form,
+    for one or two sources, either slot size per source, both schemes, with the fused skip conv."""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(cin0 + cin1 + cout + T)
+    B, K = 3, 5
+    d = dev()
+    cin = cin0 + cin1
+    x0 = torch.randn(B, T, cin0, generator=g).to(d) * 1.3 + 0.2
+    x1 = (torch.randn(B, T, cin1, generator=g) - 0.4).to(d) if cin1 else None
+
+    def slot_stats(x, slot):   # (B, ceil(T / slot), C, 2) partial sums, as a producing conv's epilogue leaves them
+        n = (T + slot - 1) // slot
+        xp = torch.cat([x, torch.zeros(B, n * slot - T, x.shape[2], device=d)], 1).view(B, n, slot, x.shape[2])
+        return torch.stack([xp.sum(2), (xp * xp).sum(2)], -1).contiguous()
+    st0 = slot_stats(x0, slots[0])
+    st1 = slot_stats(x1, slots[1]) if cin1 else None
+    gam, bet = (torch.rand(cin, generator=g) + 0.5).to(d), torch.randn(cin, generator=g).to(d)
+    w = (torch.randn(cout, cin, K, generator=g) / math.sqrt(cin * K)).to(d)
+    b, emb = torch.randn(cout, generator=g).to(d), torch.randn(B, cout, generator=g).to(d)
+    kw = dict(x1=x1, silu=True, emb=emb, wfmt=wf, t_tile=32)
+    if skipc:
+        sx = torch.randn(B, T, skipc, generator=g).to(d)
+        kw["skip"] = (sx, None, (torch.randn(cout, skipc, 1, generator=g) / math.sqrt(skipc)).to(d), torch.randn(cout, generator=g).to(d))
+    else:
+        kw["residual"] = torch.randn(B, T, cout, generator=g).to(d)
+    a_ref, h_ref, m_ref = ops.gn_finalize(st0, cin0, T, gam, bet, stats1=st1, C1=cin1, slot0=slots[0], slot1=slots[1])
+    y_ref, s_ref = ops.conv1d(x0, w, b, gscale=a_ref, gshift=h_ref, **kw)
+    nan = float("nan")
+    a, h, m = torch.full_like(a_ref, nan), torch.full_like(h_ref, nan), torch.full_like(m_ref, nan)
+    y, s_ = ops.conv1d(x0, w, b, gscale=a, gshift=h, gn_fold=(st0, st1, slots[0], slots[1], gam, bet, m), **kw)
+    assert torch.equal(a, a_ref) and torch.equal(h, h_ref) and torch.equal(m, m_ref)
+    assert torch.equal(y, y_ref) and torch.equal(s_, s_ref)
+    # the default tiles are not built for it: refused, nothing launched
+    import ctypes as Ct
+    from tqdne_amd import _lib
+    with pytest.raises(_lib.TqError, match="TQ_ERR_SHAPE"):
+        ops.conv1d(x0, w, b, gscale=a, gshift=h, gn_fold=(st0, st1, slots[0], slots[1], gam, bet, m), **dict(kw, t_tile=0))
+
+
 def test_conv_small_tile_refuses_what_it_is_not_built_for():
     import ctypes as C
     from tqdne_amd import _lib

@@ -258,7 +258,7 @@ def _layout(struct):
     return [(n, getattr(struct, n).offset, getattr(struct, n).size) for n, *_ in struct._fields_], ctypes.sizeof(struct)
 
 
-@pytest.mark.parametrize("name", ["TqConvDesc", "TqConvBwdDesc", "TqPackJob", "TqGnFuse"])
+@pytest.mark.parametrize("name", ["TqConvDesc", "TqConvBwdDesc", "TqPackJob", "TqGnFuse", "TqGnFold"])
 def test_ctypes_structs_match_the_header(name):
     import ctypes
     from tqdne_amd import _lib

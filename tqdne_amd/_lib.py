@@ -77,6 +77,11 @@ class TqGnFuse(C.Structure):
                 ("mean_rstd", C.c_void_p)]
 
 
+class TqGnFold(C.Structure):
+    _fields_ = [("stats0", C.c_void_p), ("stats1", C.c_void_p), ("slot0", C.c_int32), ("slot1", C.c_int32),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean_rstd", C.c_void_p)]
+
+
 class TqConvDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T_in", C.c_int32), ("T_out", C.c_int32),
@@ -86,6 +91,7 @@ class TqConvDesc(C.Structure):
         ("dropout_site", C.c_uint32), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("C_skip0", C.c_int32), ("C_skip1", C.c_int32), ("wfmt", C.c_int32),
         ("range_flag", C.c_void_p), ("gn_fuse", C.POINTER(TqGnFuse)), ("t_tile", C.c_int32), ("reserved2", C.c_int32),
+        ("gn_fold", C.POINTER(TqGnFold)),
     ]
 
 

@@ -792,6 +792,18 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2 && SCH == 0) ?
     // pays one global round trip, not two in a row (table, barrier, then the chunk).  Branch-free: threads past the table repeat
     // its last entry (same value to the same slot).
     static_assert(!(SCH == 2 && ACT >= 1) || C::NTHR >= 256, "one table entry per thread");
+    // Round 6, consumer-side GroupNorm fold (TqConvDesc.gn_fold; small tile only): the workgroup forms the folded coefficients of ITS sample
+    // from the source tensors' partial statistics here -- the arithmetic of tq_gn_finalize (gn_fold_sample: bit-identical coefficients for
+    // any workgroup size) -- writes them where the prologue below (and, later, the backward) reads them, and goes on; every workgroup of
+    // a sample writes the same bits.  Replaces the tq_gn_finalize launch in front of this one: a launch-bound plan (<= 4 samples: ~100
+    // dependent launches of 5-30 us) loses 45 % of its launches for ~3 us more in the prologue of each conv.
+    if constexpr (TBW == 2 && ACT >= 1 && !PW && EPI == 0) {
+        if (p.cf_st0) {   // (uniform over the launch)
+            gn_fold_sample<false, false>(reinterpret_cast<double*>(lds), b, p.cf_st0, p.C0, p.cf_st1, p.C1, p.T_in, p.cf_ns0, p.cf_ns1, p.cf_gamma,
+                                         p.cf_beta, const_cast<float*>(p.gscale), const_cast<float*>(p.gshift), p.cf_mean_rstd);
+            __syncthreads();   // the coefficients (global) are read back by other threads; the LDS scratch becomes the staging buffers
+        }
+    }
     float4 gt_a = make_float4(0.f, 0.f, 0.f, 0.f), gt_s = gt_a;
     int gt_i = 0;
     if constexpr (SCH == 2 && ACT >= 1) {
@@ -1396,6 +1408,9 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int GTAB_MAX = (SCH == 2 && ACT >= 1) ? 2 * 4 * 1024 : 0;   // room for C_in <= 1024
     constexpr int LDS_BYTES = (PW ? 4 * C::BUF : C::LDS_BYTES) + GTAB_MAX;
     if (SCH == 2 && a.C0 + a.C1 > 1024) return TQ_ERR_SHAPE;
+    if (a.cf_st0) {   // consumer-side GroupNorm fold: built into the small tile's forward launches; its scratch (2 C + 64 doubles) must fit the staging buffers
+        if (!(TBW == 2 && ACT >= 1 && !PW && EPI == 0) || (size_t)(2 * (a.C0 + a.C1) + 64) * sizeof(double) > (size_t)LDS_BYTES) return TQ_ERR_SHAPE;
+    }
     // The dynamic-LDS limit is a per-device property of the kernel: remember, per device ordinal, that it has been raised
     // (idempotent call: two threads racing here both set the same value; the mask only saves the repeated runtime call).
     static std::atomic<uint64_t> attr_done{0};

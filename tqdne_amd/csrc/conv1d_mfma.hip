@@ -117,6 +117,18 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.in_amax = nullptr;
     a.gf_counters = nullptr; a.exp_stagger = conv_exp_stagger(); a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
     a.gf_gamma = a.gf_beta = nullptr; a.gf_gscale = a.gf_gshift = a.gf_mean_rstd = nullptr;
+    a.cf_st0 = a.cf_st1 = a.cf_gamma = a.cf_beta = nullptr; a.cf_mean_rstd = nullptr; a.cf_ns0 = a.cf_ns1 = 0;
+    if (d->gn_fold) {   // consumer-side GroupNorm fold (ABI 7): this launch forms its own folded coefficients (see TqGnFold)
+        const TqGnFold* f = d->gn_fold;
+        if (!(d->flags & TQ_CONV_GN) || a.t_tile != 32 || kv_planes || d->gn_fuse) return TQ_ERR_SHAPE;
+        if (!f->stats0 || !f->gamma || !f->beta || (d->C_in1 > 0 && !f->stats1)) return TQ_ERR_ARG;
+        const int s0 = f->slot0 ? f->slot0 : STAT_SLOT, s1 = f->slot1 ? f->slot1 : STAT_SLOT;
+        if ((s0 != STAT_SLOT && s0 != 32) || (s1 != STAT_SLOT && s1 != 32)) return TQ_ERR_ARG;
+        if ((d->C_in0 + d->C_in1) % GN_GROUPS) return TQ_ERR_SHAPE;
+        a.cf_st0 = f->stats0; a.cf_st1 = d->C_in1 > 0 ? f->stats1 : nullptr;
+        a.cf_ns0 = (d->T_in + s0 - 1) / s0; a.cf_ns1 = (d->T_in + s1 - 1) / s1;
+        a.cf_gamma = f->gamma; a.cf_beta = f->beta; a.cf_mean_rstd = f->mean_rstd;
+    }
 #ifndef TQ_BUILD_EXPERIMENTS
     if (d->gn_fuse) return TQ_ERR_ARG;   // reserved: the in-launch GroupNorm fold is an experiment (TQDNE_BUILD_EXPERIMENTS=1 builds it)
 #else
@@ -201,6 +213,7 @@ extern "C" int tq_conv1d_bwd_data(const TqConvBwdDesc* d, const float* dy, const
     a.range_flag = nullptr;
     a.gf_counters = nullptr; a.exp_stagger = conv_exp_stagger(); a.gf_partner = nullptr; a.gf_Cp = 0; a.gf_partner_first = 0; a.gf_narrive = 0;
     a.gf_gamma = a.gf_beta = nullptr; a.gf_gscale = a.gf_gshift = a.gf_mean_rstd = nullptr;
+    a.cf_st0 = a.cf_st1 = a.cf_gamma = a.cf_beta = nullptr; a.cf_mean_rstd = nullptr; a.cf_ns0 = a.cf_ns1 = 0;
     return conv_launch_dgrad(a, d->ktaps, stream);
 }
 

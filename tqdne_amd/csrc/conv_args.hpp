@@ -53,6 +53,13 @@ struct ConvArgs {
     float* gf_gscale;
     float* gf_gshift;
     float* gf_mean_rstd;
+    // consumer-side GroupNorm fold (TqConvDesc.gn_fold): statistics of the two sources, slots per source, affine parameters; cf_st0 == nullptr: off
+    const float* cf_st0;
+    const float* cf_st1;
+    int cf_ns0, cf_ns1;
+    const float* cf_gamma;
+    const float* cf_beta;
+    float* cf_mean_rstd;
     int exp_stagger;   // experiment builds (-DTQ_EXP_STAGGER): s_sleep units by which the workgroups of a launch start apart; else 0, unread
 };
 

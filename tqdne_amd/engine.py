@@ -82,6 +82,9 @@ SMALL_TILE_B = int(os.environ.get("TQDNE_SMALL_TILE_B", "4")) if os.environ.get(
 # device between them, and there the small tile's 4x weight traffic costs 161 -> 180 ms per B = 64 sample; the mid level (128
 # workgroups) loses 7-18 % alone (profiles/r04_v_small_tile_per_layer.txt).
 SMALL_TILE_WGS = int(os.environ.get("TQDNE_SMALL_TILE_WGS", "64")) if os.environ.get("TQDNE_SMALL_TILE", "1") != "0" else 0
+# Round 6: a small-tile conv folds its own GroupNorm (TqConvDesc.gn_fold, consumer side) instead of a tq_gn_finalize launch in front of it:
+# a plan of <= 4 samples is ~100 dependent launches of 5-30 us, and 45 % of them were these.  TQDNE_GN_FOLD_SMALL=0: the launches.
+GN_FOLD_SMALL = os.environ.get("TQDNE_GN_FOLD_SMALL", "1") != "0"
 CONCURRENT_LANE0 = 8   # plan-cache lane ids from here on: sub-batch plans that run concurrently (see UNetModel._engine)
 
 
@@ -393,7 +396,7 @@ class UNetEngine:
         self.ops_infer.append(op if infer_op is None else infer_op)
         self.op_bytes.append(nbytes)
 
-    def _gn(self, srcs: Sequence[Act], norm: torch.nn.GroupNorm):
+    def _gn(self, srcs: Sequence[Act], norm: torch.nn.GroupNorm, defer: bool = False):
         """Folded scale / shift (B, C) of a GroupNorm over the (concatenated) sources.  Where the most recent source is written by a
         conv launch that can do it, the fold rides in that launch (TqGnFuse: the workgroup completing a sample's statistics folds
         them); otherwise -- the stem's output, a tensor that is already the last source of another GroupNorm -- a tq_gn_finalize
@@ -420,10 +423,16 @@ class UNetEngine:
                 d.gn_fuse = C.pointer(f)
             self.gn_fused += 1
             return gscale, gshift, mean_rstd
-        self._emit((self.lib.tq_gn_finalize, (
+        fin = ((self.lib.tq_gn_finalize, (
             _p(s0.stats), s0.C, _p(s1.stats) if s1 else None, s1.C if s1 else 0, self.B, s0.T,
             _p(norm.weight), _p(norm.bias), _p(gscale), _p(gshift), _p(mean_rstd), s0.slot, s1.slot if s1 else 0), "gn_finalize", 0),
-            nbytes=4 * self.B * (2 * nslots(s0.T) * C_ + 2 * C_))
+            4 * self.B * (2 * nslots(s0.T) * C_ + 2 * C_))
+        if defer:
+            # the consuming conv decides (``_conv``): a small-tile launch folds these statistics itself, any other launch gets the
+            # tq_gn_finalize launch in front of it
+            self._pending_gn = dict(key=gscale.data_ptr(), fin=fin, srcs=(s0, s1), norm=norm, mean_rstd=mean_rstd)
+            return gscale, gshift, mean_rstd
+        self._emit(fin[0], nbytes=fin[1])
         return gscale, gshift, mean_rstd
 
     def _conv(self, srcs: Sequence[Act], site: ConvSite, *, gn=None, silu=False, emb_ptr=None, res: Optional[Act] = None,
@@ -458,6 +467,20 @@ class UNetEngine:
             out = self._act(site.C_out, T_out, stats, slot=32 if small else STAT_SLOT) if launch else None
         d = TqConvDesc()
         d.t_tile = 32 if small else 0
+        pend = getattr(self, "_pending_gn", None)
+        if pend is not None and gn is not None and pend["key"] == gn[0].data_ptr():
+            self._pending_gn = None
+            if small and launch and GN_FOLD_SMALL and not self.ckpt and not GN_FUSE:
+                f = _lib.TqGnFold()
+                ps0, ps1 = pend["srcs"]
+                f.stats0, f.stats1 = _p(ps0.stats), (_p(ps1.stats) if ps1 is not None else None)
+                f.slot0, f.slot1 = ps0.slot, (ps1.slot if ps1 is not None else 0)
+                f.gamma, f.beta, f.mean_rstd = _p(pend["norm"].weight), _p(pend["norm"].bias), _p(pend["mean_rstd"])
+                self._keep.append(f)
+                d.gn_fold = C.pointer(f)
+                self.gn_folded = getattr(self, "gn_folded", 0) + 1
+            else:
+                self._emit(pend["fin"][0], nbytes=pend["fin"][1])
         d.B, d.T_in, d.T_out = self.B, T_in, T_out
         d.C_in0, d.C_in1, d.C_out = s0.C, (s1.C if s1 else 0), site.C_out
         assert d.C_in0 + d.C_in1 == site.C_in, (site.name, d.C_in0, d.C_in1, site.C_in)
@@ -640,16 +663,17 @@ class UNetEngine:
         _check_head_limits(h.C, m.out[2].out_channels, m.out[2].kernel_size[0])
         self.head_gn = self._gn([h], m.out[0])
         self.out_nct = self._empty(B, m.out_channels, T)
+        assert getattr(self, "_pending_gn", None) is None, "a deferred GroupNorm finalisation was never placed"
 
     def _res_block(self, x, rb, name: str) -> Act:
         srcs = list(x) if isinstance(x, tuple) else [x]
         emb_ptr = self.emb_all.data_ptr() + 4 * self.emb_offsets[id(rb)] if hasattr(rb, "emb_layers") else None
-        g1 = self._gn(srcs, rb.in_layers[0])
+        g1 = self._gn(srcs, rb.in_layers[0], defer=not self.ckpt)   # (use_checkpoint plans keep their recompute lists: no consumer-side fold)
         i_conv1 = len(self.ops)
         h1 = self._conv(srcs, self._site(name + ".in_layers.2", rb.in_layers[2]), gn=g1, silu=True, emb_ptr=emb_ptr, ckpt_tag="h1")
         rec1 = self.last_rec
         i_gn2 = len(self.ops)
-        g2 = self._gn([h1], rb.out_layers[0])
+        g2 = self._gn([h1], rb.out_layers[0], defer=not self.ckpt)
         # use_checkpoint: h1 and its statistics live in a shared buffer; the backward re-issues [conv1, GroupNorm 2's fold] first
         recompute = list(range(i_conv1, len(self.ops))) if self.ckpt else None
         rec_sk = None

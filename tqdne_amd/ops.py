@@ -34,10 +34,13 @@ def pack_conv_weight(w: torch.Tensor, mode: int = 0) -> torch.Tensor:
 
 
 def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=False, emb=None, residual=None,
-           stride=1, upsample=False, stats=True, dropout_p=0.0, dropout_seed=0, dropout_site=0, skip=None, wfmt=None, t_tile=0):
+           stride=1, upsample=False, stats=True, dropout_p=0.0, dropout_seed=0, dropout_site=0, skip=None, wfmt=None, t_tile=0,
+           gn_fold=None):
     """x0/x1 (B, T, C) channels-last fp32; weight (C_out, C_in, K) torch layout.  Returns (y, stats|None).
     skip=(sx0, sx1|None, w_skip (C_out, Cs, 1), b_skip|None): fused 1x1 conv of the un-activated sx (tq_conv1d_fwd_skip).
-    t_tile=32: the small tile (TqConvDesc.t_tile); the statistics then have one slot per 32 positions."""
+    t_tile=32: the small tile (TqConvDesc.t_tile); the statistics then have one slot per 32 positions.
+    gn_fold=(stats0, stats1|None, slot0, slot1, gamma, beta, mean_rstd|None): the launch folds its own GroupNorm (TqConvDesc.gn_fold) and
+    WRITES the coefficients into ``gscale`` / ``gshift`` (pass empty (B, C_in) tensors) and ``mean_rstd``."""
     lib = _lib.load()
     B, T_in, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[2]
@@ -71,6 +74,11 @@ def conv1d(x0, weight, bias=None, *, x1=None, gscale=None, gshift=None, silu=Fal
         wfmt = _lib.forward_wfmt(C_out, srcs, stride, upsample, fused_skip=skip is not None,
                                  k5_act=K == 5 and gscale is not None and silu and stride == 1 and not upsample and t_tile == 0)
     d.wfmt = wfmt
+    if gn_fold is not None:
+        f = _lib.TqGnFold()
+        f.stats0, f.stats1, f.slot0, f.slot1 = _p(gn_fold[0]), _p(gn_fold[1]), gn_fold[2], gn_fold[3]
+        f.gamma, f.beta, f.mean_rstd = _p(gn_fold[4]), _p(gn_fold[5]), _p(gn_fold[6])
+        d.gn_fold = C.pointer(f)
     pmode = _lib.PACK_MODE[wfmt]
     wp = pack_conv_weight(weight, pmode)
     if skip is not None:
