@@ -50,9 +50,18 @@ def main():
             t.copy_(h)
             return _Done()
 
-    sd, d = load_golden("micro_unet.npz")
-    cfg = dict(cfg_of(d), dropout=0.0)  # masks are indexed by the position in the LOCAL batch: equivalence needs p = 0
-    Bg, T = 8, 256
+    which = os.environ.get("TQ_TEST_CONFIG", "micro")
+    if which == "paper":   # the configuration of BASELINE cfg2 (the paper UNet under data parallelism), at a length the test can afford
+        from test_hip_unet import perturbed_state
+        from tqdne_amd import UNetModel, paper_1d_unet_config
+        cfg = dict(paper_1d_unet_config(), dropout=0.0)
+        torch.manual_seed(0)
+        sd = perturbed_state(UNetModel(**cfg), 31)
+        Bg, T = 4, 512
+    else:
+        sd, d = load_golden("micro_unet.npz")
+        cfg = dict(cfg_of(d), dropout=0.0)  # masks are indexed by the position in the LOCAL batch: equivalence needs p = 0
+        Bg, T = 8, 256
     g = torch.Generator().manual_seed(11)
     batch = {"signal": 0.5 * torch.randn(Bg, 3, T, generator=g), "cond": torch.randn(Bg, 5, generator=g)}
     eps_g, noise_g = torch.randn(Bg, generator=g), torch.randn(Bg, 3, T, generator=g)
@@ -86,7 +95,7 @@ def main():
         local = {k: v.to(dev) for k, v in shard_batch(batch, rank, world).items()}
         per = Bg // world
         m.inject = (eps_g[rank * per:(rank + 1) * per].to(dev), noise_g[rank * per:(rank + 1) * per].contiguous().to(dev))
-        tr = Trainer(m, world_size=world, bucket_bytes=64 << 10, overlap=overlap, fused_optimizer=True)
+        tr = Trainer(m, world_size=world, bucket_bytes=(16 << 20) if which == "paper" else (64 << 10), overlap=overlap, fused_optimizer=True)
         # exchange only (optimizer held back): capture the reduced gradients
         opt_step = tr.optimizer.step
         grabbed = {}

@@ -1466,7 +1466,10 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
     if (a.wfmt == TQ_WFMT_F16_MX6) {  // same shapes as TQ_WFMT_F16_MX8 (below), fp6 block-scaled corrections
         if constexpr (STRIDE == 1 && UPS == 0 && EPI == 1 && ACT == 0 && !FUSE) {   // data gradient (dy scaled by a power of two)
             if (a.C0 % 64 || a.C1) return TQ_ERR_SHAPE;
-            if (a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
+            // TQDNE_DGRAD_TILE256=0 (A/B switch, round 6): 256-channel outputs as two co-resident 4-wave workgroups -- does a neighbour's
+            // MFMA stream cover the chain epilogue (x read back behind the last MFMA, +26 ... +73 % per launch)?
+            static const int dg256 = [] { const char* e = getenv("TQDNE_DGRAD_TILE256"); return (e && e[0] == '0') ? 0 : 1; }();
+            if (dg256 && a.C_out % 256 == 0) return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2>(a, s);
             if (a.C_out % 128 == 0) return launch<KT, STRIDE, UPS, 4, 1, EPI, ACT, FUSE, 2>(a, s);
             if (a.C_out % 64 == 0) return launch<KT, STRIDE, UPS, 2, 2, EPI, ACT, FUSE, 2, false, 4>(a, s);   // (round 6: 64 / 192 input channels)
             return TQ_ERR_SHAPE;
