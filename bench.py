@@ -344,6 +344,14 @@ def other_configs(dev, args):
             ts.append(1e3 * (time.perf_counter() - t0))
         return _median(ts)
 
+    def release():
+        """the previous configuration's model, plans and scratch are gone before the next one is built (and before a peak-memory reading
+        takes its base line): modules and plans reference each other, so collect, then hand the blocks back"""
+        import gc
+        gc.collect()
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
+
     def entry(config, B, unit, ms, ms_train, nbytes, **parts):
         return dict(config=config, value=B / (ms * 1e-3), unit=unit, ms_per_step=ms,
                     train_wf_s=B / (ms_train * 1e-3), sample_wf_s=B / ((ms - ms_train) * 1e-3),
@@ -385,6 +393,7 @@ def other_configs(dev, args):
         res.append(dict(config="cfg0", error=repr(e)))
     # ---- cfg3
     try:
+        release()
         torch.manual_seed(args.seed)
         ae = LightningAutoencoder(dict(AE_BASE, in_channels=3, out_channels=32), dict(AE_BASE, in_channels=16, out_channels=3),
                                   {"learning_rate": 1e-4, "max_steps": 1000, "eta_min": 0.0})
@@ -427,6 +436,7 @@ def other_configs(dev, args):
     # ---- cfg4: consistency-model sampling on the paper UNet (consistency_model.py:81-106), B = 64: one network evaluation per sample
     # (sigmas = []) and the reference's default call (sigmas = [1.0]: two evaluations + one uniform-noise refinement)
     try:
+        release()
         from tqdne_amd import UNetModel
         from tqdne_amd.consistency_model import LithningConsistencyModel
         torch.manual_seed(args.seed)
@@ -454,6 +464,7 @@ def other_configs(dev, args):
     # ---- the reference's real data shape (experiments/config.py:62-67, train_1d_edm.py): 3 x 4064 waveforms -> MovingAverageEnvelope ->
     # 6 x 4064 signals, paper UNet with 6 channels in / out, B = 64; the representation and its inverse run on the GPU here
     try:
+        release()
         from tqdne_amd.representation import MovingAverageEnvelope
         torch.manual_seed(args.seed)
         edm = LightningEDM(paper_1d_unet_config(in_channels=6, out_channels=6), opt, num_sampling_steps=args.sample_steps)
@@ -493,6 +504,7 @@ def other_configs(dev, args):
     # with every activation kept and with use_checkpoint=True (block-internal activations recomputed in the backward), and the step
     for ckpt in (False, True):
         try:
+            release()
             torch.manual_seed(args.seed)
             edm = LightningEDM(dict(paper_1d_unet_config(), use_checkpoint=ckpt), opt, num_sampling_steps=args.sample_steps)
             edm.unet.load_state_dict(perturbed_state(edm.unet, 17))

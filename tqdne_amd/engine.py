@@ -114,6 +114,15 @@ def side_stream(dev, i: int = 1) -> "torch.cuda.Stream":
     return s
 
 
+def hiprio_stream(dev) -> "torch.cuda.Stream":
+    """a high-priority stream of the device (experiment TQDNE_BWD_HIPRIO, engine_bwd.BackwardPlan.run)"""
+    key = (str(dev), "hiprio")
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1)
+    return s
+
+
 def reserve_side_streams(dev, n: int = 3):
     """Create the pool's first ``n`` streams NOW (called when the first plan of a device is built).  Stream creation order decides
     how ROCm spreads streams over hardware queues: with the three lane streams created AFTER anything had captured a HIP graph

@@ -42,6 +42,7 @@ FUSE_COLSUM = __import__("os").environ.get("TQDNE_FUSE_COLSUM", "0") != "0"
 # Weight-gradient launches on a second HIP stream next to the rest of the sweep (see BackwardPlan.run): measured -0.9 ms on the
 # 27 ms training step of the paper UNet at B = 64 (same box, twice).  TQDNE_BWD_STREAMS=1: everything on one stream.
 BWD_STREAMS = int(__import__("os").environ.get("TQDNE_BWD_STREAMS", "2"))
+BWD_HIPRIO = __import__("os").environ.get("TQDNE_BWD_HIPRIO", "0") == "1"
 
 # Round 4.  (1) Column sums (and max|.|) of a gradient tensor inside the tq_gn_bwd_apply launch that writes it last, instead of a
 # tq_colsum pass of their own (TQDNE_FUSE_APPLY_COLSUM=0: separate passes).  (2) Data gradients in the fp16 + MX-fp6 scheme on dy
@@ -579,8 +580,24 @@ class BackwardPlan:
             dx.mul_(last["in_scale"][:, None, None])
         return dx
 
-    def run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True, on_bucket=None, bucket_elems: int = 4 << 20,
-            tail_fill=None, want_dx: bool = False):
+    def run(self, *args, **kw):
+        """The reverse sweep (``_run``).  TQDNE_BWD_HIPRIO=1 (experiment, round 6): the sweep's chain -- data gradients, GroupNorm backward,
+        column sums -- runs on a HIGH-priority stream while the weight gradients stay on the normal-priority side stream, so that the
+        chain's small launches are dispatched ahead of the weight gradients' pending workgroups instead of queueing behind them (under
+        rocprofv3 a `gn_bwd_finalize` launch takes 33-43 us next to a weight gradient and 8 us alone)."""
+        if BWD_HIPRIO and self._trace is None and BWD_STREAMS == 2 and not torch.cuda.is_current_stream_capturing():
+            from .engine import hiprio_stream
+            main_t = torch.cuda.current_stream(self.dev)
+            hp = hiprio_stream(self.dev)
+            hp.wait_stream(main_t)
+            with torch.cuda.stream(hp):
+                res = self._run(*args, **kw)
+            main_t.wait_stream(hp)
+            return res
+        return self._run(*args, **kw)
+
+    def _run(self, dpred: torch.Tensor, gloss: torch.Tensor, clone: bool = True, on_bucket=None, bucket_elems: int = 4 << 20,
+             tail_fill=None, want_dx: bool = False):
         """``want_dx``: also form d loss / d x of the forward's input; left in ``self.last_dx`` (B, C_in, T).
         ``on_bucket(flat_slice)``: called from inside the sweep, right after the launch that finalises the last gradient of
         each bucket of >= ``bucket_elems`` floats has been enqueued (buckets = contiguous slices of the flat buffer in the
