@@ -1138,19 +1138,32 @@ class SeqEngine(UNetEngine):
                 d.flags &= ~TQ_CONV_DROPOUT
         self._last = dict(x=x, train=train, dropout_p=p, dropout_seed=dropout_seed, block_kv=self._block_kv)
         stem = m.input_layer
+        trace = None if torch.cuda.is_current_stream_capturing() else self._trace   # (measurement only: HIP events around every launch)
+        ev = _recorded_event if trace is not None else None
+        e0 = ev() if ev else None
         check(lib.tq_stem_conv_fwd(_p(x), None, _p(stem.weight), _p(stem.bias), _p(self.stem_out.buf), _p(self.stem_out.stats), B,
                                    m.in_channels, T, stem.out_channels, stem.kernel_size[0], stream), "input layer")
-        for fn, args, what, _ in self.ops:
+        if ev:
+            trace.append(("input layer", 2 * B * T * m.in_channels * stem.out_channels * stem.kernel_size[0],
+                          4 * B * T * (m.in_channels + stem.out_channels), e0, ev()))
+        for i, (fn, args, what, fl) in enumerate(self.ops):
+            a = ev() if ev else None
             rc = fn(*args, stream)
+            if ev:
+                trace.append((what, fl, self.op_bytes[i], a, ev()))
             if rc:
                 check(rc, what)
         out = m.output_layer
+        e0 = ev() if ev else None
         if self.out_mode == "head":
             check(lib.tq_head_conv_fwd(_p(self.final.buf), None, None, _p(out.weight), _p(out.bias), None, None, None,
                                        _p(self.out_nct), B, self.final.T, self.final.C, out.out_channels, out.kernel_size[0],
                                        stream), "output layer")
         else:
             self.out_nct.copy_(self.out_btc.buf.permute(0, 2, 1))  # (B,T,C) -> (B,C,T): 1/60 of the encoder's traffic
+        if ev:
+            trace.append(("output layer" if self.out_mode == "head" else "output layout flip", 2 * B * self.final.T * self.final.C * out.out_channels
+                          * out.kernel_size[0] if self.out_mode == "head" else 0, 4 * B * self.final.T * (self.final.C + out.out_channels), e0, ev()))
         self._mark_use(stream)
         return self.out_nct
 
