@@ -804,16 +804,33 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2 && SCH == 0) ?
             __syncthreads();   // the coefficients (global) are read back by other threads; the LDS scratch becomes the staging buffers
         }
     }
+    // ... and for the default tiles of the fp16 + MX-fp6 scheme (TBW == 8; experiment, TQDNE_GN_FOLD=1): the fold runs AFTER the first
+    // chunk's staging loads and the first weight fragments have been requested (gtab_store below), so that its statistics loads share
+    // their round trip, and leaves the coefficients in the LDS table directly -- what it adds to a workgroup is its arithmetic and three
+    // barriers, not a global round trip.
+    constexpr bool FOLD_LATE = SCH == 2 && ACT >= 1 && !PW && EPI == 0 && TBW == 8;
+    const bool fold_late = FOLD_LATE && p.cf_st0 != nullptr;
     float4 gt_a = make_float4(0.f, 0.f, 0.f, 0.f), gt_s = gt_a;
     int gt_i = 0;
     if constexpr (SCH == 2 && ACT >= 1) {
         const int n4 = Cin >> 2;
         gt_i = tid < n4 ? tid : n4 - 1;
-        gt_a = reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin)[gt_i];
-        gt_s = reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin)[gt_i];
+        if (!fold_late) {
+            gt_a = reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin)[gt_i];
+            gt_s = reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin)[gt_i];
+        }
     }
     auto gtab_store = [&]() __attribute__((always_inline)) {
         if constexpr (SCH == 2 && ACT >= 1) {
+            if constexpr (FOLD_LATE) {
+                if (fold_late) {   // (uniform over the launch)
+                    gn_fold_sample<false, false>(reinterpret_cast<double*>(lds), b, p.cf_st0, p.C0, p.cf_st1, p.C1, p.T_in, p.cf_ns0, p.cf_ns1,
+                                                 p.cf_gamma, p.cf_beta, const_cast<float*>(p.gscale), const_cast<float*>(p.gshift), p.cf_mean_rstd,
+                                                 gtab, gtab + Cin);
+                    __syncthreads();   // table complete; the scratch at the start of LDS becomes staging buffer 0
+                    return;
+                }
+            }
             float4* g4 = reinterpret_cast<float4*>(gtab);
             g4[gt_i] = gt_a;
             g4[(Cin >> 2) + gt_i] = gt_s;
@@ -1409,7 +1426,8 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS_BYTES = (PW ? 4 * C::BUF : C::LDS_BYTES) + GTAB_MAX;
     if (SCH == 2 && a.C0 + a.C1 > 1024) return TQ_ERR_SHAPE;
     if (a.cf_st0) {   // consumer-side GroupNorm fold: built into the small tile's forward launches; its scratch (2 C + 64 doubles) must fit the staging buffers
-        if (!(TBW == 2 && ACT >= 1 && !PW && EPI == 0) || (size_t)(2 * (a.C0 + a.C1) + 64) * sizeof(double) > (size_t)LDS_BYTES) return TQ_ERR_SHAPE;
+        constexpr bool built = (TBW == 2 && ACT >= 1 && !PW && EPI == 0) || (SCH == 2 && ACT >= 1 && !PW && EPI == 0 && TBW == 8);
+        if (!built || (size_t)(2 * (a.C0 + a.C1) + 64) * sizeof(double) > (size_t)LDS_BYTES) return TQ_ERR_SHAPE;
     }
     // The dynamic-LDS limit is a per-device property of the kernel: remember, per device ordinal, that it has been raised
     // (idempotent call: two threads racing here both set the same value; the mask only saves the repeated runtime call).

@@ -120,7 +120,8 @@ static int conv1d_fwd_impl(const TqConvDesc* d, const float* x0, const float* x1
     a.cf_st0 = a.cf_st1 = a.cf_gamma = a.cf_beta = nullptr; a.cf_mean_rstd = nullptr; a.cf_ns0 = a.cf_ns1 = 0;
     if (d->gn_fold) {   // consumer-side GroupNorm fold (ABI 7): this launch forms its own folded coefficients (see TqGnFold)
         const TqGnFold* f = d->gn_fold;
-        if (!(d->flags & TQ_CONV_GN) || a.t_tile != 32 || kv_planes || d->gn_fuse) return TQ_ERR_SHAPE;
+        // built for the small tile, and (experiment) for the default tiles of the fp16 + MX-fp6 scheme -- the dispatcher refuses the rest
+        if (!(d->flags & TQ_CONV_GN) || kv_planes || d->gn_fuse || (a.t_tile != 32 && d->wfmt != TQ_WFMT_F16_MX6)) return TQ_ERR_SHAPE;
         if (!f->stats0 || !f->gamma || !f->beta || (d->C_in1 > 0 && !f->stats1)) return TQ_ERR_ARG;
         const int s0 = f->slot0 ? f->slot0 : STAT_SLOT, s1 = f->slot1 ? f->slot1 : STAT_SLOT;
         if ((s0 != STAT_SLOT && s0 != 32) || (s1 != STAT_SLOT && s1 != 32)) return TQ_ERR_ARG;

@@ -28,7 +28,10 @@ template <bool COH0, bool COH1>
 __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* __restrict__ st0, int C0, const float* __restrict__ st1,
                                                int C1, int T, int nslots0, int nslots1, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, float* __restrict__ gscale,
-                                               float* __restrict__ gshift, float* __restrict__ mean_rstd) {
+                                               float* __restrict__ gshift, float* __restrict__ mean_rstd,
+                                               float* lds_scale = nullptr, float* lds_shift = nullptr) {
+    // lds_scale / lds_shift (optional, C floats each, outside ``sh``): the coefficients of this sample ALSO go to these LDS tables (the
+    // consuming conv's prologue reads them from there instead of a global round trip behind the stores below)
     // Latency-bound (a few KB per sample): three dependent steps, so every global load is issued as early as possible -- a thread's
     // slot loads all together before the first add.
     const int C = C0 + C1;
@@ -115,8 +118,10 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
                 const int g = c / G;
                 const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
                 const float a = gam[j] * rstd;
+                const float sft = fmaf(-mean, a, bet[j]);   // (explicit: the same rounding in every kernel this is inlined into)
                 gscale[(size_t)b * C + c] = a;
-                gshift[(size_t)b * C + c] = fmaf(-mean, a, bet[j]);   // (explicit: the same rounding in every kernel this is inlined into)
+                gshift[(size_t)b * C + c] = sft;
+                if (lds_scale) { lds_scale[c] = a; lds_shift[c] = sft; }
             }
         }
         return;
@@ -125,8 +130,10 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
         const int g = c / G;
         const float mean = (float)gstat[2 * g], rstd = (float)gstat[2 * g + 1];
         const float a = gamma[c] * rstd;
+        const float sft = fmaf(-mean, a, beta[c]);
         gscale[(size_t)b * C + c] = a;
-        gshift[(size_t)b * C + c] = fmaf(-mean, a, beta[c]);
+        gshift[(size_t)b * C + c] = sft;
+        if (lds_scale) { lds_scale[c] = a; lds_shift[c] = sft; }
     }
 }
 

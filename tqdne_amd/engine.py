@@ -37,6 +37,11 @@ def require_device(x: torch.Tensor):
         raise TypeError("tqdne_amd expects fp32 tensors at the boundary, like the reference (precision 32)")
 
 
+def _noop_launch(*_args):
+    """stands where a launch was planned that another launch has absorbed (returns the C ABI's success code)"""
+    return 0
+
+
 def nslots(T: int) -> int:
     return (T + STAT_SLOT - 1) // STAT_SLOT
 
@@ -85,6 +90,8 @@ SMALL_TILE_WGS = int(os.environ.get("TQDNE_SMALL_TILE_WGS", "64")) if os.environ
 # Round 6: a small-tile conv folds its own GroupNorm (TqConvDesc.gn_fold, consumer side) instead of a tq_gn_finalize launch in front of it:
 # a plan of <= 4 samples is ~100 dependent launches of 5-30 us, and 45 % of them were these.  TQDNE_GN_FOLD_SMALL=0: the launches.
 GN_FOLD_SMALL = os.environ.get("TQDNE_GN_FOLD_SMALL", "1") != "0"
+# ... and (experiment) the default tiles of the fp16 + MX-fp6 scheme, with the fold behind the first chunk's loads: TQDNE_GN_FOLD=1
+GN_FOLD_DEFAULT = os.environ.get("TQDNE_GN_FOLD", "0") == "1"
 CONCURRENT_LANE0 = 8   # plan-cache lane ids from here on: sub-batch plans that run concurrently (see UNetModel._engine)
 
 
@@ -479,7 +486,16 @@ class UNetEngine:
         pend = getattr(self, "_pending_gn", None)
         if pend is not None and gn is not None and pend["key"] == gn[0].data_ptr():
             self._pending_gn = None
-            if small and launch and GN_FOLD_SMALL and not self.ckpt and not GN_FUSE:
+            fold_default = (GN_FOLD_DEFAULT and not small and k5_act and wfmt == _lib.TQ_WFMT_F16_MX6 and self.scheme == "auto"
+                            and getattr(self.m, "_conv_scheme", "auto") == "auto")
+            if fold_default and launch and not self.ckpt and not GN_FUSE:
+                # the tq_gn_finalize launch stays in the plan as a no-op: the range-guard fallback moves this conv to the three-product
+                # scheme, whose default tiles do not fold -- it then gets its launch back (_set_scheme_bf16x3)
+                fn, fargs, fname, ffl = pend["fin"][0]
+                self._fold_default_ops = getattr(self, "_fold_default_ops", [])
+                self._fold_default_ops.append((len(self.ops), fn, d))
+                self._emit((_noop_launch, fargs, fname + " (folded into its consumer)", ffl), nbytes=0)
+            if launch and ((small and GN_FOLD_SMALL) or fold_default) and not self.ckpt and not GN_FUSE:
                 f = _lib.TqGnFold()
                 ps0, ps1 = pend["srcs"]
                 f.stats0, f.stats1 = _p(ps0.stats), (_p(ps1.stats) if ps1 is not None else None)
@@ -783,6 +799,12 @@ class UNetEngine:
             d.wfmt = _lib.TQ_WFMT_BF16X3
             for st in sites:
                 st.pack_mode = 0
+        for i, fn, d in getattr(self, "_fold_default_ops", ()):   # default-tile convs that folded their own GroupNorm get the launch back
+            for ops in (self.ops, self.ops_infer):
+                _f, a_, w_, fl_ = ops[i]
+                ops[i] = (fn, a_, "gn_finalize", fl_)
+            d.gn_fold = None
+        self._fold_default_ops = []
         if getattr(self, "emb_desc", None) is not None:
             self.emb_desc.wfmt = _lib.TQ_WFMT_BF16X3
             self.emb_pack_mode = 0
