@@ -665,11 +665,17 @@ def test_conv_small_tile_folds_its_own_group_norm(cin0, cin1, cout, T, wf, slots
     y, s_ = ops.conv1d(x0, w, b, gscale=a, gshift=h, gn_fold=(st0, st1, slots[0], slots[1], gam, bet, m), **kw)
     assert torch.equal(a, a_ref) and torch.equal(h, h_ref) and torch.equal(m, m_ref)
     assert torch.equal(y, y_ref) and torch.equal(s_, s_ref)
-    # the default tiles are not built for it: refused, nothing launched
-    import ctypes as Ct
     from tqdne_amd import _lib
-    with pytest.raises(_lib.TqError, match="TQ_ERR_SHAPE"):
-        ops.conv1d(x0, w, b, gscale=a, gshift=h, gn_fold=(st0, st1, slots[0], slots[1], gam, bet, m), **dict(kw, t_tile=0))
+    if wf == _lib.TQ_WFMT_F16_MX6:
+        # the default tiles of the fp16 + MX-fp6 scheme fold too (behind the first chunk's loads, coefficients straight into the LDS table)
+        a2, h2, m2 = torch.full_like(a_ref, nan), torch.full_like(h_ref, nan), torch.full_like(m_ref, nan)
+        y_ref0, s_ref0 = ops.conv1d(x0, w, b, gscale=a_ref, gshift=h_ref, **dict(kw, t_tile=0))
+        y2, s2 = ops.conv1d(x0, w, b, gscale=a2, gshift=h2, gn_fold=(st0, st1, slots[0], slots[1], gam, bet, m2), **dict(kw, t_tile=0))
+        assert torch.equal(a2, a_ref) and torch.equal(h2, h_ref) and torch.equal(m2, m_ref)
+        assert torch.equal(y2, y_ref0) and torch.equal(s2, s_ref0)
+    else:   # the three-product scheme's default tiles are not built for it: refused, nothing launched
+        with pytest.raises(_lib.TqError, match="TQ_ERR_SHAPE"):
+            ops.conv1d(x0, w, b, gscale=a, gshift=h, gn_fold=(st0, st1, slots[0], slots[1], gam, bet, m), **dict(kw, t_tile=0))
 
 
 def test_conv_small_tile_refuses_what_it_is_not_built_for():
