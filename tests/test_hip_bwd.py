@@ -99,6 +99,54 @@ def test_wgrad_fused_prologue_concat():
     assert rel_err(dw.cpu(), w.grad) < TOL
 
 
+@pytest.mark.parametrize("C0,C1,k,T,B", [(64, 0, 5, 4096, 2), (128, 64, 5, 333, 3), (64, 64, 3, 127, 2), (192, 0, 5, 65, 5), (64, 0, 5, 31, 1)])
+def test_wgrad_64_output_channels_four_wave_form(C0, C1, k, T, B):
+    """Round 6: convs with exactly 64 output channels (the paper UNet's T = 4096 level) take the four-wave form of the shared-tile
+    kernel (2 output-channel blocks x 2 halves of a 64-channel input tile) instead of half-filling the 128-channel tile: with the
+    fused prologue (GroupNorm scale / shift, SiLU, dropout), a concat source, ragged lengths; same numbers as the 128-channel form."""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(C0 + C1 + k + T)
+    Co = 64
+    x0 = torch.randn(B, C0, T, generator=g)
+    x1 = torch.randn(B, C1, T, generator=g) if C1 else None
+    a, s = torch.randn(B, C0 + C1, generator=g), torch.randn(B, C0 + C1, generator=g)
+    w = (torch.randn(Co, C0 + C1, k, generator=g) / math.sqrt((C0 + C1) * k)).requires_grad_(True)
+    dy = torch.randn(B, Co, T, generator=g)
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    F.conv1d(F.silu(x * a[:, :, None] + s[:, :, None]), w, None, padding=k // 2).backward(dy)
+    d = dev()
+    kw = dict(x1=cl(x1) if C1 else None, gscale=a.to(d), gshift=s.to(d), silu=True)
+    dw = ops.conv1d_bwd_weight(cl(dy), cl(x0), w.shape, **kw)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+    # dropout in the prologue: the same mask in both forms (the element index does not depend on the tiling)
+    dwd = ops.conv1d_bwd_weight(cl(dy), cl(x0), w.shape, dropout_p=0.25, dropout_seed=77, dropout_site=3, **kw)
+    # with fused column sums the launch takes the four-wave kernel of 128 output channels: the reference form for the new one
+    bc, c1 = torch.zeros(B, Co, device=d), torch.ones(Co, device=d)
+    dw4 = ops.conv1d_bwd_weight(cl(dy), cl(x0), w.shape, colsum=(bc, c1), **kw)
+    dwd4 = ops.conv1d_bwd_weight(cl(dy), cl(x0), w.shape, dropout_p=0.25, dropout_seed=77, dropout_site=3,
+                                 colsum=(torch.zeros(B, Co, device=d), None), **kw)
+    assert rel_err(dw4.cpu(), w.grad) < TOL
+    assert rel_err(dw.cpu(), dw4.cpu()) < 1e-5 and rel_err(dwd.cpu(), dwd4.cpu()) < 1e-5
+    assert float((dwd - dw).norm() / dw.norm()) > 1e-2    # (the mask did something)
+    assert rel_err(bc.cpu(), dy.sum(-1)) < 1e-5 and rel_err(c1.cpu(), 1 + dy.sum((0, 2))) < 1e-5
+
+
+def test_wgrad_with_fused_column_sums_on_a_shape_of_the_eight_wave_form():
+    """a launch that carries column sums plans AND runs the four-wave kernel (the plan used to be made for the eight-wave form)"""
+    from tqdne_amd import ops
+    g = torch.Generator().manual_seed(19)
+    B, Ci, Co, T = 3, 128, 128, 200
+    x = torch.randn(B, Ci, T, generator=g)
+    w = (torch.randn(Co, Ci, 5, generator=g) / 25).requires_grad_(True)
+    dy = torch.randn(B, Co, T, generator=g)
+    F.conv1d(x, w, None, padding=2).backward(dy)
+    d = dev()
+    bc, c1 = torch.zeros(B, Co, device=d), torch.zeros(Co, device=d)
+    dw = ops.conv1d_bwd_weight(cl(dy), cl(x), w.shape, colsum=(bc, c1))
+    assert rel_err(dw.cpu(), w.grad) < TOL
+    assert rel_err(bc.cpu(), dy.sum(-1)) < 1e-5 and rel_err(c1.cpu(), dy.sum((0, 2))) < 1e-5
+
+
 @pytest.mark.parametrize("C,T", [(64, 256), (128, 251), (32, 130)])
 def test_downsample_backward(C, T):
     from tqdne_amd import ops

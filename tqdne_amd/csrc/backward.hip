@@ -96,17 +96,24 @@ __device__ __forceinline__ int wg_x_swz256(int row) { return ((row & 3) << 5) | 
 // halves of a 64-channel xhat tile (accumulators as NCI = 1: 80 registers at k = 5, where the 64-channel chunk in ONE wave -- NCI = 2,
 // 160 registers -- spilled).  Every dy element is then fetched from L2, split and stored to LDS C_in / 64 instead of C_in / 32 times:
 // the kernel was moving ~6 TB/s from L2 at 38 % MFMA-busy (667 MB per 256 -> 256, k = 5 launch).
-template <int KT, int STRIDE, int UPS, int NCI, bool W8 = false>
-__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const WgArgs p) {
+// H64 (round 6): the W8 layout for convs with 64 output channels, in FOUR waves: 2 blocks of 32 output channels x the two 32-channel
+// halves of the 64-channel xhat tile, a 64-row x 64-channel dy tile, two workgroups per CU.  In the 128-channel tile of the other forms
+// such a conv leaves every second wave without matrix work (wave_active) while the whole workgroup still stages, splits and stores a
+// dy tile that is half zeros, and it re-stages dy once per 32 input channels.
+template <int KT, int STRIDE, int UPS, int NCI, bool W8 = false, bool H64 = false>
+__global__ __launch_bounds__((W8 && !H64) ? 512 : 256, (W8 && !H64) ? 1 : 2) void wgrad_kernel(const WgArgs p) {
     static_assert(!W8 || NCI == 1, "W8: per-wave accumulators of a 32-channel chunk");
-    constexpr int NT = W8 ? 512 : 256;
+    static_assert(!H64 || W8, "H64: the W8 layout (two 32-channel halves of one xhat tile) with two output-channel blocks");
+    constexpr int NT = (W8 && !H64) ? 512 : 256;
+    constexpr int COT = H64 ? 64 : 128;      // output channels of the workgroup's dy tile
+    constexpr int DYC4 = COT / 4;            // float4 columns of the dy tile
     constexpr int NCX = W8 ? 2 : NCI;        // width of the staged xhat tile in 32-channel units
     constexpr int PAD = (STRIDE == 1) ? KT / 2 : 1;
     constexpr int XR = (STRIDE == 1) ? (WG_TT + KT - 1) : (2 * WG_TT + 1);
     constexpr int WG_X_STRIDE = 64 * NCX;    // bytes per xhat image row (32 NCX ci * 2 B)
     constexpr int XC4 = 8 * NCX;             // float4 columns of the xhat tile
     constexpr int XIT = (XR * XC4 + NT - 1) / NT;
-    constexpr int DYIT = 2048 / NT;          // float4 of the 64 x 128 dy tile per thread
+    constexpr int DYIT = WG_TT * DYC4 / NT;  // float4 of the 64 x COT dy tile per thread
     static_assert(NCI != 4 || (KT == 1 && STRIDE == 1 && !UPS), "128-channel chunks: the 1x1 convs");
     constexpr int WG_DY_STRIDE = (NCI == 1 || NCI == 4) ? WG_DY_STRIDE1 : WG_DY_STRIDE2;
     constexpr int DY_PLANE = WG_TT * WG_DY_STRIDE;
@@ -119,8 +126,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = W8 ? (wave_id & 3) : wave_id;   // 32-channel block of the 128 output channels
-    const int wci = W8 ? (wave_id >> 2) : 0;         // W8: which 32-channel half of the xhat tile
+    const int wave = H64 ? (wave_id & 1) : (W8 ? (wave_id & 3) : wave_id);   // 32-channel block of the COT output channels
+    const int wci = H64 ? (wave_id >> 1) : (W8 ? (wave_id >> 2) : 0);        // W8 / H64: which 32-channel half of the xhat tile
     // Workgroups are dealt round-robin over the 8 XCDs (ids i and i + 8 share an L2).  The input-channel-chunk workgroups of one
     // (split, co-tile) pair all stage the same dy tile: keep a pair on ONE XCD, so its L2 serves the re-reads (with the plain
     // order every XCD fetched every dy tile: 404 MB from HBM for 134 MB of operands, 57 % L2 misses).
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
             sp = bid / (p.n_cotiles * p.n_cichunks);
         }
     }
-    const int co0 = ct * 128;
+    const int co0 = ct * COT;
     const int cb = cc * 32 * NCX;
     const int Cin = p.C0 + p.C1;
     const int T_src = UPS ? 2 * p.T_in : p.T_in;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
     const int u_begin = sp * p.units_per_split;
     const int u_end = min(U, u_begin + p.units_per_split);
     const bool wave_active = (co0 + wave * 32) < p.C_out;
-    const int cvalid4 = min(128, p.C_out - co0) >> 2;  // float4 columns of dy actually present
+    const int cvalid4 = min(COT, p.C_out - co0) >> 2;  // float4 columns of dy actually present
 
     // xhat source (one concat source per 32-channel chunk)
     const float* xsrc; int xcs, xoff;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
 #pragma unroll
         for (int it = 0; it < DYIT; ++it) {
             const int task = tid + it * NT;
-            const int row = task >> 5, c4 = task & 31;
+            const int row = task / DYC4, c4 = task & (DYC4 - 1);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t0 + row < p.T_out && c4 < cvalid4) v = *reinterpret_cast<const float4*>(dyb + (size_t)(t0 + row) * p.C_out + 4 * c4);
             dyr[it] = v;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
             float4 a4 = dyr[0];
 #pragma unroll
             for (int it = 1; it < DYIT; ++it) { a4.x += dyr[it].x; a4.y += dyr[it].y; a4.z += dyr[it].z; a4.w += dyr[it].w; }
-            float* dst = cs_lds + 4 * (tid & 31);
+            float* dst = cs_lds + 4 * (tid & (DYC4 - 1));
             atomicAdd(dst, a4.x); atomicAdd(dst + 1, a4.y); atomicAdd(dst + 2, a4.z); atomicAdd(dst + 3, a4.w);
         }
 #ifdef TQ_ABL_NODY
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void wgrad_kernel(const
 #pragma unroll
         for (int it = 0; it < DYIT; ++it) {
             const int task = tid + it * NT;
-            const int row = task >> 5, c4 = task & 31;
+            const int row = task / DYC4, c4 = task & (DYC4 - 1);
             const float v[4] = {dyr[it].x, dyr[it].y, dyr[it].z, dyr[it].w};
             bf16x4 h, l;
 #pragma unroll
@@ -511,6 +518,14 @@ bool wgrad_w8(const TqConvDesc* d) {
     return d->C_in0 % 64 == 0 && d->C_in1 % 64 == 0 && d->C_out % 128 == 0;
 }
 
+// The four-wave form of the W8 layout for convs with exactly 64 output channels (H64, see wgrad_kernel): k = 3 / k = 5, stride 1, sources
+// made of whole 64-channel chunks; TQDNE_WGRAD_H64=0 keeps the 128-channel tile for them (A/B switch).
+bool wgrad_h64(const TqConvDesc* d) {
+    static const int sw = [] { const char* e = getenv("TQDNE_WGRAD_H64"); return e ? atoi(e) : 1; }();
+    if (!sw || d->ktaps == 1 || d->stride != 1 || d->upsample) return false;
+    return d->C_in0 % 64 == 0 && d->C_in1 % 64 == 0 && d->C_out == 64;
+}
+
 // Workgroups of the weight-gradient kernel the device holds at once (occupancy of the instantiation x compute units), per
 // (taps, stride, upsample, chunk width); queried once.  The (b, t) reduction is split over as many workgroups as fill ONE
 // residency round: with the former fixed target of 768 the paper UNet's launches were 1.46 rounds of 512 resident workgroups
@@ -522,16 +537,16 @@ size_t wgrad_lds(int nci, bool w8) {
     return 2 * WG_TT * ((nci == 1 || nci == 4) ? WG_DY_STRIDE1 : WG_DY_STRIDE2) + 2 * XR * 64 * ncx + 128 * sizeof(float);   // (+ the fused column sums)
 }
 
-template <int KT, int STRIDE, int UPS, int NCI, bool W8>
+template <int KT, int STRIDE, int UPS, int NCI, bool W8, bool H64 = false>
 int wgrad_slots_of() {
     static const int slots = [] {
         const size_t sh = wgrad_lds<KT, STRIDE, UPS>(NCI, W8);
         int per_cu = 0, dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_kernel<KT, STRIDE, UPS, NCI, W8>, W8 ? 512 : 256, sh) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_kernel<KT, STRIDE, UPS, NCI, W8, H64>, (W8 && !H64) ? 512 : 256, sh) != hipSuccess ||
             per_cu < 1 || cus < 1) {
             (void)hipGetLastError();
-            return W8 ? 256 : 512;   // (no device: what __launch_bounds__ asks for on MI355X's 256 compute units)
+            return (W8 && !H64) ? 256 : 512;   // (no device: what __launch_bounds__ asks for on MI355X's 256 compute units)
         }
         return per_cu * cus;
     }();
@@ -539,7 +554,10 @@ int wgrad_slots_of() {
 }
 
 template <int KT, int STRIDE, int UPS>
-int wgrad_slots_k(int nci, bool w8) {
+int wgrad_slots_k(int nci, bool w8, bool h64 = false) {
+    if constexpr (KT != 1 && STRIDE == 1 && UPS == 0) {
+        if (h64) return wgrad_slots_of<KT, STRIDE, UPS, 1, true, true>();
+    }
     if (w8) return wgrad_slots_of<KT, STRIDE, UPS, 1, true>();
     if constexpr (KT == 1 && STRIDE == 1 && UPS == 0) {
         if (nci == 4) return wgrad_slots_of<KT, STRIDE, UPS, 4, false>();
@@ -547,24 +565,27 @@ int wgrad_slots_k(int nci, bool w8) {
     return nci == 2 ? wgrad_slots_of<KT, STRIDE, UPS, 2, false>() : wgrad_slots_of<KT, STRIDE, UPS, 1, false>();
 }
 
-int wgrad_slots(const TqConvDesc* d, int nci, bool w8) {
+int wgrad_slots(const TqConvDesc* d, int nci, bool w8, bool h64) {
     if (d->stride == 2) return wgrad_slots_k<3, 2, 0>(nci, w8);
     if (d->upsample) return d->ktaps == 5 ? wgrad_slots_k<5, 1, 1>(nci, w8) : wgrad_slots_k<3, 1, 1>(nci, w8);
-    if (d->ktaps == 5) return wgrad_slots_k<5, 1, 0>(nci, w8);
-    if (d->ktaps == 3) return wgrad_slots_k<3, 1, 0>(nci, w8);
+    if (d->ktaps == 5) return wgrad_slots_k<5, 1, 0>(nci, w8, h64);
+    if (d->ktaps == 3) return wgrad_slots_k<3, 1, 0>(nci, w8, h64);
     return wgrad_slots_k<1, 1, 0>(nci, false);
 }
 
-void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_ttiles, int& nsplit, int& ups) {
+// ``wide``: the forms with a 64-channel xhat tile shared by two groups of waves (W8, H64) are allowed; the fused column sums are not
+// built into them, so a launch that carries column sums plans -- and runs -- the four-wave kernel of 128 output channels
+void wgrad_plan(const TqConvDesc* d, bool wide, int& n_cotiles, int& n_cichunks, int& n_ttiles, int& nsplit, int& ups) {
     const int nci = wgrad_nci(d);
-    const bool w8 = wgrad_w8(d);
-    n_cotiles = (d->C_out + 127) / 128;
+    const bool h64 = wide && wgrad_h64(d);
+    const bool w8 = wide && (h64 || wgrad_w8(d));
+    n_cotiles = h64 ? 1 : (d->C_out + 127) / 128;
     n_cichunks = (d->C_in0 + d->C_in1) / (32 * (w8 ? 2 : nci));
     n_ttiles = (d->T_out + WG_TT - 1) / WG_TT;
     const int U = d->B * n_ttiles;
     const int ntiles = n_cotiles * n_cichunks;
     static const int forced = [] { const char* e = getenv("TQDNE_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();   // (A/B switch)
-    const int slots = forced > 0 ? forced : wgrad_slots(d, nci, w8);
+    const int slots = forced > 0 ? forced : wgrad_slots(d, nci, w8, h64);
     int want = slots / ntiles;   // splits per output tile: the grid fills one round of resident workgroups, not more
     if (want < 1) want = 1;
     if (want > U) want = U;
@@ -573,10 +594,16 @@ void wgrad_plan(const TqConvDesc* d, int& n_cotiles, int& n_cichunks, int& n_tti
 }
 
 template <int KT, int STRIDE, int UPS>
-int launch_wgrad(const WgArgs& a, int nci, bool w8, hipStream_t stream) {
-    const size_t sh = wgrad_lds<KT, STRIDE, UPS>(nci, w8);
+int launch_wgrad(const WgArgs& a, int nci, bool w8, bool h64, hipStream_t stream) {
+    const size_t sh = wgrad_lds<KT, STRIDE, UPS>(nci, w8 || h64);
     const unsigned grid = (unsigned)(a.n_cotiles * a.n_cichunks * a.nsplit);
-    if (w8) {
+    if (h64) {
+        if constexpr (KT != 1 && STRIDE == 1 && UPS == 0) {
+            hipLaunchKernelGGL((wgrad_kernel<KT, STRIDE, UPS, 1, true, true>), dim3(grid), dim3(256), sh, stream, a);   // (54 KB of LDS)
+        } else {
+            return TQ_ERR_SHAPE;
+        }
+    } else if (w8) {
         static const bool raised = [] {   // (the 8-wave form's LDS images exceed the 64 KB default of a dynamic allocation)
             return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<KT, STRIDE, UPS, 1, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
@@ -606,9 +633,10 @@ int launch_wgrad(const WgArgs& a, int nci, bool w8, hipStream_t stream) {
 
 extern "C" size_t tq_conv1d_bwd_weight_workspace(const TqConvDesc* d) {
     if (!d) return 0;
-    int a, b, c, nsplit, ups;
-    wgrad_plan(d, a, b, c, nsplit, ups);
-    return (size_t)nsplit * d->ktaps * d->C_out * (d->C_in0 + d->C_in1) * sizeof(float);
+    int a, b, c, nsplit, nsplit4, ups;   // (the larger of the two plans: with and without fused column sums)
+    wgrad_plan(d, true, a, b, c, nsplit, ups);
+    wgrad_plan(d, false, a, b, c, nsplit4, ups);
+    return (size_t)(nsplit > nsplit4 ? nsplit : nsplit4) * d->ktaps * d->C_out * (d->C_in0 + d->C_in1) * sizeof(float);
 }
 
 extern "C" int tq_conv1d_bwd_weight(const TqConvDesc* d, const float* dy, const float* x0, const float* x1,
@@ -632,7 +660,8 @@ extern "C" int tq_conv1d_bwd_weight_colsum(const TqConvDesc* d, const float* dy,
     a.B = d->B; a.T_in = d->T_in; a.T_out = d->T_out; a.C0 = d->C_in0; a.C1 = d->C_in1; a.C_out = d->C_out;
     a.flags = d->flags;
     a.cs_bc = colsum_bc; a.cs_stride = bc_stride; a.cs_c = colsum_c; a.cs_c2 = colsum_c2;
-    wgrad_plan(d, a.n_cotiles, a.n_cichunks, a.n_ttiles, a.nsplit, a.units_per_split);
+    const bool wide = !(colsum_bc || colsum_c);   // (the fused column sums live in the four-wave kernel of 128 output channels)
+    wgrad_plan(d, wide, a.n_cotiles, a.n_cichunks, a.n_ttiles, a.nsplit, a.units_per_split);
     static const bool plain_order = [] { const char* e = getenv("TQDNE_WGRAD_XCD"); return e && atoi(e) == 0; }();
     if (plain_order) a.flags |= TQ_WGRAD_PLAIN_ORDER;
     a.drop_site = d->dropout_site; a.drop_seed = d->dropout_seed;
@@ -642,19 +671,19 @@ extern "C" int tq_conv1d_bwd_weight_colsum(const TqConvDesc* d, const float* dy,
     a.drop_scale = 1.0f / (1.0f - pdrop);
     int rc;
     const int nci = wgrad_nci(d);
-    bool w8 = wgrad_w8(d);
-    if (w8 && (colsum_bc || colsum_c)) w8 = false;   // (the fused column sums live in the 4-wave kernel's epilogue; never both)
+    const bool h64 = wide && wgrad_h64(d);
+    const bool w8 = wide && !h64 && wgrad_w8(d);
     if (d->stride == 2) {
         if (d->ktaps != 3) return TQ_ERR_SHAPE;
-        rc = launch_wgrad<3, 2, 0>(a, nci, w8, stream);
+        rc = launch_wgrad<3, 2, 0>(a, nci, w8, false, stream);
     } else if (d->upsample) {
-        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 1>(a, nci, w8, stream);
-        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 1>(a, nci, w8, stream);
+        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 1>(a, nci, w8, false, stream);
+        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 1>(a, nci, w8, false, stream);
         else return TQ_ERR_SHAPE;
     } else {
-        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 0>(a, nci, w8, stream);
-        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 0>(a, nci, w8, stream);
-        else if (d->ktaps == 1) rc = launch_wgrad<1, 1, 0>(a, nci, false, stream);
+        if (d->ktaps == 5) rc = launch_wgrad<5, 1, 0>(a, nci, w8, h64, stream);
+        else if (d->ktaps == 3) rc = launch_wgrad<3, 1, 0>(a, nci, w8, h64, stream);
+        else if (d->ktaps == 1) rc = launch_wgrad<1, 1, 0>(a, nci, false, false, stream);
         else return TQ_ERR_SHAPE;
     }
     if (rc) return rc;

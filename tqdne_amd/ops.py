@@ -209,7 +209,9 @@ def conv1d_bwd_data(dy, weight, *, x0=None, x1=None, gscale=None, gshift=None, s
 
 
 def conv1d_bwd_weight(dy, x0, wshape, *, x1=None, gscale=None, gshift=None, silu=False, stride=1, upsample=False,
-                      dropout_p=0.0, dropout_seed=0, dropout_site=0):
+                      dropout_p=0.0, dropout_seed=0, dropout_site=0, colsum=None):
+    """weight gradient; ``colsum`` = (per-sample sums (B, C_out) | None, per-channel sums (C_out,) | None): column sums of dy ACCUMULATED
+    into those tensors by the same launch (tq_conv1d_bwd_weight_colsum)"""
     lib = _lib.load()
     B, T_in, C0 = x0.shape
     C1 = 0 if x1 is None else x1.shape[2]
@@ -229,6 +231,12 @@ def conv1d_bwd_weight(dy, x0, wshape, *, x1=None, gscale=None, gshift=None, silu
     d.dropout_site, d.dropout_p, d.dropout_seed = dropout_site, dropout_p, dropout_seed
     ws = torch.empty(lib.tq_conv1d_bwd_weight_workspace(C.byref(d)), dtype=torch.uint8, device=dy.device)
     dw = torch.empty(C_out, C_in, K, device=dy.device)
+    if colsum is not None:
+        bc, c1 = colsum
+        check(lib.tq_conv1d_bwd_weight_colsum(C.byref(d), _p(dy), _p(x0), _p(x1), _p(gscale), _p(gshift), _p(dw), _p(ws), ws.numel(),
+                                              _p(bc), C_out if bc is not None else 0, _p(c1), None, _stream(dy.device)),
+              "conv1d_bwd_weight_colsum")
+        return dw
     check(lib.tq_conv1d_bwd_weight(C.byref(d), _p(dy), _p(x0), _p(x1), _p(gscale), _p(gshift), _p(dw), _p(ws), ws.numel(),
                                    _stream(dy.device)), "conv1d_bwd_weight")
     return dw
