@@ -322,6 +322,30 @@ def test_attention(H, D, T):
     assert rel_err(ncw(out1), ref) < TOL
 
 
+@pytest.mark.parametrize("B,H,T", [(4, 1, 512), (5, 1, 512), (2, 2, 333), (1, 1, 65)])
+def test_attention_key_split_for_grids_far_below_the_chip(B, H, T):
+    """Round 6: with one head of 128 channels and a handful of samples (the tiny config's middle block at B = 4) the first-generation
+    kernel's grid is 32 workgroups walking 8 key tiles each; given the workspace it deals the key tiles over up to 8 workgroups per
+    query tile (even and uneven splits, a ragged last tile) and a combine launch merges the partial rows.  Output and log-sum-exp
+    against the unsplit launch and the reference, on scores with a peaked row distribution (the splits' maxima differ by tens)."""
+    from tqdne_amd import ops
+    D = 128
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = torch.randn(B, 3 * H * D, T, generator=g)
+    qkv[:, :2 * H * D] *= 2.5                      # q, k: score standard deviation ~ 6
+    qkv[:, H * D:2 * H * D, T // 3] *= 3.0         # one key far outside the others' range
+    out, lse = ops.attention(cl(qkv), H, return_lse=True)
+    out1, lse1 = ops.attention(cl(qkv), H, return_lse=True, workspace=False)
+    q, k, v = qkv.chunk(3, dim=1)
+    sc = 1 / math.sqrt(math.sqrt(D))
+    w = torch.einsum("bct,bcs->bts", (q * sc).reshape(B * H, D, T).double(), (k * sc).reshape(B * H, D, T).double())
+    ref = torch.einsum("bts,bcs->bct", torch.softmax(w, dim=-1), v.reshape(B * H, D, T).double()).reshape(B, -1, T).float()
+    assert rel_err(ncw(out), ref) < TOL and rel_err(ncw(out1), ref) < TOL
+    assert rel_err(ncw(out), ncw(out1)) < 2e-5
+    ref_lse = torch.logsumexp(w, dim=-1).reshape(B, H, T).float()
+    assert rel_err(lse.cpu(), ref_lse) < 1e-5 and rel_err(lse.cpu(), lse1.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("H,D,T,peaked", [(4, 64, 512, False), (2, 32, 190, False), (4, 64, 256, True), (1, 64, 64, False)])
 def test_qkv_conv_feeding_the_presplit_attention(H, D, T, peaked):
     """The inference pair of an AttentionBlock (blocks.py:127-190): tq_conv1d_fwd_qkv writes q as fp32 and K / V as the attention

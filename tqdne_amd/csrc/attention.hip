@@ -18,9 +18,13 @@ namespace {
 constexpr int QT = 64;   // queries per workgroup
 constexpr int KTILE = 64;  // keys per tile
 
+// Round 6: ``ksplit`` > 1 -- the key tiles of one (b, head, query tile) are dealt over ``ksplit`` workgroups, each leaving its
+// un-normalised output rows, running maxima and row sums in ``part``; attn_combine_kernel merges them.  For grids far below the chip
+// (the tiny config's middle block at B = 4: one head of 128 channels, 32 workgroups walking 8 key tiles each).
 template <int D>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                           float* __restrict__ lse, int T, int H, float scale) {
+                                                           float* __restrict__ lse, int T, int H, float scale, int ksplit,
+                                                           float* __restrict__ part) {
     constexpr int KS = D / 32;       // k-steps over the head dimension
     constexpr int CB = D / 16;       // output column blocks
     constexpr int KROW = D * 2 + 16;   // bytes per key row of the K image (padded)
@@ -36,7 +40,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nqt = (T + QT - 1) / QT;
-    int bid = xcd_group_id(blockIdx.x, nqt, gridDim.x / nqt);  // the tiles of one (b, h) share an XCD's L2
+    const int grp = nqt * ksplit;
+    int bid = xcd_group_id(blockIdx.x, grp, gridDim.x / grp);  // the tiles of one (b, h) share an XCD's L2
+    const int ksid = bid % ksplit; bid /= ksplit;
     const int qt = bid % nqt; bid /= nqt;
     const int h = bid % H;
     const int b = bid / H;
@@ -77,7 +83,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
 
     const int nkt = (T + KTILE - 1) / KTILE;
-    for (int kt = 0; kt < nkt; ++kt) {
+    const int kt_begin = ksid * nkt / ksplit, kt_end = (ksid + 1) * nkt / ksplit;   // (ksplit <= nkt: never empty)
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int s0 = kt * KTILE;
         __syncthreads();  // previous tile fully consumed
         // ---- stage K tile: thread -> (key = i / (D/4), 4 channels)
@@ -190,6 +197,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
             }
         }
     }
+    if (ksplit > 1) {   // ---- partial result: rows relative to this split's running maximum, with (m, l) behind them
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = q0 + 4 * (lane >> 4) + r;
+            if (q < T) {
+                float* pr = part + ((((size_t)b * H + h) * ksplit + ksid) * T + q) * (D + 4);   // (rows of D + 4 floats: 16-byte aligned)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) pr[cb * 16 + (lane & 15)] = o[cb][r];
+                if ((lane & 15) == 0) { pr[D] = m_run[r]; pr[D + 1] = l_run[r]; }
+            }
+        }
+        return;
+    }
     // ---- normalise and store
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -204,16 +224,63 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     }
 }
 
+// out[b, q, h D + c] = sum_s o_s[c] e^(m_s - M) / sum_s l_s e^(m_s - M), M = max_s m_s; one thread per (row, 4 channels)
 template <int D>
-int launch_attn(const float* qkv, float* out, float* lse, int B, int T, int H, hipStream_t stream) {
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ lse,
+                                                           int T, int H, int ksplit, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c4 = (int)(i % (D / 4));
+    size_t row = i / (D / 4);
+    const int q = (int)(row % T); row /= T;
+    const int h = (int)(row % H);
+    const int b = (int)(row / H);
+    const float* pr = part + ((((size_t)b * H + h) * ksplit) * T + q) * (D + 4);
+    const size_t stride = (size_t)T * (D + 4);
+    float M = -INFINITY;
+    for (int s = 0; s < ksplit; ++s) M = fmaxf(M, pr[s * stride + D]);
+    float L = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < ksplit; ++s) {
+        const float w = __expf(pr[s * stride + D] - M);
+        L += pr[s * stride + D + 1] * w;
+        const float4 o = *reinterpret_cast<const float4*>(pr + s * stride + 4 * c4);
+        acc.x += o.x * w; acc.y += o.y * w; acc.z += o.z * w; acc.w += o.w * w;
+    }
+    const float inv = 1.0f / L;
+    *reinterpret_cast<float4*>(out + ((size_t)b * T + q) * (H * D) + h * D + 4 * c4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    if (lse && c4 == 0) lse[((size_t)b * H + h) * T + q] = M + __logf(L);
+}
+
+constexpr int ATT_KSPLIT_MAX = 8;
+
+template <int D>
+int launch_attn(const float* qkv, float* out, float* lse, int B, int T, int H, hipStream_t stream, void* workspace = nullptr) {
     constexpr int KROW = D * 2 + 16, VROW = KTILE * 2 + 16, PROW = KTILE * 2 + 16;
     const size_t sh = 2 * KTILE * KROW + 2 * D * VROW + 4 * 2 * 16 * PROW;
     if (sh > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    const int nqt = (T + QT - 1) / QT;
+    const int nqt = (T + QT - 1) / QT, nkt = (T + KTILE - 1) / KTILE;
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));  // blocks.py:173 (python double, then fp32)
-    hipLaunchKernelGGL(attention_kernel<D>, dim3(B * H * nqt), dim3(256), sh, stream, qkv, out, lse, T, H, scale);
+    // key split (needs the workspace): where the grid would leave most of the chip idle -- under 128 workgroups for 256 compute units
+    // -- deal the key tiles over as many workgroups as bring it to ~256 (TQDNE_ATTN_KSPLIT: 1 = never, n = that many where allowed)
+    static const int forced = [] { const char* e = getenv("TQDNE_ATTN_KSPLIT"); return e ? atoi(e) : 0; }();
+    int ksplit = 1;
+    const int wgs = B * H * nqt;
+    if (workspace && (forced > 1 || (forced == 0 && wgs < 128))) {
+        ksplit = forced > 1 ? forced : 256 / wgs;
+        if (ksplit > nkt) ksplit = nkt;
+        if (ksplit > ATT_KSPLIT_MAX) ksplit = ATT_KSPLIT_MAX;
+        if (ksplit < 1) ksplit = 1;
+    }
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(attention_kernel<D>, dim3(wgs * ksplit), dim3(256), sh, stream, qkv, out, lse, T, H, scale, ksplit, part);
     TQ_CHECK_LAUNCH();
+    if (ksplit > 1) {
+        const size_t n = (size_t)B * H * T * (D / 4);
+        hipLaunchKernelGGL(attn_combine_kernel<D>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, out, lse, T, H, ksplit, n);
+        TQ_CHECK_LAUNCH();
+    }
     return 0;
 }
 }  // namespace
@@ -630,7 +697,12 @@ int launch_attn2(const float* qkv, float* out, float* lse, void* ws, int B, int 
 
 extern "C" size_t tq_attention_workspace_bytes(int B, int T, int H, int D) {
     const size_t Tp = (size_t)(T + 63) / 64 * 64;
-    return (size_t)B * H * 4 * Tp * D * 2;
+    const size_t planes = (size_t)B * H * 4 * Tp * D * 2;
+    if (D == 128) {   // (first-generation kernel: no planes; the partial rows of its key split)
+        const size_t part = (size_t)ATT_KSPLIT_MAX * B * H * T * (D + 4) * sizeof(float);
+        return part > planes ? part : planes;
+    }
+    return planes;
 }
 
 extern "C" int tq_attention_fwd(const float* qkv, float* out, float* lse, void* workspace, int B, int T, int H, int D,
@@ -640,7 +712,8 @@ extern "C" int tq_attention_fwd(const float* qkv, float* out, float* lse, void* 
     if (workspace) {
         if (D == 64) return launch_attn2<64>(qkv, out, lse, workspace, B, T, H, stream);
         if (D == 32) return launch_attn2<32>(qkv, out, lse, workspace, B, T, H, stream);
-        if (D != 128) return TQ_ERR_SHAPE;  // D = 128 (tiny config's middle block) stays on the first-generation kernel
+        if (D == 128) return launch_attn<128>(qkv, out, lse, B, T, H, stream, workspace);   // first-generation kernel (+ key split, round 6)
+        return TQ_ERR_SHAPE;
     }
     if (D == 64) return launch_attn<64>(qkv, out, lse, B, T, H, stream);
     if (D == 32) return launch_attn<32>(qkv, out, lse, B, T, H, stream);

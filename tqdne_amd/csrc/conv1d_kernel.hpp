@@ -797,18 +797,24 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2 && SCH == 0) ?
     // any workgroup size) -- writes them where the prologue below (and, later, the backward) reads them, and goes on; every workgroup of
     // a sample writes the same bits.  Replaces the tq_gn_finalize launch in front of this one: a launch-bound plan (<= 4 samples: ~100
     // dependent launches of 5-30 us) loses 45 % of its launches for ~3 us more in the prologue of each conv.
-    if constexpr (TBW == 2 && ACT >= 1 && !PW && EPI == 0) {
+#ifdef TQ_ABL_FOLD_EARLY   // (A/B build: the small tile of scheme 2 folds in front of its loads too, as until the end of round 6)
+    constexpr bool FOLD_EARLY = TBW == 2 && ACT >= 1 && !PW && EPI == 0;
+#else
+    constexpr bool FOLD_EARLY = TBW == 2 && SCH != 2 && ACT >= 1 && !PW && EPI == 0;   // (scheme 2 folds behind its first loads, below)
+#endif
+    if constexpr (FOLD_EARLY) {
         if (p.cf_st0) {   // (uniform over the launch)
             gn_fold_sample<false, false>(reinterpret_cast<double*>(lds), b, p.cf_st0, p.C0, p.cf_st1, p.C1, p.T_in, p.cf_ns0, p.cf_ns1, p.cf_gamma,
                                          p.cf_beta, const_cast<float*>(p.gscale), const_cast<float*>(p.gshift), p.cf_mean_rstd);
             __syncthreads();   // the coefficients (global) are read back by other threads; the LDS scratch becomes the staging buffers
         }
     }
-    // ... and for the default tiles of the fp16 + MX-fp6 scheme (TBW == 8; experiment, TQDNE_GN_FOLD=1): the fold runs AFTER the first
+    // ... and in the fp16 + MX-fp6 scheme (the small tile; the default tiles as an experiment, TQDNE_GN_FOLD=1): the fold runs AFTER the first
     // chunk's staging loads and the first weight fragments have been requested (gtab_store below), so that its statistics loads share
     // their round trip, and leaves the coefficients in the LDS table directly -- what it adds to a workgroup is its arithmetic and three
-    // barriers, not a global round trip.
-    constexpr bool FOLD_LATE = SCH == 2 && ACT >= 1 && !PW && EPI == 0 && TBW == 8;
+    // barriers, not a global round trip (the small tile folded in FRONT of its loads until the end of round 6: two round trips in a row
+    // in launches that are one dependent chain of latencies).
+    constexpr bool FOLD_LATE = SCH == 2 && ACT >= 1 && !PW && EPI == 0 && (TBW == 8 || TBW == 2) && !FOLD_EARLY;
     const bool fold_late = FOLD_LATE && p.cf_st0 != nullptr;
     float4 gt_a = make_float4(0.f, 0.f, 0.f, 0.f), gt_s = gt_a;
     int gt_i = 0;
@@ -1427,7 +1433,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     if (SCH == 2 && a.C0 + a.C1 > 1024) return TQ_ERR_SHAPE;
     if (a.cf_st0) {   // consumer-side GroupNorm fold: built into the small tile's forward launches; its scratch (2 C + 64 doubles) must fit the staging buffers
         constexpr bool built = (TBW == 2 && ACT >= 1 && !PW && EPI == 0) || (SCH == 2 && ACT >= 1 && !PW && EPI == 0 && TBW == 8);
-        if (!built || (size_t)(2 * (a.C0 + a.C1) + 64) * sizeof(double) > (size_t)LDS_BYTES) return TQ_ERR_SHAPE;
+        if (!built || (size_t)(2 * (a.C0 + a.C1) + 64) * sizeof(double) > (size_t)(LDS_BYTES - GTAB_MAX)) return TQ_ERR_SHAPE;   // (the table behind them is being written meanwhile)
     }
     // The dynamic-LDS limit is a per-device property of the kernel: remember, per device ordinal, that it has been raised
     // (idempotent call: two threads racing here both set the same value; the mask only saves the repeated runtime call).

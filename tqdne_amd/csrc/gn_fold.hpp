@@ -73,7 +73,13 @@ __device__ __forceinline__ void gn_fold_sample(double* sh, int b, const float* _
 #pragma unroll
             for (int u = 0; u < 8; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
         }
-        {   // up to 7 left: again all loads first (clamped index, masked add)
+#ifdef TQ_ABL_FOLD_REMAINDER   // (A/B build: the remainder batch always issued, as in rounds 3-5)
+        if (true) {
+#else
+        if (s < nslots) {
+#endif
+            // up to 7 left: again all loads first (clamped index, masked add).  (Round 6: skipped when nothing is left -- the
+            // clamped loads of an empty remainder were one more dependent global round trip in every fold.)
             float2 v[7];
 #pragma unroll
             for (int u = 0; u < 7; ++u) {
