@@ -4,7 +4,7 @@
 # one-lane sample (51 tq_gn_finalize launches per evaluation), alternated x 3 on one box.
 #   python -c "from tqdne_amd import _build; _build.build(force=True, extra_flags=('-DTQ_ABL_FOLD_REMAINDER',), out_name='libtq_fold_rem.so')"
 cd ${GRAFT_REPO_ROOT:-.}
-OUT=$PWD/gpurun_out/r06v; mkdir -p $OUT
+OUT=$PWD/gpurun_out/${R06_OUT:-r06v}; mkdir -p $OUT
 REM=$PWD/tqdne_amd/lib/libtq_fold_rem.so
 for rep in 1 2 3; do
   echo "== with-remainder rep=$rep" >> $OUT/ab.txt
