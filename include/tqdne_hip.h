@@ -342,7 +342,10 @@ int tq_linear_fwd(const float* x, const float* w, const float* bias, float* out,
 
 /* ---- attention -------------------------------------------------------------------------------------------- */
 /* QKVAttention (blocks.py:156-190), qkv (B, T, 3*H*D) channels-last with channel order [q heads | k heads | v heads],
- * q and k each scaled by D^-1/4, softmax over keys in fp32, out (B, T, H*D).  D in {32, 64, 128}. */
+ * q and k each scaled by D^-1/4, softmax over keys in fp32, out (B, T, H*D).  D in {32, 64, 128}.
+ * The workspace holds the pre-split K / V planes of the second-generation kernels (D = 32 / 64); for D = 128 (first-generation kernel)
+ * it holds the partial rows of the key split that kernel uses where its grid is far below the chip (round 6; without a workspace it
+ * never splits). */
 size_t tq_attention_workspace_bytes(int B, int T, int H, int D);
 int tq_attention_fwd(const float* qkv, float* out, float* lse /* (B,H,T) log-sum-exp per query, NULL at inference */,
                      void* workspace /* tq_attention_workspace_bytes(); NULL selects the workspace-free kernel */, int B, int T,
