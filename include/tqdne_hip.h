@@ -44,6 +44,11 @@ typedef struct ihipStream_t* hipStream_t;
  * statistics: 2*ceil(T_out/128) slots of C channels (slot = 2*tile + p; with TQ_CONV_STATS T_out must be a multiple of 128 or leave
  * more than 64 rows in its last tile, so that this equals the ceil(2*T_out/128) slots of the (B, 2*T_out, C) tensor). */
 #define TQ_CONV_POLY2 64
+/* TQ_CONV_CH_TILES (round 6): a hint of launch-bound plans (a grid far below the chip): where a conv has an input-stationary form with one
+ * workgroup per position tile (the qkv projection: C_out >= 512 over 128 / 256 input channels) take the channel-tiled form instead --
+ * C_out / 256 times the workgroups (a 16-sample plan alone on the device at T = 512: 64 -> 192; 37 -> 21 us).  Same numbers.  With the
+ * device full (B = 64, or four 16-sample lanes) the input-stationary form is the faster one (+0.7 % of a sample with this flag). */
+#define TQ_CONV_CH_TILES 128
 
 /* TqConvDesc.wfmt: how the fp32 product x * w is contracted on the matrix cores (= format of the packed weights).
  * BF16X3: both operands split into bf16 hi + lo, three bf16 MFMA products; fp32 range, ~2^-16 relative (pack modes 0 / 1).

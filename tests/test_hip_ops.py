@@ -395,6 +395,14 @@ def test_qkv_conv_feeding_the_presplit_attention(H, D, T, peaked):
         errs[vf16] = rel_err(out.cpu(), ref)
     print(f"attention pair H={H} D={D} T={T} peaked={peaked}: fp16 P / V {errs['1']:.2e}, bf16 hi / lo {errs['0']:.2e}")
     assert errs["1"] < 5e-4 and errs["0"] < 2e-4
+    # round 6: TQ_CONV_CH_TILES (the hint of launch-bound plans: channel-tiled instead of input-stationary form) -- the same q and planes
+    if 3 * Cc >= 512 and Cc in (128, 256) and wfmt == _lib.TQ_WFMT_F16_MX6:
+        qkv2, ws2 = torch.zeros_like(qkv), torch.zeros_like(ws)
+        desc.flags = 1 | _lib.TQ_CONV_CH_TILES
+        assert lib.tq_conv1d_fwd_qkv(C.byref(desc), p(xd), p(gsd), p(ghd), p(wp), p(bd), p(qkv2), p(ws2), H, D, vfmt, stream) == 0
+        desc.flags = 1
+        torch.cuda.synchronize()
+        assert torch.equal(qkv2[:, :, :Cc], qkv[:, :, :Cc]) and torch.equal(ws2, ws)
     # the V planes' range guard (ABI 6): a bias that lifts one V channel to 4e4 raises the flag in the fp16 format only
     if not peaked:
         big = bias.clone()

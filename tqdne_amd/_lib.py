@@ -18,6 +18,7 @@ SZ = C.c_size_t
 
 TQ_CONV_GN, TQ_CONV_SILU, TQ_CONV_EMB, TQ_CONV_RES, TQ_CONV_STATS, TQ_CONV_DROPOUT = 1, 2, 4, 8, 16, 32
 TQ_CONV_POLY2 = 64
+TQ_CONV_CH_TILES = 128
 TQ_WFMT_BF16X3, TQ_WFMT_F16_MX8, TQ_WFMT_F16_MX6 = 0, 1, 2
 TQ_KV_V_BF16, TQ_KV_V_F16 = 0, 1     # v_format of tq_conv1d_fwd_qkv / tq_attention_fwd_presplit
 PACK_MODE = {TQ_WFMT_BF16X3: 0, TQ_WFMT_F16_MX8: 2, TQ_WFMT_F16_MX6: 3}   # tq_pack_conv_weight mode of a forward weight format

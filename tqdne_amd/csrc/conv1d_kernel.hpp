@@ -1502,7 +1502,11 @@ int dispatch_tile(const ConvArgs& a, hipStream_t s) {
             if (a.C0 % 64 || a.C1 % 64 || a.sC0 % 64 || a.sC1 % 64) return TQ_ERR_SHAPE;
             if constexpr (KT == 1 && UPS == 0 && ACT <= 1) {
                 const int cin = a.C0 + a.C1;
-                if (a.C_out % 256 == 0 && a.C_out >= 512 && (cin == 128 || cin == 256))
+                // TQ_CONV_CH_TILES (round 6; TQDNE_QKV_PW=0 / 1 forces one form everywhere: A/B switch): launch-bound plans take the
+                // channel-tiled form for the qkv projection too -- three times the workgroups of the input-stationary one
+                static const int force = [] { const char* e = getenv("TQDNE_QKV_PW"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+                const bool pw = force >= 0 ? force == 1 : !(a.flags & TQ_CONV_CH_TILES);
+                if (pw && a.C_out % 256 == 0 && a.C_out >= 512 && (cin == 128 || cin == 256))
                     return launch<KT, STRIDE, UPS, 8, 1, EPI, ACT, FUSE, 2, true>(a, s);
             }
             // (256-channel outputs as two co-resident 4-wave workgroups instead of one 8-wave one: measured 2-8 % slower per layer)

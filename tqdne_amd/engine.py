@@ -522,6 +522,10 @@ class UNetEngine:
             assert res.C == site.C_out and res.T == T_out
         if stats:
             flags |= TQ_CONV_STATS
+        if site.K == 1 and (self.B <= SMALL_TILE_B or (self.solo and self.B * ((T_out + 127) // 128) <= SMALL_TILE_WGS)):
+            # launch-bound plans (the rule of the small tile): the qkv projection in its channel-tiled form -- the input-stationary one
+            # has ONE workgroup per 128 positions (a 16-sample plan at T = 512: 64 on 256 compute units; 37 -> 21 us)
+            flags |= _lib.TQ_CONV_CH_TILES
         d.flags = flags
         d.emb_stride = self.emb_total
         d.wfmt = wfmt
