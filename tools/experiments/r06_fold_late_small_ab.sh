@@ -4,7 +4,7 @@
 # B = 4) and the paper UNet at B = 4: 18-step sample, alternated x 3 on one box.
 #   python -c "from tqdne_amd import _build; _build.build(force=True, extra_flags=('-DTQ_ABL_FOLD_EARLY',), out_name='libtq_fold_early.so')"
 cd ${GRAFT_REPO_ROOT:-.}
-OUT=$PWD/gpurun_out/r06r; mkdir -p $OUT
+OUT=$PWD/gpurun_out/${R06_OUT:-r06r}; mkdir -p $OUT
 EARLY=$PWD/tqdne_amd/lib/libtq_fold_early.so
 for rep in 1 2 3; do
   echo "== early rep=$rep" >> $OUT/ab.txt

@@ -340,6 +340,14 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2 && SCH == 0) ?
     asm volatile("" : "+s"(nlog2e), "+s"(n4096));  // kept in an SGPR: a literal would split the packed multiply into two scalar-literal ones
 
     float* gtab = reinterpret_cast<float*>(lds + (PW ? 4 * C::BUF : C::LDS_BYTES));   // [Cin] scale, [Cin] shift of sample b
+    // bf16x3 small tile with the consumer-side GroupNorm fold (TqConvDesc.gn_fold): the fold runs behind the first chunk's loads and hands
+    // that chunk's coefficients over through the table (see FOLD_LATE below); later chunks read what it wrote to global memory
+#ifdef TQ_ABL_FOLD_EARLY
+    constexpr bool FOLD_LATE0 = false;
+#else
+    constexpr bool FOLD_LATE0 = SCH == 0 && TBW == 2 && ACT >= 1 && !PW && EPI == 0;
+#endif
+    const bool fold0_pending = FOLD_LATE0 && p.cf_st0 != nullptr;
     auto chunk_base2 = [&](int stage, int& cs) -> const float* __attribute__((always_inline)) {
         const bool sk = FUSE && stage >= nchunks;
         const int cb = (sk ? stage - nchunks : stage) * C::CH;
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2 && SCH == 0) ?
         const float* base = chunk_base(chunk, cs);
 #pragma unroll
         for (int it = 0; it < PRE; ++it) raw[it] = load_one(base, cs, it);
-        if (ACT >= 1) {  // folded GroupNorm coefficients of this thread's 4 channels (skip stages: clamped, unused)
+        if (ACT >= 1 && !(fold0_pending && chunk == 0)) {  // folded GroupNorm coefficients of this thread's 4 channels (skip stages: clamped, unused)
             const int cb = (chunk < nchunks ? chunk : nchunks - 1) * C::CH;
             g_a = *reinterpret_cast<const float4*>(p.gscale + (size_t)b * Cin + cb + 4 * m);
             g_s = *reinterpret_cast<const float4*>(p.gshift + (size_t)b * Cin + cb + 4 * m);
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBW == 4 && NCB == 2 && SCH == 0) ?
 #ifdef TQ_ABL_FOLD_EARLY   // (A/B build: the small tile of scheme 2 folds in front of its loads too, as until the end of round 6)
     constexpr bool FOLD_EARLY = TBW == 2 && ACT >= 1 && !PW && EPI == 0;
 #else
-    constexpr bool FOLD_EARLY = TBW == 2 && SCH != 2 && ACT >= 1 && !PW && EPI == 0;   // (scheme 2 folds behind its first loads, below)
+    constexpr bool FOLD_EARLY = TBW == 2 && SCH != 2 && ACT >= 1 && !PW && EPI == 0 && !FOLD_LATE0;   // (both schemes of the small tile fold behind their first loads, below)
 #endif
     if constexpr (FOLD_EARLY) {
         if (p.cf_st0) {   // (uniform over the launch)
@@ -914,6 +922,15 @@ next_pass:  // (PW only: a loop statement here costs the other instantiations re
             }
         }
         gtab_store();
+        if constexpr (FOLD_LATE0) {
+            if (fold0_pending) {   // (uniform over the launch)
+                gn_fold_sample<false, false>(reinterpret_cast<double*>(lds), b, p.cf_st0, p.C0, p.cf_st1, p.C1, p.T_in, p.cf_ns0, p.cf_ns1, p.cf_gamma,
+                                             p.cf_beta, const_cast<float*>(p.gscale), const_cast<float*>(p.gshift), p.cf_mean_rstd, gtab, gtab + Cin);
+                __syncthreads();   // table complete (it sits behind the staging buffers; the fold's scratch at the start of LDS is free again)
+                g_a = *reinterpret_cast<const float4*>(gtab + 4 * m);
+                g_s = *reinterpret_cast<const float4*>(gtab + Cin + 4 * m);
+            }
+        }
         stage_write(0, 0);
         __syncthreads();
 #ifdef TQ_STAMP
@@ -1428,8 +1445,9 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     using C = Cfg<KT, STRIDE, UPS, WM, WN, SCH, TBW, NCB>;
     auto kern = conv1d_mfma_kernel<KT, STRIDE, UPS, WM, WN, EPI, ACT, FUSE, SCH, PW, TBW, NCB>;
     // scheme 2 keeps the folded GroupNorm coefficients of the workgroup's sample behind the staging buffers (2 x C_in floats)
-    constexpr int GTAB_MAX = (SCH == 2 && ACT >= 1) ? 2 * 4 * 1024 : 0;   // room for C_in <= 1024
+    constexpr int GTAB_MAX = ((SCH == 2 && ACT >= 1) || (SCH == 0 && TBW == 2 && ACT >= 1 && !PW && EPI == 0)) ? 2 * 4 * 1024 : 0;   // room for C_in <= 1024
     constexpr int LDS_BYTES = (PW ? 4 * C::BUF : C::LDS_BYTES) + GTAB_MAX;
+    if (GTAB_MAX && a.cf_st0 && a.C0 + a.C1 > 1024) return TQ_ERR_SHAPE;
     if (SCH == 2 && a.C0 + a.C1 > 1024) return TQ_ERR_SHAPE;
     if (a.cf_st0) {   // consumer-side GroupNorm fold: built into the small tile's forward launches; its scratch (2 C + 64 doubles) must fit the staging buffers
         constexpr bool built = (TBW == 2 && ACT >= 1 && !PW && EPI == 0) || (SCH == 2 && ACT >= 1 && !PW && EPI == 0 && TBW == 8);
