@@ -103,6 +103,48 @@ def step_bytes(A, W, B, nfe, train=True, sample=True, ema=True):
     return ((3 * B * A + (13 if ema else 10) * W) if train else 0) + ((nfe * (B * A + W)) if sample else 0)
 
 
+def pmc_traffic_live(timeout_s=150):
+    """HBM bytes of ONE launch of the dominant conv (512 -> 256, k = 5, T = 1024, B = 64) measured in this run: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate passes with --kernel-trace only (MI355X_MICROARCH.md, HBM section), each around tools/bench_one.py in a
+    child process (started as a child, never exec'ed from this GPU-initialised process; the program itself follows ``--``).  gfx950
+    corrections: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (x 2), both counters are in KiB.  None when the
+    profiler is missing, this process is itself being profiled, or a pass fails -- the line then keeps the recorded file's value."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None   # (bench.py under rocprofv3, e.g. tools/profile.sh: no profiler inside a profiled process)
+    out = tempfile.mkdtemp(prefix="tqdne_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "bench_one.py"), "256", "256", "256", "5", "1024", "64", "5"]
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=timeout_s, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            got = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "conv1d_mfma" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        got.append(float(r["Counter_Value"]))
+            if not got:
+                return None
+            vals[ctr] = sum(got) / len(got)
+        rd, wr = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
+        return {"FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"], "hbm_read_bytes_corrected": rd,
+                "hbm_write_bytes": wr, "hbm_traffic_bytes_per_launch": rd + wr}
+    except Exception as e:   # (a reported extra: never takes the headline line down)
+        log(f"live PMC pass skipped: {e!r}")
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def hbm_block(nbytes, ms, note=None):
     gbps = nbytes / (ms * 1e-3) / 1e9
     d = dict(bound="hbm", achieved=gbps, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbps / HBM_PEAK_GBS, algorithmic_bytes_per_step=nbytes)
@@ -752,6 +794,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the same-run parity gate (it rides in the CPU-baseline child)")
     ap.add_argument("--no-tables", action="store_true", help="skip the per-class traced passes after the timed region")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (HBM traffic of the dominant conv, measured in this run)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gradient all-reduce after the backward instead of under it")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg0 / cfg3 extras of the headline run")
     ap.add_argument("--no-ema", action="store_true", help="train step without the EMA of the weights (the reference's 1-D trainer "
@@ -1059,6 +1102,17 @@ def main():
                                                   "the conv kernel template): traffic not reported")
             except Exception:
                 pass
+        if world == 1 and not args.no_pmc and args.config == "paper" and B == 64 and T == 4096 and args.mode == "step":
+            # ... and measured IN THIS RUN where the profiler is there (the file above is the builder's box): two more child processes
+            live = pmc_traffic_live()
+            if live is not None:
+                if roofline.get("traffic") is not None:
+                    roofline["traffic_recorded"] = {"bytes": roofline["traffic"], "source": roofline.get("traffic_source")}
+                roofline["traffic"] = live["hbm_traffic_bytes_per_launch"]
+                roofline["traffic_source"] = ("this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) around "
+                                              "tools/bench_one.py 256 256 256 5 1024 64 = the dominant launch alone; FETCH_SIZE x 2 (gfx950), KiB units")
+                roofline["traffic_counters"] = live
+                roofline["algorithmic_bytes_per_launch"] = 4 * 64 * 1024 * (512 + 256)
         nfe = 2 * args.sample_steps - 1
         n_fwd = (3 if do_train else 0) + (nfe if do_sample else 0) if cm is None else 1
         work_flop = B * flops_fwd * n_fwd
