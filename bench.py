@@ -103,7 +103,7 @@ def step_bytes(A, W, B, nfe, train=True, sample=True, ema=True):
     return ((3 * B * A + (13 if ema else 10) * W) if train else 0) + ((nfe * (B * A + W)) if sample else 0)
 
 
-def pmc_traffic_live(timeout_s=150):
+def pmc_traffic_live(timeout_s=60):
     """HBM bytes of ONE launch of the dominant conv (512 -> 256, k = 5, T = 1024, B = 64) measured in this run: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate passes with --kernel-trace only (MI355X_MICROARCH.md, HBM section), each around tools/bench_one.py in a
     child process (started as a child, never exec'ed from this GPU-initialised process; the program itself follows ``--``).  gfx950
