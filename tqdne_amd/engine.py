@@ -90,10 +90,8 @@ SMALL_TILE_WGS = int(os.environ.get("TQDNE_SMALL_TILE_WGS", "64")) if os.environ
 # Round 6: a small-tile conv folds its own GroupNorm (TqConvDesc.gn_fold, consumer side) instead of a tq_gn_finalize launch in front of it:
 # a plan of <= 4 samples is ~100 dependent launches of 5-30 us, and 45 % of them were these.  TQDNE_GN_FOLD_SMALL=0: the launches.
 GN_FOLD_SMALL = os.environ.get("TQDNE_GN_FOLD_SMALL", "1") != "0"
-# ... and the default tiles of the fp16 + MX-fp6 scheme, with the fold behind the first chunk's loads (bit-identical): on by default since the
-# end of round 6 -- the whole B = 64 bench step alternated five times on one box: +0.46 % waveforms/s, five of five (sample -1.0 %, train
-# step -0.4 %; profiles/r06_m_*).  TQDNE_GN_FOLD=0: the tq_gn_finalize launches.
-GN_FOLD_DEFAULT = os.environ.get("TQDNE_GN_FOLD", "1") != "0"
+# ... and (experiment) the default tiles of the fp16 + MX-fp6 scheme, with the fold behind the first chunk's loads: TQDNE_GN_FOLD=1
+GN_FOLD_DEFAULT = os.environ.get("TQDNE_GN_FOLD", "0") == "1"
 CONCURRENT_LANE0 = 8   # plan-cache lane ids from here on: sub-batch plans that run concurrently (see UNetModel._engine)
 
 
